@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: bsw 'large' GCUPS on N MI355X (BASELINE.json).
+
+A step = one pass of the bsw hot path (gbx_bsw_extend_device: classify + every row kernel)
+over this rank's shard of the synthetic bsw-large pair set, inputs resident in HBM.
+Pairs are independent, so ranks shard them with no data-path collective ("weak": per-GPU
+work fixed).  value = nominal DP cells (sum len1*len2, main_banded.cpp:183) of ALL ranks
+per second of the slowest rank, in GCUPS.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+CLASS_OF_KERNEL = {"bsw_rows_16x2": (1, 32), "bsw_rows_16x4": (33, 64), "bsw_rows_16x8": (65, 128),
+                   "bsw_rows_16x16": (129, 256), "bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)}
+
+
+def cpu_baseline(batch, params, max_pairs):
+    """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
+    else the oracle restatement (kind 'port'); all host cores; bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    cores = os.cpu_count() or 1
+    n = min(batch.n, max_pairs)
+    sample = batch.slice(0, n)
+    kind = "port"
+    t0 = time.perf_counter()
+    ref = O.ref_lib("bsw")
+    if ref is not None and hasattr(ref, "ref_bsw_getscores16_mt"):
+        import ctypes as C
+        out = np.zeros((n, 6), dtype=np.int32)
+        t0 = time.perf_counter()
+        ref.ref_bsw_getscores16_mt(*O._bsw_args(params, sample, out), C.c_int32(512), C.c_int32(cores))
+        kind = "reference"
+    else:
+        O.bsw_oracle(params, sample, cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+            "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" %
+                      (n, "reference AVX2 getScores16 -b 512, one object per thread" if kind == "reference"
+                       else "oracle/bsw_oracle.c scalar restatement, OpenMP", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=2_000_000, help="pairs per GPU (bsw 'large' = 2M, seed 1002)")
+    ap.add_argument("--cpu-pairs", type=int, default=1_000_000, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from genomicsbench_amd import _native as N
+    from genomicsbench_amd.bsw import DeviceBswBatch, make_params
+    from genomicsbench_amd.datagen import gen_bsw
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libgbx has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    params = make_params()
+    batch = gen_bsw(args.pairs, 1002, first=rank * args.pairs)       # this rank's shard
+    dbatch = DeviceBswBatch(batch, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    for _ in range(args.warmup):
+        dbatch.run(params, stream)
+    barrier()
+    N.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dbatch.run(params, stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = N.profile_end()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cells = torch.tensor([float(batch.nominal_cells)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cells, op=dist.ReduceOp.SUM)
+    dt_max, total_cells = float(t.item()), float(cells.item())
+
+    if rank == 0:
+        # roofline of the dominant kernel: algorithmic bytes of the pairs it processes / its mean duration
+        name, (ms_sum, launches) = max(stages.items(), key=lambda kv: kv[1][0])
+        lo, hi = CLASS_OF_KERNEL.get(name, (1, 1 << 30))
+        sel = (batch.len2 >= lo) & (batch.len2 <= hi)
+        alg_bytes = int(batch.len1[sel].astype(np.int64).sum() + batch.len2[sel].astype(np.int64).sum() + 36 * sel.sum())
+        k_ms = ms_sum / max(launches, 1)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "bsw_large_gcups", "value": total_cells * args.steps / dt_max / 1e9, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), "
+                                   "nominal cells = sum len1*len2" % args.pairs,
+                       "pairs_per_gpu": args.pairs, "nominal_cells_per_gpu": batch.nominal_cells,
+                       "parallelism": "pairs sharded over %d rank(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "cells_per_s_dominant_kernel": float((batch.len1[sel].astype(np.int64) * batch.len2[sel]).sum()) / (k_ms * 1e-3)},
+            "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_pairs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,539 @@
+// bsw_kernels.hip — banded Smith-Waterman seed extension for gfx950 (MI355X).
+//
+// Semantics: BandedPairWiseSW::scalarBandedSWA, R/benchmarks/bsw/bandedSWA.cpp:128-249
+// (bwa ksw_extend2), bit-exact on all six outputs.  The driver's entry point
+// getScores16 (bandedSWA.cpp:1124-1148) is what gbx_bsw_extend_* replaces.
+//
+// Design: the DP is a row-sequential state machine (band clip,
+// zero-row exit, z-drop on the LAST arg-max, window narrowing) so the row is
+// the unit of parallelism.  A *group* of LPP lanes owns one pair; each lane
+// keeps CPL consecutive columns of the reference's eh[] array (h and e planes)
+// in registers for the whole extension.  Within a row
+//     M(j), E'(j)          depend only on the previous row    -> element-wise
+//     F(j+1)=max(F(j)-e, max(M(j)-oe,0))                      -> max-plus prefix scan
+// The in-lane part of the scan is serial over CPL columns; the cross-lane part
+// is 4 DPP row_shr steps (16-lane DPP rows are exactly one group for LPP=16,
+// so four pairs run per wavefront with no cross-talk).  Row max / last arg-max,
+// first / last live column and the global-score cell are DPP all-reduces.
+// No LDS, no MFMA.  Long queries (qlen > 1024) use the one-pair-per-wavefront
+// LDS-staged kernel at the bottom of this file.
+//
+// State invariants relied on (proved in DESIGN.md, checked by the adversarial
+// tests): cells right of the live window are either never written (first-row
+// initial values, E=0) or hold zeros; cells left of it are never read again.
+#include "gbx_internal.h"
+
+namespace gbx {
+namespace {
+
+constexpr int NEG = -(1 << 29);
+constexpr int BIGJ = 1 << 20;
+
+// qlen classes -> kernel shapes
+constexpr int NCLS = 6;      // 0:(16,2) 1:(16,4) 2:(16,8) 3:(16,16) 4:(64,16) 5:LDS general
+constexpr int REG_SCORE_LIMIT = 1 << 20;   // register kernels pack (h<<10|j) in 31 bits
+
+struct BswDev {
+    int o_del, e_del, o_ins, e_ins, oe_del, oe_ins, zdrop, end_bonus, w, max_mat;
+    uint32_t colword[5];   // colword[q] = bytes mat[0][q], mat[1][q], mat[2][q], mat[3][q]
+    int32_t col4[5];       // col4[q]    = mat[4][q]
+};
+
+struct BswPairs {
+    const uint8_t *ref, *qer;
+    const int64_t *idr, *idq;
+    const int32_t *len1, *len2, *h0;
+    gbx_bsw_result *out;
+};
+
+// workspace layout (ints): [0..NCLS) counts, [8..8+NCLS) cursors, [16] bad-pair count,
+// then order[n]
+struct BswWork {
+    int32_t *counts, *cursors, *bad, *order;
+};
+
+__host__ __device__ inline int cls_of(int qlen, int bound)
+{
+    if (qlen > 1024 || bound >= REG_SCORE_LIMIT) return 5;
+    if (qlen <= 32) return 0;
+    if (qlen <= 64) return 1;
+    if (qlen <= 128) return 2;
+    if (qlen <= 256) return 3;
+    return 4;
+}
+
+__device__ inline int imax3(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int CTRL, int ROWMASK = 0xf>
+__device__ inline int dpp(int old, int x)
+{
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xf, false);
+}
+
+// ---- group primitives -----------------------------------------------------
+// inclusive prefix max over the LPP lanes of a group (identity NEG)
+template <int LPP>
+__device__ inline int group_scan_max(int x)
+{
+    x = max(x, dpp<0x111>(NEG, x));
+    x = max(x, dpp<0x112>(NEG, x));
+    x = max(x, dpp<0x114>(NEG, x));
+    x = max(x, dpp<0x118>(NEG, x));
+    if (LPP >= 32) x = max(x, dpp<0x142, 0xa>(NEG, x));   // row_bcast15 -> rows 1,3
+    if (LPP >= 64) x = max(x, dpp<0x143, 0xc>(NEG, x));   // row_bcast31 -> rows 2,3
+    return x;
+}
+
+// value of the previous lane of the group; lane 0 of the group gets `fill`
+template <int LPP>
+__device__ inline int group_shift_up(int x, int fill, int gl)
+{
+    if (LPP == 16) return dpp<0x111>(fill, x);            // row_shr:1, old = fill
+    int y = dpp<0x138>(fill, x);                          // wave_shr:1
+    return gl == 0 ? fill : y;
+}
+
+// all-reduce max over the group; every lane gets the result
+template <int LPP>
+__device__ inline int group_allmax(int x)
+{
+    if (LPP == 16) {
+        x = max(x, dpp<0x121>(x, x));                     // row_ror:1,2,4,8
+        x = max(x, dpp<0x122>(x, x));
+        x = max(x, dpp<0x124>(x, x));
+        x = max(x, dpp<0x128>(x, x));
+        return x;
+    }
+    x = max(x, dpp<0x111>(x, x));
+    x = max(x, dpp<0x112>(x, x));
+    x = max(x, dpp<0x114>(x, x));
+    x = max(x, dpp<0x118>(x, x));
+    x = max(x, dpp<0x142, 0xa>(x, x));
+    if (LPP == 32) {
+        int a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63);
+        return (threadIdx.x & 32) ? b : a;
+    }
+    x = max(x, dpp<0x143, 0xc>(x, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// ---- classify / bin pairs by query length ----------------------------------
+// Degenerate pairs (len 0) are answered here; bad pairs (negative or too long)
+// get -1 outputs and bump work.bad.
+__global__ void __launch_bounds__(256) bsw_classify_kernel(BswDev prm, BswPairs P, int64_t n, BswWork W, int pass)
+{
+    __shared__ int lcount[NCLS];
+    __shared__ int lbase[NCLS];
+    const int tid = threadIdx.x;
+    if (tid < NCLS) lcount[tid] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * 256 + tid;
+    int cls = -1, slot = 0;
+    if (k < n) {
+        const int qlen = P.len2[k], tlen = P.len1[k], h0 = P.h0[k];
+        if (qlen < 0 || tlen < 0 || qlen > GBX_BSW_MAX_QLEN || tlen > GBX_BSW_MAX_TLEN) {
+            if (pass == 0) {
+                gbx_bsw_result r = {-1, -1, -1, -1, -1, -1};
+                P.out[k] = r;
+                atomicAdd(W.bad, 1);
+            }
+        } else if (tlen == 0 || qlen == 0) {
+            if (pass == 0) {
+                // scalarBandedSWA with an empty matrix: no row at all (tlen==0), or one row
+                // with an empty window that only updates gscore (qlen==0), bandedSWA.cpp:174-218
+                gbx_bsw_result r;
+                r.score = h0; r.tle = 0; r.qle = 0; r.max_off = 0;
+                if (tlen == 0) { r.gtle = 0; r.gscore = -1; }
+                else { int left = max(h0 - (prm.o_del + prm.e_del), 0); r.gtle = 1; r.gscore = max(-1, left); }
+                P.out[k] = r;
+            }
+        } else {
+            const int bound = max(h0, 0) + qlen * max(prm.max_mat, 0);
+            cls = cls_of(qlen, bound);
+            slot = atomicAdd(&lcount[cls], 1);
+        }
+    }
+    __syncthreads();
+    if (pass == 0) {
+        if (tid < NCLS && lcount[tid]) atomicAdd(&W.counts[tid], lcount[tid]);
+        return;
+    }
+    if (tid < NCLS) {
+        int base = 0;
+        for (int c = 0; c < tid; ++c) base += W.counts[c];
+        lbase[tid] = lcount[tid] ? base + atomicAdd(&W.cursors[tid], lcount[tid]) : 0;
+    }
+    __syncthreads();
+    if (cls >= 0) W.order[lbase[cls] + slot] = (int)k;
+}
+
+// ---- register-resident row kernel ------------------------------------------
+template <int LPP, int CPL>
+__global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
+{
+    constexpr int KB = 10;                       // bits for the column index in the row key
+    constexpr int GROUPS_PER_BLOCK = 256 / LPP;
+    static_assert(LPP * CPL <= (1 << KB), "column index must fit the key");
+    static_assert(CPL <= 16, "in-lane column index uses 4 bits");
+
+    const int tid = threadIdx.x;
+    const int gl = tid & (LPP - 1);
+    const int j0 = gl * CPL;
+    const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
+    int next = blockIdx.x * GROUPS_PER_BLOCK + tid / LPP;
+
+    int cnt = W.counts[cls], first = 0;
+    for (int c = 0; c < cls; ++c) first += W.counts[c];
+    const int32_t *order = W.order + first;
+
+    const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
+    const int lane_tilt = gl * (CPL * e_ins);
+
+    int Hs[CPL], Ev[CPL], P4[CPL];
+    uint32_t Pw[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { Hs[c] = 0; Ev[c] = 0; P4[c] = 0; Pw[c] = 0; }
+
+    // group-uniform state (replicated in every lane of the group)
+    int qlen = 1, tlen = 1, h0 = 0, w = 0, beg = 0, end = 0, i = 0, pair = 0;
+    int best = 0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
+    const uint8_t *tptr = P.ref;
+    int tcur = 0, tnext = 0;
+    bool active = false, done = false;
+
+    for (;;) {
+        if (done) {                                                   // retire
+            if (gl == 0) {
+                gbx_bsw_result r;
+                r.score = best; r.tle = best_i + 1; r.gtle = g_i + 1; r.qle = best_j + 1;
+                r.gscore = g_score; r.max_off = off;
+                P.out[pair] = r;
+            }
+            done = false; active = false;
+            tptr = P.ref; tlen = 1; i = 0;
+        }
+        if (!active && next < cnt) {                                  // fetch + first row (:155-168)
+            pair = order[next];
+            next += ngroups;
+            qlen = P.len2[pair]; tlen = P.len1[pair]; h0 = P.h0[pair];
+            const uint8_t *q = P.qer + P.idq[pair];
+            tptr = P.ref + P.idr[pair];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = j0 + c;
+                int qc = j < qlen ? q[j] : 0;
+                qc = min(qc, 4);
+                uint32_t pw = prm.colword[0]; int p4 = prm.col4[0];
+                pw = qc == 1 ? prm.colword[1] : pw; p4 = qc == 1 ? prm.col4[1] : p4;
+                pw = qc == 2 ? prm.colword[2] : pw; p4 = qc == 2 ? prm.col4[2] : p4;
+                pw = qc == 3 ? prm.colword[3] : pw; p4 = qc == 3 ? prm.col4[3] : p4;
+                pw = qc == 4 ? prm.colword[4] : pw; p4 = qc == 4 ? prm.col4[4] : p4;
+                Pw[c] = pw; P4[c] = p4;
+                Hs[c] = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
+                Ev[c] = 0;
+            }
+            {   // band clamp, :159-168
+                int lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_ins) / (double)e_ins + 1.);
+                lim = max(lim, 1);
+                w = min(prm.w, lim);
+                lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_del) / (double)e_del + 1.);
+                lim = max(lim, 1);
+                w = min(w, lim);
+            }
+            best = h0; best_i = -1; best_j = -1; g_i = -1; g_score = -1; off = 0;
+            beg = 0; end = qlen; i = 0;
+            tcur = tptr[0];
+            tnext = tptr[min(1, tlen - 1)];
+            active = true;
+        }
+        if (!__any(active)) break;
+
+        // ------------------------------------------------------------ one row
+        const int b = max(beg, i - w);                                 // :179-181
+        const int e = min(min(end, i + w + 1), qlen);
+        const int left0 = b == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;   // :183-186
+        const int lo = b - j0, hi = e - j0;
+        const int t = min(tcur, 4);
+        tcur = tnext;
+        tnext = tptr[min(i + 2, tlen - 1)];
+        const int t8 = t << 3;
+        const bool t4 = t == 4;
+
+        int M[CPL], Ein[CPL], Fl[CPL], Hc[CPL];
+        int lf = NEG;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool p = (c >= lo) & (c < hi);
+            const int s = t4 ? P4[c] : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+            const int hsv = Hs[c];
+            const int m = (p & (hsv != 0)) ? hsv + s : 0;              // :196
+            const int ein = p ? Ev[c] : 0;
+            M[c] = m; Ein[c] = ein; Fl[c] = lf;
+            lf = imax3(lf - e_ins, m - oe_ins, 0);                     // F(i,j+1), :207-210
+            Ev[c] = imax3(ein - e_del, m - oe_del, 0);                 // E(i+1,j), :202-206
+        }
+        // cross-lane part of the F scan: carry-out of lane l, tilted by l*CPL*e_ins
+        int carry = group_scan_max<LPP>(lf + lane_tilt) - lane_tilt;
+        int X = group_shift_up<LPP>(carry, NEG, gl);                   // F entering this lane's column 0
+
+        int kl = 0, hl = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int f = max(Fl[c], X);
+            X -= e_ins;
+            int h = imax3(M[c], Ein[c], f);                            // :197-198
+            const bool pr = c < hi;
+            hl = pr ? h : hl;                                          // h of the last live column in this lane
+            h = pr ? h : 0;
+            Hc[c] = h;
+            kl = max(kl, (h << 4) | c);
+        }
+        // shifted store: eh[j].h <- H(i,j-1); column 0 takes the first-column value
+        const int hin = group_shift_up<LPP>(Hc[CPL - 1], left0, gl);
+        unsigned zm = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int hs = c == 0 ? hin : Hc[c - 1];
+            const unsigned nz = min((unsigned)(hs | Ev[c]), 1u);
+            zm |= nz << c;
+            Hs[c] = (c <= hi) ? hs : Hs[c];
+        }
+
+        // group reductions
+        const int key = group_allmax<LPP>(((kl >> 4) << KB) | (j0 + (kl & 15)));
+        const int m = key >> KB, mj = key & ((1 << KB) - 1);
+        const int zf_l = zm ? j0 + (__builtin_ffs((int)zm) - 1) : BIGJ;
+        const int zl_l = zm ? j0 + (31 - __builtin_clz(zm)) : -1;
+        const int zfirst = BIGJ - group_allmax<LPP>(BIGJ - zf_l);
+        const int zlast = group_allmax<LPP>(zl_l);
+        const int le = (e - 1) / CPL;                                  // lane holding column e-1 (e>=1 when b<e)
+        const int hsel = group_allmax<LPP>(gl == le ? hl : 0);
+
+        // row epilogue, :213-233
+        const bool live = b < e;
+        const int jfin = live ? e : b;
+        const int hend = live ? hsel : left0;
+        if (jfin == qlen) {                                            // :214-217
+            g_i = g_score > hend ? g_i : i;
+            g_score = max(g_score, hend);
+        }
+        bool brk = m == 0;                                             // :218
+        if (!brk) {
+            if (m > best) {                                            // :219-221
+                best = m; best_i = i; best_j = mj;
+                off = max(off, abs(mj - i));
+            } else if (prm.zdrop > 0) {                                // :222-228
+                const int di = i - best_i, dj = mj - best_j;
+                const int pen = di > dj ? (di - dj) * e_del : (dj - di) * e_ins;
+                brk = best - m - pen > prm.zdrop;
+            }
+        }
+        beg = min(zfirst, e);                                          // :230-233
+        end = min(zlast + 2, qlen);
+        ++i;
+        done = active & (brk | (i >= tlen));
+    }
+}
+
+// ---- one pair per wavefront, row staged in LDS (long queries) ---------------
+// hd[] / ev[] planes of eh[] live in LDS (int32), columns are swept in 64-wide
+// chunks with the F carry and the running reductions handed from chunk to chunk.
+__global__ void __launch_bounds__(64) bsw_lds_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
+{
+    extern __shared__ int lds[];
+    const int lane = threadIdx.x;
+    int cnt = W.counts[cls], first = 0;
+    for (int c = 0; c < cls; ++c) first += W.counts[c];
+    const int32_t *order = W.order + first;
+    const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
+
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
+        const int pair = order[slot];
+        const int qlen = P.len2[pair], tlen = P.len1[pair], h0 = P.h0[pair];
+        const uint8_t *q = P.qer + P.idq[pair];
+        const uint8_t *tp = P.ref + P.idr[pair];
+        int *hd = lds, *ev = lds + (qlen + 1);
+        for (int j = lane; j <= qlen; j += 64) {
+            hd[j] = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
+            ev[j] = 0;
+        }
+        __syncthreads();
+        int w;
+        {
+            int lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_ins) / (double)e_ins + 1.);
+            lim = max(lim, 1); w = min(prm.w, lim);
+            lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_del) / (double)e_del + 1.);
+            lim = max(lim, 1); w = min(w, lim);
+        }
+        int best = h0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
+        int beg = 0, end = qlen;
+        for (int i = 0; i < tlen; ++i) {
+            const int b = max(beg, i - w);
+            const int e = min(min(end, i + w + 1), qlen);
+            const int left0 = b == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;
+            const int t = min((int)tp[i], 4);
+            int fcarry = NEG;           // F entering the chunk's first column
+            int left = left0;           // H(i, j-1) entering the chunk's first column
+            int m = 0, mj = -1;
+            int zfirst = BIGJ, zlast = -1;
+            if (left0 != 0) { zfirst = b; zlast = b; }       // eh[beg].h = left0
+            for (int cb = b; cb < e; cb += 64) {
+                const int j = cb + lane;
+                const bool p = j < e;
+                const int qc = p ? min((int)q[j], 4) : 0;
+                const int s = t == 4 ? prm.col4[qc] : (int)(int8_t)(prm.colword[qc] >> (t << 3));
+                const int hsv = p ? hd[j] : 0;
+                const int ein = p ? ev[j] : 0;
+                const int mm = (p & (hsv != 0)) ? hsv + s : 0;
+                // F via tilted prefix max over the chunk
+                const int src = p ? max(mm - oe_ins, 0) : NEG;          // contributes to F at j+1
+                int pre = group_scan_max<64>(src + lane * e_ins);       // inclusive, tilted
+                int fincl = pre - lane * e_ins;                         // F(j+1) from in-chunk sources
+                int fexcl = group_shift_up<64>(fincl, NEG, lane);       // F(j) from in-chunk sources
+                fexcl = lane == 0 ? NEG : fexcl - 0;                    // (shift fills NEG)
+                // decay the in-chunk value by one column: fincl is F at j+1, shift gives F at j for this lane
+                const int f = max(fexcl, fcarry - lane * e_ins);
+                int h = imax3(mm, ein, f);
+                h = p ? h : 0;
+                const int enew = imax3(ein - e_del, mm - oe_del, 0);
+                // carry to the next chunk: F at column cb+64
+                {
+                    const int tot = __builtin_amdgcn_readlane(fincl, 63);
+                    fcarry = max(tot, fcarry - 64 * e_ins);
+                }
+                // shifted h store
+                int hprev = group_shift_up<64>(h, left, lane);
+                hprev = lane == 0 ? left : hprev;
+                left = __builtin_amdgcn_readlane(h, 63);                // may be masked 0 beyond e; fixed below
+                if (p) { hd[j] = hprev; ev[j] = enew; }
+                // reductions
+                {
+                    const int hm = group_allmax<64>(h);
+                    if (hm >= m && (hm > 0 || m == 0)) {
+                        // last column with h == hm inside this chunk
+                        const unsigned long long eq = __ballot(p && h == hm);
+                        if (eq) { mj = cb + 63 - __builtin_clzll(eq); m = hm; }
+                    }
+                    const unsigned long long nzh = __ballot(p && h != 0);      // hd[j+1] != 0
+                    const unsigned long long nze = __ballot(p && enew != 0);   // ev[j] != 0
+                    if (nzh) {
+                        zfirst = min(zfirst, cb + (int)__builtin_ctzll(nzh) + 1);
+                        zlast = max(zlast, cb + 63 - (int)__builtin_clzll(nzh) + 1);
+                    }
+                    if (nze) {
+                        zfirst = min(zfirst, cb + (int)__builtin_ctzll(nze));
+                        zlast = max(zlast, cb + 63 - (int)__builtin_clzll(nze));
+                    }
+                }
+                // h of the last live column (column e-1) for eh[end] / gscore
+                if (cb + 64 >= e) left = __builtin_amdgcn_readlane(h, (e - 1 - cb) & 63);
+            }
+            // eh[end] = {left, 0}
+            if (lane == 0) { hd[e] = b < e ? left : left0; ev[e] = 0; }
+            __syncthreads();
+            const int hend = b < e ? left : left0;
+            const int jfin = b < e ? e : b;
+            if (jfin == qlen) { g_i = g_score > hend ? g_i : i; g_score = max(g_score, hend); }
+            if (m == 0) break;
+            if (m > best) {
+                best = m; best_i = i; best_j = mj; off = max(off, abs(mj - i));
+            } else if (prm.zdrop > 0) {
+                const int di = i - best_i, dj = mj - best_j;
+                const int pen = di > dj ? (di - dj) * e_del : (dj - di) * e_ins;
+                if (best - m - pen > prm.zdrop) break;
+            }
+            beg = min(zfirst, e);
+            end = min(zlast + 2, qlen);
+        }
+        if (lane == 0) {
+            gbx_bsw_result r;
+            r.score = best; r.tle = best_i + 1; r.gtle = g_i + 1; r.qle = best_j + 1;
+            r.gscore = g_score; r.max_off = off;
+            P.out[pair] = r;
+        }
+        __syncthreads();
+    }
+}
+
+int make_dev_params(const gbx_bsw_params *p, BswDev *d)
+{
+    if (p->e_del < 1 || p->e_ins < 1 || p->o_del < 0 || p->o_ins < 0 || p->e_del > 4096 || p->e_ins > 4096 ||
+        p->o_del > (1 << 16) || p->o_ins > (1 << 16) || p->w < 0) {
+        set_error("bsw: gap penalties must satisfy 0<=o<=65536, 1<=e<=4096, w>=0");
+        return GBX_ERR_ARG;
+    }
+    d->o_del = p->o_del; d->e_del = p->e_del; d->o_ins = p->o_ins; d->e_ins = p->e_ins;
+    d->oe_del = p->o_del + p->e_del; d->oe_ins = p->o_ins + p->e_ins;
+    d->zdrop = p->zdrop; d->end_bonus = p->end_bonus; d->w = p->w;
+    int mx = 0;
+    for (int k = 0; k < 25; ++k) mx = p->mat[k] > mx ? p->mat[k] : mx;   // bandedSWA.cpp:160-162
+    d->max_mat = mx;
+    for (int q = 0; q < 5; ++q) {
+        uint32_t wv = 0;
+        for (int t = 0; t < 4; ++t) wv |= (uint32_t)(uint8_t)p->mat[t * 5 + q] << (8 * t);
+        d->colword[q] = wv;
+        d->col4[q] = p->mat[4 * 5 + q];
+    }
+    return GBX_OK;
+}
+
+}  // namespace
+
+size_t bsw_workspace_bytes(int64_t n)
+{
+    return (size_t)(32 + (n > 0 ? n : 0)) * sizeof(int32_t);
+}
+
+int bsw_launch(const gbx_bsw_params *p, int64_t n,
+               const uint8_t *d_ref, const uint8_t *d_qer,
+               const int64_t *d_idr, const int64_t *d_idq,
+               const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s)
+{
+    if (n == 0) return GBX_OK;
+    if (n > 0x7fffffffLL - 1024) { set_error("bsw: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
+    if (work_bytes < bsw_workspace_bytes(n)) { set_error("bsw: workspace too small"); return GBX_ERR_ARG; }
+    BswDev dev;
+    int rc = make_dev_params(p, &dev);
+    if (rc) return rc;
+    BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
+    int32_t *wi = (int32_t *)d_work;
+    BswWork W = {wi, wi + 8, wi + 16, wi + 32};
+    GBX_HIP(hipMemsetAsync(d_work, 0, 32 * sizeof(int32_t), s));
+    const int cblocks = (int)((n + 255) / 256);
+    {
+        Stage st("bsw_classify", s);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(256), 0, s, dev, P, n, W, 0);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(256), 0, s, dev, P, n, W, 1);
+    }
+
+    int dev_id = 0, cus = 256;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    // persistent groups: enough blocks to fill the chip, never more groups than pairs
+    auto grid_for = [&](int groups_per_block, int blocks_per_cu) {
+        int64_t want = (n + groups_per_block - 1) / groups_per_block;
+        int64_t cap = (int64_t)cus * blocks_per_cu;
+        return (int)(want < cap ? want : cap);
+    };
+    { Stage st("bsw_rows_16x2", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 2>), dim3(grid_for(16, 8)), dim3(256), 0, s, dev, P, W, 0); }
+    { Stage st("bsw_rows_16x4", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 4>), dim3(grid_for(16, 8)), dim3(256), 0, s, dev, P, W, 1); }
+    { Stage st("bsw_rows_16x8", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 8>), dim3(grid_for(16, 6)), dim3(256), 0, s, dev, P, W, 2); }
+    { Stage st("bsw_rows_16x16", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 16>), dim3(grid_for(16, 3)), dim3(256), 0, s, dev, P, W, 3); }
+    { Stage st("bsw_rows_64x16", s); hipLaunchKernelGGL((bsw_rows_kernel<64, 16>), dim3(grid_for(4, 3)), dim3(256), 0, s, dev, P, W, 4); }
+    {
+        const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            GBX_HIP(hipFuncSetAttribute((const void *)bsw_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        int blocks = (int)(n < (int64_t)cus * 2 ? n : (int64_t)cus * 2);
+        Stage st("bsw_lds", s);
+        hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, 5);
+    }
+    GBX_HIP(hipGetLastError());
+    return GBX_OK;
+}
+
+}  // namespace gbx

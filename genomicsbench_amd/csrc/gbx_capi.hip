@@ -1,0 +1,308 @@
+// gbx_capi.hip — the extern "C" boundary of libgbx.so (see include/gbx.h).
+// Host-buffer entry points stage through device memory here; there is no CPU
+// compute path in this library: without a HIP device every compute entry
+// returns GBX_ERR_NO_DEVICE.
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include "gbx_internal.h"
+
+namespace gbx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? GBX_ERR_NOMEM : GBX_ERR_HIP;
+}
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (libgbx has no CPU fallback)");
+        return GBX_ERR_NO_DEVICE;
+    }
+    return GBX_OK;
+}
+
+// ---- stage profiler ---------------------------------------------------------
+struct StageRec { const char *name; hipEvent_t a, b; };
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<StageRec> g_prof;
+
+Stage::Stage(const char *name, hipStream_t s) : slot_(-1), s_(s)
+{
+    if (!g_prof_on) return;
+    StageRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+    slot_ = (int)g_prof.size() - 1;
+}
+Stage::~Stage()
+{
+    if (slot_ >= 0) (void)hipEventRecord(g_prof[slot_].b, s_);
+}
+
+// RAII device buffer for the *_host entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes + 64);   // 64 B slack: kernels may read a few bytes past the last base
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        return GBX_OK;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+
+}  // namespace gbx
+
+using namespace gbx;
+
+struct gbx_timer {
+    hipEvent_t a, b;
+};
+
+extern "C" {
+
+const char *gbx_version(void) { return "gbx 0.1.0 (gfx950)"; }
+const char *gbx_last_error(void) { return g_err; }
+
+int gbx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int gbx_set_device(int dev)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    GBX_HIP(hipSetDevice(dev));
+    return GBX_OK;
+}
+
+int gbx_device_name(char *buf, size_t cap)
+{
+    if (!buf || cap == 0) { set_error("gbx_device_name: null buffer"); return GBX_ERR_ARG; }
+    int rc = require_device();
+    if (rc) return rc;
+    int dev = 0;
+    GBX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    GBX_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return GBX_OK;
+}
+
+int gbx_timer_create(gbx_timer **t)
+{
+    if (!t) { set_error("gbx_timer_create: null"); return GBX_ERR_ARG; }
+    int rc = require_device();
+    if (rc) return rc;
+    gbx_timer *x = new gbx_timer;
+    GBX_HIP(hipEventCreate(&x->a));
+    GBX_HIP(hipEventCreate(&x->b));
+    *t = x;
+    return GBX_OK;
+}
+int gbx_timer_start(gbx_timer *t, void *stream) { GBX_HIP(hipEventRecord(t->a, (hipStream_t)stream)); return GBX_OK; }
+int gbx_timer_stop(gbx_timer *t, void *stream) { GBX_HIP(hipEventRecord(t->b, (hipStream_t)stream)); return GBX_OK; }
+int gbx_timer_elapsed_ms(gbx_timer *t, float *ms)
+{
+    GBX_HIP(hipEventSynchronize(t->b));
+    GBX_HIP(hipEventElapsedTime(ms, t->a, t->b));
+    return GBX_OK;
+}
+void gbx_timer_destroy(gbx_timer *t)
+{
+    if (!t) return;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+}
+
+int gbx_profile_begin(void)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return GBX_OK;
+}
+
+int gbx_profile_end(int cap, const char **names, float *ms_sum, int *launches, int *n_stages)
+{
+    g_prof_on = false;
+    int n = 0;
+    for (auto &r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            int k = 0;
+            while (k < n && strcmp(names[k], r.name) != 0) ++k;
+            if (k == n) {
+                if (n == cap) continue;
+                names[n] = r.name; ms_sum[n] = 0.f; launches[n] = 0; ++n;
+            }
+            ms_sum[k] += ms; launches[k] += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    if (n_stages) *n_stages = n;
+    return GBX_OK;
+}
+
+int gbx_malloc_device(void **p, size_t bytes)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    GBX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    return GBX_OK;
+}
+int gbx_free_device(void *p) { if (p) GBX_HIP(hipFree(p)); return GBX_OK; }
+int gbx_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes) GBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return GBX_OK;
+}
+int gbx_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes) GBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return GBX_OK;
+}
+int gbx_stream_synchronize(void *stream) { GBX_HIP(hipStreamSynchronize((hipStream_t)stream)); return GBX_OK; }
+
+/* --------------------------------------------------------------------- bsw */
+void gbx_bsw_fill_scmat(int a, int b, int ambig, int8_t mat[25])
+{
+    int k = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) mat[k++] = (int8_t)(i == j ? a : -b);
+        mat[k++] = (int8_t)ambig;
+    }
+    for (int j = 0; j < 5; ++j) mat[k++] = (int8_t)ambig;
+}
+
+void gbx_bsw_default_params(gbx_bsw_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->o_del = p->o_ins = 6; p->e_del = p->e_ins = 1;
+    p->zdrop = 100; p->end_bonus = 5; p->w = 100;
+    gbx_bsw_fill_scmat(1, 4, -1, p->mat);
+}
+
+size_t gbx_bsw_workspace_bytes(int64_t n) { return bsw_workspace_bytes(n); }
+
+int gbx_bsw_extend_device(const gbx_bsw_params *p, int64_t n,
+                          const uint8_t *d_ref, const uint8_t *d_qer,
+                          const int64_t *d_idr, const int64_t *d_idq,
+                          const int32_t *d_len1, const int32_t *d_len2,
+                          const int32_t *d_h0, gbx_bsw_result *d_out,
+                          void *d_work, size_t work_bytes, void *stream)
+{
+    if (!p || n < 0) { set_error("gbx_bsw_extend_device: bad argument"); return GBX_ERR_ARG; }
+    if (n == 0) return GBX_OK;
+    if (!d_ref || !d_qer || !d_idr || !d_idq || !d_len1 || !d_len2 || !d_h0 || !d_out || !d_work) {
+        set_error("gbx_bsw_extend_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return bsw_launch(p, n, d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out, d_work, work_bytes,
+                      (hipStream_t)stream);
+}
+
+int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
+                        const uint8_t *ref, int64_t ref_bytes,
+                        const uint8_t *qer, int64_t qer_bytes,
+                        const int64_t *idr, const int64_t *idq,
+                        const int32_t *len1, const int32_t *len2,
+                        const int32_t *h0, gbx_bsw_result *out)
+{
+    if (!p || n < 0 || ref_bytes < 0 || qer_bytes < 0) { set_error("gbx_bsw_extend_host: bad argument"); return GBX_ERR_ARG; }
+    if (n == 0) return GBX_OK;
+    if (!ref || !qer || !idr || !idq || !len1 || !len2 || !h0 || !out) {
+        set_error("gbx_bsw_extend_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    for (int64_t k = 0; k < n; ++k) {
+        if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 ||
+            idr[k] + len1[k] > ref_bytes || idq[k] + len2[k] > qer_bytes) {
+            set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)k);
+            return GBX_ERR_ARG;
+        }
+        if (len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
+            set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)k);
+            return GBX_ERR_UNSUPPORTED;
+        }
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    DevBuf dref, dqer, didr, didq, dl1, dl2, dh0, dout, dwork;
+    const size_t wb = bsw_workspace_bytes(n);
+    if ((rc = dref.alloc((size_t)ref_bytes)) || (rc = dqer.alloc((size_t)qer_bytes)) ||
+        (rc = didr.alloc(n * 8)) || (rc = didq.alloc(n * 8)) || (rc = dl1.alloc(n * 4)) ||
+        (rc = dl2.alloc(n * 4)) || (rc = dh0.alloc(n * 4)) || (rc = dout.alloc(n * sizeof(gbx_bsw_result))) ||
+        (rc = dwork.alloc(wb)))
+        return rc;
+    hipStream_t s = nullptr;
+    GBX_HIP(hipMemcpyAsync(dref.p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(dqer.p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(didr.p, idr, n * 8, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(didq.p, idq, n * 8, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(dl1.p, len1, n * 4, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(dl2.p, len2, n * 4, hipMemcpyHostToDevice, s));
+    GBX_HIP(hipMemcpyAsync(dh0.p, h0, n * 4, hipMemcpyHostToDevice, s));
+    rc = bsw_launch(p, n, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>(), didq.as<int64_t>(),
+                    dl1.as<int32_t>(), dl2.as<int32_t>(), dh0.as<int32_t>(), dout.as<gbx_bsw_result>(),
+                    dwork.p, wb, s);
+    if (rc) return rc;
+    GBX_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(gbx_bsw_result), hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    return GBX_OK;
+}
+
+int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t n,
+                            const uint8_t *ref, int64_t ref_bytes,
+                            const uint8_t *qer, int64_t qer_bytes)
+{
+    if (!p || n < 0) { set_error("gbx_bsw_extend_seqpairs: bad argument"); return GBX_ERR_ARG; }
+    if (n == 0) return GBX_OK;
+    if (!pairs) { set_error("gbx_bsw_extend_seqpairs: null pointer"); return GBX_ERR_ARG; }
+    std::vector<int64_t> idr(n), idq(n);
+    std::vector<int32_t> l1(n), l2(n), h0(n);
+    std::vector<gbx_bsw_result> out(n);
+    for (int64_t k = 0; k < n; ++k) {
+        idr[k] = pairs[k].idr; idq[k] = pairs[k].idq;
+        l1[k] = pairs[k].len1; l2[k] = pairs[k].len2; h0[k] = pairs[k].h0;
+    }
+    int rc = gbx_bsw_extend_host(p, n, ref, ref_bytes, qer, qer_bytes, idr.data(), idq.data(), l1.data(),
+                                 l2.data(), h0.data(), out.data());
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; ++k) {
+        pairs[k].score = out[k].score; pairs[k].tle = out[k].tle; pairs[k].gtle = out[k].gtle;
+        pairs[k].qle = out[k].qle; pairs[k].gscore = out[k].gscore; pairs[k].max_off = out[k].max_off;
+    }
+    return GBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// gbx_internal.h — shared declarations between the C-ABI translation unit and
+// the per-kernel HIP files of libgbx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/gbx.h"
+
+namespace gbx {
+
+// thread-local last-error text (gbx_capi.hip)
+void set_error(const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what);
+
+#define GBX_HIP(call)                                            \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return gbx::hip_fail(e_, #call);   \
+    } while (0)
+
+// Optional per-kernel timing with HIP events on the launch stream (gbx_profile_*).
+// A Stage brackets one kernel launch; it is a no-op unless profiling is on.
+struct Stage {
+    Stage(const char *name, hipStream_t s);
+    ~Stage();
+    int slot_;
+    hipStream_t s_;
+};
+
+// ---- bsw (bsw_kernels.hip)
+size_t bsw_workspace_bytes(int64_t n);
+int bsw_launch(const gbx_bsw_params *p, int64_t n,
+               const uint8_t *d_ref, const uint8_t *d_qer,
+               const int64_t *d_idr, const int64_t *d_idq,
+               const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s);
+
+// ---- chain (chain_kernels.hip)
+size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors);
+int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
+                 const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
+                 int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
+                 void *d_work, size_t work_bytes, hipStream_t s);
+
+}  // namespace gbx

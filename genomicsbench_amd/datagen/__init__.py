@@ -1,0 +1,72 @@
+"""Seeded synthetic datasets in the reference input shapes.  Tooling only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(os.path.dirname(_HERE), "libgbx_datagen.so")
+_lib = None
+
+
+def _L():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            from ..build import build_datagen
+            build_datagen()
+        _lib = C.CDLL(_LIB)
+        vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
+        _lib.gbx_gen_bsw_lengths.argtypes = [u64, i64, i64, vp, vp, vp]
+        _lib.gbx_gen_bsw_lengths.restype = None
+        _lib.gbx_gen_bsw_fill.argtypes = [u64, i64, i64, vp, vp, vp, vp, vp, vp]
+        _lib.gbx_gen_bsw_fill.restype = None
+        _lib.gbx_gen_chain_count.argtypes = [u64, i64]
+        _lib.gbx_gen_chain_count.restype = i64
+        _lib.gbx_gen_chain_fill.argtypes = [u64, i64, i64, vp, vp]
+        _lib.gbx_gen_chain_fill.restype = None
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gen_bsw(n_pairs, seed, first=0):
+    """bsw 'small' = (100_000, seed 1001); 'large' = (2_000_000, seed 1002).  Returns a BswBatch."""
+    from ..bsw import BswBatch
+    L = _L()
+    len1 = np.zeros(n_pairs, dtype=np.int32)
+    len2 = np.zeros(n_pairs, dtype=np.int32)
+    h0 = np.zeros(n_pairs, dtype=np.int32)
+    L.gbx_gen_bsw_lengths(seed, first, n_pairs, _p(len1), _p(len2), _p(h0))
+    a1 = (len1.astype(np.int64) + 3) & ~3
+    a2 = (len2.astype(np.int64) + 3) & ~3
+    idr = np.concatenate([[0], np.cumsum(a1)[:-1]]).astype(np.int64) if n_pairs else np.zeros(0, np.int64)
+    idq = np.concatenate([[0], np.cumsum(a2)[:-1]]).astype(np.int64) if n_pairs else np.zeros(0, np.int64)
+    ref = np.zeros(int(a1.sum()) + 4, dtype=np.uint8)
+    qer = np.zeros(int(a2.sum()) + 4, dtype=np.uint8)
+    L.gbx_gen_bsw_fill(seed, first, n_pairs, _p(len1), _p(len2), _p(idr), _p(idq), _p(ref), _p(qer))
+    return BswBatch(ref, qer, idr, idq, len1, len2, h0)
+
+
+def gen_chain(n_calls, seed, first=0, n_override=None):
+    """chain 'large' = (10_000, seed 2001).  Returns (anchor_off, ax, ay, hdr)."""
+    from .._native import CHAIN_CALL_DTYPE
+    L = _L()
+    counts = np.array([L.gbx_gen_chain_count(seed, first + c) if n_override is None else n_override[c]
+                       for c in range(n_calls)], dtype=np.int64)
+    off = np.zeros(n_calls + 1, dtype=np.int64)
+    np.cumsum(counts, out=off[1:])
+    ax = np.zeros(int(off[-1]), dtype=np.uint64)
+    ay = np.zeros(int(off[-1]), dtype=np.uint64)
+    for c in range(n_calls):
+        L.gbx_gen_chain_fill(seed, first + c, int(counts[c]), C.c_void_p(ax.ctypes.data + 8 * int(off[c])),
+                             C.c_void_p(ay.ctypes.data + 8 * int(off[c])))
+    hdr = np.zeros(n_calls, dtype=CHAIN_CALL_DTYPE)
+    hdr["avg_qspan"] = 15.0
+    hdr["max_dist_x"] = 5000
+    hdr["max_dist_y"] = 5000
+    hdr["bw"] = 500
+    hdr["n_segs"] = 1
+    return off, ax, ay, hdr

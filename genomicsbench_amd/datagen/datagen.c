@@ -1,0 +1,148 @@
+/* datagen.c — seeded synthetic datasets in the reference benchmarks' input
+ * shapes (the real input-datasets tarball, R/README.md:18, is not available
+ * offline).  Tooling, not product and not oracle: plain C, deterministic per
+ * (seed, item index) so any sub-range can be regenerated on any rank.
+ * Distributions: SURVEY.md §8(d).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t mix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline void rng_seed(rng_t *r, uint64_t seed, uint64_t stream) { r->s = mix64(seed ^ mix64(stream * 0x632be59bd9b4e019ULL + 1)); }
+static inline uint64_t rng_u64(rng_t *r) { r->s += 0x9e3779b97f4a7c15ULL; uint64_t z = r->s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+static inline double rng_unif(rng_t *r) { return (double)(rng_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint32_t rng_below(rng_t *r, uint32_t n) { return (uint32_t)(((rng_u64(r) >> 32) * (uint64_t)n) >> 32); }
+static inline double rng_norm(rng_t *r)
+{
+    double u1 = rng_unif(r), u2 = rng_unif(r);
+    if (u1 < 1e-300) u1 = 1e-300;
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+/* ------------------------------------------------------------------- bsw
+ * Per simulated 151-bp read: seed length L = min(151, 19 + Exp(mean 40)),
+ * seed start p ~ U[0, 151-L]; pair k is the left (k even) or right (k odd)
+ * extension: qlen = p or 151-p-L (redrawn until > 0); h0 = L;
+ * tlen = qlen + min(max(qlen-5,1), 200)  (bwa cal_max_gap with a=1,o=6,e=1,w=100).
+ */
+#define READ_LEN 151
+static void bsw_lengths(uint64_t seed, int64_t k, int *qlen, int *tlen, int *h0)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)k * 2 + 0);
+    for (;;) {
+        double u = rng_unif(&r);
+        if (u < 1e-300) u = 1e-300;
+        int L = 19 + (int)floor(-40.0 * log(u));
+        if (L > READ_LEN) L = READ_LEN;
+        int p = (int)rng_below(&r, (uint32_t)(READ_LEN - L + 1));
+        int q = (k & 1) ? READ_LEN - p - L : p;
+        if (q <= 0) continue;
+        int gap = q - 5; if (gap < 1) gap = 1; if (gap > 200) gap = 200;
+        *qlen = q; *tlen = q + gap; *h0 = L;
+        return;
+    }
+}
+
+void gbx_gen_bsw_lengths(uint64_t seed, int64_t first, int64_t n, int32_t *len1, int32_t *len2, int32_t *h0)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < n; ++k) {
+        int q, t, h;
+        bsw_lengths(seed, first + k, &q, &t, &h);
+        len1[k] = t; len2[k] = q; h0[k] = h;
+    }
+}
+
+/* query ~ U{0..3} (1 % of pairs get one ambiguous base 4); target = query with
+ * 1 % substitutions, 0.05 % deletions, 0.15 % insertions, then a random tail. */
+void gbx_gen_bsw_fill(uint64_t seed, int64_t first, int64_t n,
+                      const int32_t *len1, const int32_t *len2,
+                      const int64_t *idr, const int64_t *idq, uint8_t *ref, uint8_t *qer)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < n; ++k) {
+        rng_t r;
+        rng_seed(&r, seed, (uint64_t)(first + k) * 2 + 1);
+        const int ql = len2[k], tl = len1[k];
+        uint8_t *q = qer + idq[k], *t = ref + idr[k];
+        for (int j = 0; j < ql; ++j) q[j] = (uint8_t)rng_below(&r, 4);
+        if (rng_below(&r, 100) == 0) q[rng_below(&r, (uint32_t)ql)] = 4;
+        int o = 0;
+        for (int j = 0; j < ql && o < tl; ++j) {
+            double u = rng_unif(&r);
+            if (u < 0.0005) continue;                                   /* deletion from the target */
+            uint8_t b = q[j] > 3 ? (uint8_t)rng_below(&r, 4) : q[j];
+            if (u < 0.0105) b = (uint8_t)((b + 1 + rng_below(&r, 3)) & 3);   /* substitution */
+            t[o++] = b;
+            if (o < tl && rng_unif(&r) < 0.0015) t[o++] = (uint8_t)rng_below(&r, 4);   /* insertion */
+        }
+        while (o < tl) t[o++] = (uint8_t)rng_below(&r, 4);
+    }
+}
+
+/* ----------------------------------------------------------------- chain
+ * call c: n ~ LogNormal(median 3000, sigma 0.8) clipped to [50, 60000];
+ * 1-4 colinear diagonals with jitter (dx ~ U[0,60], dy-dx ~ N(0,8)) + 20 % noise;
+ * y = (15<<32) | qpos; anchors sorted by x (insertion into place by construction
+ * of monotone x per diagonal then a merge by x).  avg_qspan 15, max_dist 5000, bw 500.
+ */
+int64_t gbx_gen_chain_count(uint64_t seed, int64_t call)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)call * 2 + 0);
+    double v = 3000.0 * exp(0.8 * rng_norm(&r));
+    if (v < 50) v = 50;
+    if (v > 60000) v = 60000;
+    return (int64_t)v;
+}
+
+static int cmp_anchor(const void *a, const void *b)
+{
+    const uint64_t *x = (const uint64_t *)a, *y = (const uint64_t *)b;
+    if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+    if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+    return 0;
+}
+
+#include <stdlib.h>
+void gbx_gen_chain_fill(uint64_t seed, int64_t call, int64_t n, uint64_t *ax, uint64_t *ay)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)call * 2 + 1);
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)n);
+    const int ndiag = 1 + (int)rng_below(&r, 4);
+    const int64_t n_noise = n / 5, n_sig = n - n_noise;
+    const int64_t span = n * 30 + 1000;                 /* read/ref extent */
+    int64_t o = 0;
+    for (int d = 0; d < ndiag; ++d) {
+        int64_t cnt = n_sig / ndiag + (d < n_sig % ndiag ? 1 : 0);
+        int64_t x = 1000 + (int64_t)rng_below(&r, 2000) + (int64_t)d * 7919;
+        int64_t y = 100 + (int64_t)rng_below(&r, 500);
+        for (int64_t k = 0; k < cnt; ++k) {
+            int64_t dx = (int64_t)rng_below(&r, 61);
+            int64_t dy = dx + (int64_t)llround(8.0 * rng_norm(&r));
+            if (dy < 0) dy = 0;
+            x += dx; y += dy;
+            tmp[2 * o] = (uint64_t)x;
+            tmp[2 * o + 1] = ((uint64_t)15 << 32) | (uint64_t)(uint32_t)(y & 0x7fffffff);
+            ++o;
+        }
+    }
+    for (int64_t k = 0; k < n_noise; ++k) {
+        tmp[2 * o] = (uint64_t)(1000 + (int64_t)(rng_unif(&r) * (double)span));
+        tmp[2 * o + 1] = ((uint64_t)15 << 32) | (uint64_t)(uint32_t)(100 + (int64_t)(rng_unif(&r) * (double)span));
+        ++o;
+    }
+    qsort(tmp, (size_t)n, 2 * sizeof(uint64_t), cmp_anchor);
+    for (int64_t k = 0; k < n; ++k) { ax[k] = tmp[2 * k]; ay[k] = tmp[2 * k + 1]; }
+    free(tmp);
+}

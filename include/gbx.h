@@ -1,0 +1,171 @@
+/* gbx.h — C-ABI of libgbx.so: MI355X (gfx950) kernels for GenomicsBench's
+ * dynamic-programming hot path (bsw, chain, phmm, poa).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes
+ * plain pointers and sizes, returns an int status (0 = GBX_OK, <0 = error;
+ * text via gbx_last_error()), never calls exit() and never falls back to a
+ * CPU implementation: with no usable HIP device every compute entry point
+ * returns GBX_ERR_NO_DEVICE.
+ *
+ * Two flavours per kernel:
+ *   *_host    host buffers in, host buffers out (H2D + kernels + D2H inside;
+ *             this is what a reference driver binds to);
+ *   *_device  device-resident buffers on a caller-provided hipStream_t (what
+ *             bench.py times: inputs already in HBM).
+ *
+ * Reference interfaces each entry replaces are cited as
+ * R/ = /root/reference/ file:line.
+ */
+#ifndef GBX_H
+#define GBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define GBX_OK               0
+#define GBX_ERR_ARG         -1   /* bad argument (null pointer, negative size, bad params) */
+#define GBX_ERR_NO_DEVICE   -2   /* no HIP device / HIP runtime unusable                   */
+#define GBX_ERR_HIP         -3   /* a HIP call failed (see gbx_last_error)                 */
+#define GBX_ERR_NOMEM       -4   /* host or device allocation failed                       */
+#define GBX_ERR_UNSUPPORTED -5   /* input exceeds a documented limit                       */
+
+const char *gbx_version(void);
+const char *gbx_last_error(void);       /* thread-local, never NULL */
+int  gbx_device_count(void);            /* number of HIP devices, 0 if none; never errors  */
+int  gbx_set_device(int dev);           /* selects the device later calls of this thread use */
+int  gbx_device_name(char *buf, size_t cap);
+
+/* Timing helpers on a stream (HIP events), so that a Python/ctypes host can
+ * time the exact stream the kernels are launched on without touching HIP. */
+typedef struct gbx_timer gbx_timer;
+int  gbx_timer_create(gbx_timer **t);
+int  gbx_timer_start(gbx_timer *t, void *stream);
+int  gbx_timer_stop(gbx_timer *t, void *stream);
+int  gbx_timer_elapsed_ms(gbx_timer *t, float *ms);   /* synchronises on the stop event */
+void gbx_timer_destroy(gbx_timer *t);
+
+/* Per-kernel timing: between gbx_profile_begin() and gbx_profile_end() every
+ * kernel launched by this thread through a *_device / *_host entry is bracketed
+ * by HIP events on its own stream.  gbx_profile_end synchronises and returns,
+ * per distinct kernel name (static strings, at most `cap`), the summed
+ * duration in ms and the number of launches. */
+int  gbx_profile_begin(void);
+int  gbx_profile_end(int cap, const char **names, float *ms_sum, int *launches, int *n_stages);
+
+/* Device memory helpers (used by the C++ drivers; bench.py uses torch tensors). */
+int  gbx_malloc_device(void **p, size_t bytes);
+int  gbx_free_device(void *p);
+int  gbx_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int  gbx_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int  gbx_stream_synchronize(void *stream);
+
+/* --------------------------------------------------------------------- bsw
+ * Banded Smith-Waterman seed extension (bwa-mem2 BSW).
+ * Replaces  BandedPairWiseSW::BandedPairWiseSW(...)        R/benchmarks/bsw/bandedSWA.cpp:51-100
+ *           BandedPairWiseSW::getScores16(...)              R/benchmarks/bsw/bandedSWA.cpp:1124-1148
+ *           (called at R/benchmarks/bsw/main_banded.cpp:286)
+ * Per-pair semantics are those of BandedPairWiseSW::scalarBandedSWA
+ *           R/benchmarks/bsw/bandedSWA.cpp:128-249 (bwa ksw_extend2), bit-exact.
+ */
+typedef struct gbx_bsw_params {
+    int32_t o_del, e_del, o_ins, e_ins;  /* gap open / extend penalties (>=0; e_* >= 1)   */
+    int32_t zdrop;                       /* 100 in the driver, main_banded.cpp:250        */
+    int32_t end_bonus;                   /* 5 in the driver                                */
+    int32_t w;                           /* band width, 100 in the driver                  */
+    int8_t  mat[25];                     /* 5x5 score matrix, bwa_fill_scmat main_banded.cpp:73-81 */
+    int8_t  pad_[3];
+} gbx_bsw_params;
+
+/* Fills p with the driver's defaults: a=1 b=4 ambig=-1 o=6 e=1 zdrop=100 end_bonus=5 w=100. */
+void gbx_bsw_default_params(gbx_bsw_params *p);
+/* Same as bwa_fill_scmat(a, b, ambig, mat) (main_banded.cpp:73-81); b is the positive penalty. */
+void gbx_bsw_fill_scmat(int a, int b, int ambig, int8_t mat[25]);
+
+/* Per-pair output record, 6 x int32, same field meaning as SeqPair's outputs
+ * (R/benchmarks/bsw/bandedSWA.h:91-100). */
+typedef struct gbx_bsw_result {
+    int32_t score, tle, gtle, qle, gscore, max_off;
+} gbx_bsw_result;
+
+/* Mirror of the reference's 72-byte SeqPair (bandedSWA.h:91-100). */
+typedef struct gbx_seqpair {
+    int64_t idr, idq, id;
+    int32_t len1, len2;
+    int32_t h0;
+    int32_t seqid, regid;
+    int32_t score, tle, gtle, qle;
+    int32_t gscore, max_off;
+} gbx_seqpair;
+
+/* Limits of the device path: query (len2) and target (len1) lengths. */
+#define GBX_BSW_MAX_QLEN  8192
+#define GBX_BSW_MAX_TLEN  65535
+
+/* Host flat-array entry.  ref/qer are byte arenas of base codes 0..4; pair k's
+ * target is ref[idr[k] .. idr[k]+len1[k]), its query qer[idq[k] .. +len2[k]).
+ * Writes out[k] for k in [0,n).  Does not write pad records and does not
+ * reorder caller memory (cf. bandedSWA.cpp:1172-1177, 1183-1210). */
+int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
+                        const uint8_t *ref, int64_t ref_bytes,
+                        const uint8_t *qer, int64_t qer_bytes,
+                        const int64_t *idr, const int64_t *idq,
+                        const int32_t *len1, const int32_t *len2,
+                        const int32_t *h0, gbx_bsw_result *out);
+
+/* Drop-in for getScores16 on the reference's own SeqPair array: reads
+ * idr/idq/len1/len2/h0 from pairs[k] and writes score,tle,gtle,qle,gscore,
+ * max_off in place.  ref_bytes/qer_bytes bound the two arenas. */
+int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t n,
+                            const uint8_t *ref, int64_t ref_bytes,
+                            const uint8_t *qer, int64_t qer_bytes);
+
+/* Device-resident entry: all pointers are device pointers; the arenas must be
+ * readable for 16 bytes past their last base (hipMalloc slack is enough);
+ * work = scratch of gbx_bsw_workspace_bytes(n) bytes.  Asynchronous on
+ * `stream` (a hipStream_t, may be NULL). */
+size_t gbx_bsw_workspace_bytes(int64_t n);
+int gbx_bsw_extend_device(const gbx_bsw_params *p, int64_t n,
+                          const uint8_t *d_ref, const uint8_t *d_qer,
+                          const int64_t *d_idr, const int64_t *d_idq,
+                          const int32_t *d_len1, const int32_t *d_len2,
+                          const int32_t *d_h0, gbx_bsw_result *d_out,
+                          void *d_work, size_t work_bytes, void *stream);
+
+/* ------------------------------------------------------------------- chain
+ * minimap2 anchor chaining DP.
+ * Replaces  host_chain_kernel(std::vector<call_t>&, std::vector<return_t>&, int)
+ *           R/benchmarks/chain/src/host_kernel.cpp:96-108  (chain_dp :30-94)
+ * Calls are concatenated: call c owns anchors [anchor_off[c], anchor_off[c+1]).
+ */
+typedef struct gbx_chain_call {
+    float   avg_qspan;                         /* host_data.h:24-29 */
+    int32_t max_dist_x, max_dist_y, bw, n_segs;
+} gbx_chain_call;
+
+#define GBX_CHAIN_MAX_ITER 5000   /* host_kernel.cpp:37 */
+#define GBX_CHAIN_MAX_SKIP 25     /* host_kernel.cpp:38 */
+
+/* target/peak may be NULL (the reference computes them but never prints them). */
+int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off,
+                   const uint64_t *ax, const uint64_t *ay,
+                   const gbx_chain_call *hdr,
+                   int32_t *score, int32_t *parent,
+                   int32_t *target, int32_t *peak);
+
+size_t gbx_chain_workspace_bytes(int64_t n_calls, int64_t n_anchors);
+int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor_off,
+                     const uint64_t *d_ax, const uint64_t *d_ay,
+                     const gbx_chain_call *d_hdr,
+                     int32_t *d_score, int32_t *d_parent,
+                     int32_t *d_target, int32_t *d_peak,
+                     void *d_work, size_t work_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBX_H */

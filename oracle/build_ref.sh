@@ -1,0 +1,43 @@
+#!/usr/bin/env bash
+# build_ref.sh — compile the REFERENCE's own kernels, from the sources where
+# they lie under /root/reference, into oracle/_ref/ (git-ignored, but shipped
+# to the GPU box by gpurun).  Test infrastructure only.  No reference source
+# is copied into this repo and no stand-in header/library is written.
+#
+#   oracle/_ref/libbsw_ref.so    bandedSWA.cpp (scalar + AVX2 getScores16) + our shim
+#   oracle/_ref/libchain_ref.so  host_kernel.cpp (chain_dp)                + our shim
+#
+# phmm and poa are NOT buildable here: their arithmetic lives in the GKL and
+# spoa submodules, which are empty in this checkout.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REF="${GBX_REFERENCE_DIR:-/root/reference}"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/benchmarks/bsw" ]; then
+    echo "build_ref.sh: $REF not present (GPU box?) - keeping prebuilt oracle/_ref" >&2
+    exit 0
+fi
+mkdir -p "$OUT"
+CXX="${CXX:-g++}"
+
+# ---- bsw: flags of R/benchmarks/bsw/Makefile:59 with arch=avx2 (:39-44)
+BSW="$REF/benchmarks/bsw"
+$CXX -shared -fPIC -O3 -std=c++11 -fopenmp -mavx2 -w \
+    -DSORT_PAIRS -DENABLE_PREFETCH -DBWA_OTHER_ELE=0 \
+    -I"$BSW" "$BSW/bandedSWA.cpp" "$HERE/ref_harness/bsw_ref_shim.cpp" \
+    -o "$OUT/libbsw_ref.so"
+
+# ---- chain: R/benchmarks/chain/src/host_kernel.cpp names three minimap2
+# headers (minimap.h, mmpriv.h, kalloc.h :8-10) from the un-vendored
+# tools/minimap2 submodule and uses nothing from them.  We do not write
+# stand-ins for them: the translation unit is fed to the compiler through a
+# pipe with exactly those three #include lines dropped; every other byte is
+# the reference's.  If a future checkout starts using those headers this
+# build fails and the chain oracle must be re-labelled "parity unpinned".
+CH="$REF/benchmarks/chain/src"
+grep -v -E '^#include "(minimap|mmpriv|kalloc)\.h"' "$CH/host_kernel.cpp" |
+    $CXX -c -x c++ -fPIC -O3 -std=c++11 -fopenmp -w -I"$CH" - -o "$OUT/chain_host_kernel.o"
+$CXX -shared -fPIC -O3 -std=c++11 -fopenmp -w -I"$CH" \
+    "$OUT/chain_host_kernel.o" "$HERE/ref_harness/chain_ref_shim.cpp" -o "$OUT/libchain_ref.so"
+rm -f "$OUT/chain_host_kernel.o"
+echo "built: $(ls "$OUT")"

@@ -1,0 +1,42 @@
+/* gbx_oracle.h — CPU restatements of the reference algorithms.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load liboracle.so, and only as the checker / the CPU number beside the GPU
+ * one.  libgbx.so never links or calls it.
+ *
+ * Each function cites the reference lines (R/ = /root/reference/) it restates.
+ */
+#ifndef GBX_ORACLE_H
+#define GBX_ORACLE_H
+#include <stdint.h>
+#include "../include/gbx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bsw: scalarBandedSWA, R/benchmarks/bsw/bandedSWA.cpp:128-249 */
+int  oracle_bsw_extend_one(const gbx_bsw_params *p, int qlen, const uint8_t *query,
+                           int tlen, const uint8_t *target, int h0,
+                           gbx_bsw_result *out, int64_t *cells_computed);
+/* loops pairs (scalarBandedSWAWrapper, bandedSWA.cpp:254-272); nthreads>1 = OpenMP */
+void oracle_bsw_extend(const gbx_bsw_params *p, int64_t n,
+                       const uint8_t *ref, const uint8_t *qer,
+                       const int64_t *idr, const int64_t *idq,
+                       const int32_t *len1, const int32_t *len2, const int32_t *h0,
+                       gbx_bsw_result *out, int nthreads, int64_t *cells_computed);
+
+/* chain: chain_dp, R/benchmarks/chain/src/host_kernel.cpp:30-94 */
+void oracle_chain_one(int64_t n, const uint64_t *ax, const uint64_t *ay,
+                      const gbx_chain_call *hdr, int32_t *score, int32_t *parent,
+                      int32_t *target, int32_t *peak, int64_t *pairs_evaluated);
+void oracle_chain(int64_t n_calls, const int64_t *anchor_off,
+                  const uint64_t *ax, const uint64_t *ay, const gbx_chain_call *hdr,
+                  int32_t *score, int32_t *parent, int32_t *target, int32_t *peak,
+                  int nthreads, int64_t *pairs_evaluated);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

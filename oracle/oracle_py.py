@@ -1,0 +1,85 @@
+"""ctypes binding of oracle/liboracle.so and (when present) oracle/_ref/*.so.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never by the genomicsbench_amd package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_cache = {}
+
+
+def _load(path):
+    if path not in _cache:
+        _cache[path] = C.CDLL(path) if os.path.exists(path) else None
+    return _cache[path]
+
+
+def oracle_lib():
+    L = _load(os.path.join(_HERE, "liboracle.so"))
+    if L is None:
+        raise ImportError("oracle/liboracle.so not built (make -C oracle)")
+    return L
+
+
+def ref_lib(name):
+    """oracle/_ref/lib<name>_ref.so or None (the reference build only exists where /root/reference did)."""
+    return _load(os.path.join(_HERE, "_ref", "lib%s_ref.so" % name))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _bsw_args(params, b, out):
+    return [C.byref(params), C.c_int64(b.n), _p(b.ref), _p(b.qer), _p(b.idr), _p(b.idq), _p(b.len1), _p(b.len2),
+            _p(b.h0), _p(out)]
+
+
+def bsw_oracle(params, batch, nthreads=1, return_cells=False):
+    out = np.zeros((batch.n, 6), dtype=np.int32)
+    cells = C.c_int64(0)
+    f = oracle_lib().oracle_bsw_extend
+    f.restype = None
+    f(*_bsw_args(params, batch, out), C.c_int(nthreads), C.byref(cells))
+    return (out, cells.value) if return_cells else out
+
+
+def bsw_ref_scalar(params, batch):
+    L = ref_lib("bsw")
+    out = np.zeros((batch.n, 6), dtype=np.int32)
+    L.ref_bsw_scalar(*_bsw_args(params, batch, out))
+    return out
+
+
+def bsw_ref_avx2(params, batch, batch_size=512):
+    L = ref_lib("bsw")
+    out = np.zeros((batch.n, 6), dtype=np.int32)
+    L.ref_bsw_getscores16(*_bsw_args(params, batch, out), C.c_int32(batch_size))
+    return out
+
+
+def _chain_args(off, ax, ay, hdr, score, parent, target, peak):
+    return [C.c_int64(len(off) - 1), _p(off), _p(ax), _p(ay), _p(hdr), _p(score), _p(parent), _p(target), _p(peak)]
+
+
+def chain_oracle(off, ax, ay, hdr, nthreads=1, return_pairs=False):
+    n = int(off[-1])
+    score, parent, target, peak = (np.zeros(n, dtype=np.int32) for _ in range(4))
+    ev = C.c_int64(0)
+    f = oracle_lib().oracle_chain
+    f.restype = None
+    f(*_chain_args(off, ax, ay, hdr, score, parent, target, peak), C.c_int(nthreads), C.byref(ev))
+    r = (score, parent, target, peak)
+    return r + (ev.value,) if return_pairs else r
+
+
+def chain_ref(off, ax, ay, hdr, nthreads=1):
+    L = ref_lib("chain")
+    n = int(off[-1])
+    score, parent, target, peak = (np.zeros(n, dtype=np.int32) for _ in range(4))
+    L.ref_chain(*_chain_args(off, ax, ay, hdr, score, parent, target, peak), C.c_int(nthreads))
+    return score, parent, target, peak

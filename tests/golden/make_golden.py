@@ -1,0 +1,61 @@
+"""Generates the committed golden fixtures from the COMPILED REFERENCE (oracle/_ref/*.so).
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+Fixtures are data: seeded synthetic inputs in the reference's own input formats and the
+outputs the reference's code produced for them.
+
+bsw_<name>.pairs.txt.gz   input, reference format (main_banded.cpp:131-141)
+bsw_<name>.golden.txt.gz  per pair: 6 outputs of scalarBandedSWA, then 6 of getScores16 (AVX2, -b 512)
+chain_<name>.in.gz        input, reference format (host_data_io.cpp:13-51)
+chain_<name>.golden.txt.gz  per anchor: score parent target peak (return_t vectors of host_chain_kernel)
+"""
+import gzip
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cases import adversarial_bsw, edge_bsw, chain_cases  # noqa: E402
+from genomicsbench_amd import io as gio  # noqa: E402
+from genomicsbench_amd.bsw import BswBatch, make_params  # noqa: E402
+from genomicsbench_amd.datagen import gen_bsw, gen_chain  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+
+def bsw_fixture(name, batch):
+    keep = np.nonzero((batch.len1 > 0) & (batch.len2 > 0))[0]      # the text format cannot hold empty lines
+    b = BswBatch(batch.ref, batch.qer, batch.idr[keep], batch.idq[keep], batch.len1[keep], batch.len2[keep],
+                 batch.h0[keep])
+    gio.write_bsw_pairs(os.path.join(HERE, "bsw_%s.pairs.txt.gz" % name), b)
+    b = gio.read_bsw_pairs(os.path.join(HERE, "bsw_%s.pairs.txt.gz" % name))
+    p = make_params()
+    sc = O.bsw_ref_scalar(p, b)
+    av = O.bsw_ref_avx2(p, b, 512)
+    with gzip.open(os.path.join(HERE, "bsw_%s.golden.txt.gz" % name), "wt") as f:
+        for k in range(b.n):
+            f.write(" ".join(map(str, list(sc[k]) + list(av[k]))) + "\n")
+    print(name, b.n, "pairs; scalar/AVX2 row mismatches:", int((sc != av).any(1).sum()))
+
+
+def chain_fixture(name, off, ax, ay, hdr):
+    gio.write_chain_calls(os.path.join(HERE, "chain_%s.in.gz" % name), off, ax, ay, hdr)
+    off, ax, ay, hdr = gio.read_chain_calls(os.path.join(HERE, "chain_%s.in.gz" % name))
+    s, p, t, k = O.chain_ref(off, ax, ay, hdr, 1)
+    with gzip.open(os.path.join(HERE, "chain_%s.golden.txt.gz" % name), "wt") as f:
+        for i in range(len(s)):
+            f.write("%d %d %d %d\n" % (s[i], p[i], t[i], k[i]))
+    print(name, len(off) - 1, "calls", len(s), "anchors")
+
+
+if __name__ == "__main__":
+    assert O.ref_lib("bsw") is not None and O.ref_lib("chain") is not None, "run oracle/build_ref.sh first"
+    bsw_fixture("realistic", gen_bsw(3000, 1001))
+    bsw_fixture("adversarial", adversarial_bsw(3000, 4242))
+    bsw_fixture("edge", edge_bsw())
+    for name, case in chain_cases().items():
+        chain_fixture(name, *case)

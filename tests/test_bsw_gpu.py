@@ -1,0 +1,114 @@
+"""GPU parity tests for bsw: HIP kernels (through the C-ABI) vs the oracle, bit-exact on all six outputs."""
+import numpy as np
+import pytest
+
+from cases import adversarial_bsw, edge_bsw
+from genomicsbench_amd import _native as N
+from genomicsbench_amd.bsw import BandedPairWiseSW, BswBatch, DeviceBswBatch, extend_host, fill_scmat, make_params
+from genomicsbench_amd.datagen import gen_bsw
+from oracle import oracle_py as O
+from util import load_bsw_golden
+
+pytestmark = pytest.mark.gpu
+FIELDS = N.BSW_RESULT_FIELDS
+
+
+def assert_same(got, want, batch=None):
+    if not np.array_equal(got, want):
+        rows = np.nonzero((got != want).any(1))[0]
+        k = int(rows[0])
+        msg = "%d/%d pairs differ; first k=%d got=%s want=%s" % (len(rows), len(want), k, got[k], want[k])
+        if batch is not None:
+            msg += " (len1=%d len2=%d h0=%d)" % (batch.len1[k], batch.len2[k], batch.h0[k])
+        raise AssertionError(msg)
+
+
+@pytest.mark.parametrize("name", ["realistic", "adversarial", "edge"])
+def test_goldens(name):
+    b, scalar, avx2 = load_bsw_golden(name)
+    got = extend_host(make_params(), b)
+    assert_same(got, scalar, b)
+    assert np.array_equal(got[:, [0, 1, 3, 5]], avx2[:, [0, 1, 3, 5]])
+
+
+def test_edge_cases_including_empty_sequences():
+    b = edge_bsw()
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_random(seed):
+    b = adversarial_bsw(6000, seed)
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+def test_long_queries_all_kernel_classes():
+    b = adversarial_bsw(300, 9, max_q=3000, max_t=4000)
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(o_del=5, e_del=2, o_ins=7, e_ins=3, zdrop=50, end_bonus=9, w=37, mat=fill_scmat(2, 5, -2)),
+    dict(zdrop=0, w=5),
+    dict(w=1000, zdrop=10),
+    dict(o_del=0, e_del=1, o_ins=0, e_ins=1, mat=fill_scmat(3, 1, 0)),
+])
+def test_non_default_scoring(kw):
+    p = make_params(**kw)
+    b = adversarial_bsw(3000, 21)
+    assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
+
+
+def test_bsw_small_config_100k():
+    """BASELINE config[0] workload (bsw 'small', 100k pairs) against the oracle."""
+    b = gen_bsw(100_000, 1001)
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
+
+
+def test_seqpair_dropin_matches_flat_entry():
+    b = gen_bsw(5000, 3)
+    pairs = np.zeros(b.n, dtype=N.SEQPAIR_DTYPE)
+    pairs["idr"], pairs["idq"], pairs["id"] = b.idr, b.idq, np.arange(b.n)
+    pairs["len1"], pairs["len2"], pairs["h0"] = b.len1, b.len2, b.h0
+    for f in FIELDS:
+        pairs[f] = -1
+    mat = fill_scmat(1, 4, -1)
+    sw = BandedPairWiseSW(6, 1, 6, 1, 100, 5, mat, 1, 4, 1)
+    sw.getScores16(pairs, b.ref, b.qer, b.n, 1, 100)
+    want = O.bsw_oracle(make_params(), b, 4)
+    got = np.stack([pairs[f] for f in FIELDS], axis=1)
+    assert_same(got, want, b)
+
+
+def test_device_resident_entry_and_rerun_idempotence():
+    import torch
+    b = gen_bsw(20000, 8)
+    d = DeviceBswBatch(b, torch.device("cuda:0"))
+    p = make_params()
+    s = torch.cuda.current_stream().cuda_stream
+    d.run(p, s)
+    torch.cuda.synchronize()
+    first = d.results().copy()
+    d.out.fill_(-7)
+    d.run(p, s)
+    torch.cuda.synchronize()
+    assert_same(d.results(), first)
+    assert_same(first, O.bsw_oracle(p, b, 4), b)
+
+
+def test_permutation_and_shard_equivalence_large():
+    """Size-independent properties at the bsw 'large' scale: results do not depend on pair order or sharding."""
+    b = gen_bsw(400_000, 1002)
+    p = make_params()
+    full = extend_host(p, b)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(b.n)
+    pb = BswBatch(b.ref, b.qer, b.idr[perm], b.idq[perm], b.len1[perm], b.len2[perm], b.h0[perm])
+    assert_same(extend_host(p, pb), full[perm])
+    cut = b.n // 3
+    parts = np.concatenate([extend_host(p, b.slice(0, cut)), extend_host(p, b.slice(cut, b.n))])
+    assert_same(parts, full)
+    # anchor a sample on the oracle
+    idx = rng.choice(b.n, 20000, replace=False)
+    sb = BswBatch(b.ref, b.qer, b.idr[idx], b.idq[idx], b.len1[idx], b.len2[idx], b.h0[idx])
+    assert_same(full[idx], O.bsw_oracle(p, sb, 8), sb)
