@@ -36,12 +36,17 @@ def cpu_baseline(batch, params, max_pairs):
     if ref is not None and hasattr(ref, "ref_bsw_getscores16_mt"):
         import ctypes as C
         out = np.zeros((n, 6), dtype=np.int32)
-        t0 = time.perf_counter()
-        ref.ref_bsw_getscores16_mt(*O._bsw_args(params, sample, out), C.c_int32(512), C.c_int32(cores))
+        secs = C.c_double(0.0)
+        best = None
+        for _ in range(3):      # median-free: best of 3, the driver's own timed region (objects built outside)
+            ref.ref_bsw_getscores16_mt(*O._bsw_args(params, sample, out), C.c_int32(512), C.c_int32(cores),
+                                       C.byref(secs))
+            best = secs.value if best is None else min(best, secs.value)
         kind = "reference"
+        dt = best
     else:
         O.bsw_oracle(params, sample, cores)
-    dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
     return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
             "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" %
                       (n, "reference AVX2 getScores16 -b 512, one object per thread" if kind == "reference"
@@ -54,7 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=2_000_000, help="pairs per GPU (bsw 'large' = 2M, seed 1002)")
-    ap.add_argument("--cpu-pairs", type=int, default=1_000_000, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-pairs", type=int, default=2_000_000, help="pairs in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

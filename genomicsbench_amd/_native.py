@@ -53,6 +53,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libgbx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(expected at %s)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP/HSA runtime.  Two copies of the runtime in one process cannot
+        # both own the GPU, so when torch is installed it must be loaded first; libgbx.so then binds to the
+        # runtime already in the process (same SONAME).  The C++ drivers never load torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

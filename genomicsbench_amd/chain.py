@@ -1,0 +1,57 @@
+"""Host mirror of the reference chain interface (R/benchmarks/chain/src/host_kernel.h:6).
+
+``host_chain_kernel(calls) -> rets`` over flat numpy arrays; all arithmetic in libgbx.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def chain_host(off, ax, ay, hdr, want_target=True, want_peak=True):
+    """gbx_chain_host -> (score, parent, target, peak) int32 arrays over the concatenated anchors."""
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ax = np.ascontiguousarray(ax, dtype=np.uint64)
+    ay = np.ascontiguousarray(ay, dtype=np.uint64)
+    hdr = np.ascontiguousarray(hdr, dtype=N.CHAIN_CALL_DTYPE)
+    n = int(off[-1]) if len(off) else 0
+    score = np.zeros(n, dtype=np.int32)
+    parent = np.zeros(n, dtype=np.int32)
+    target = np.zeros(n, dtype=np.int32) if want_target else None
+    peak = np.zeros(n, dtype=np.int32) if want_peak else None
+    N.check(N.lib().gbx_chain_host(len(off) - 1, N.ptr(off), N.ptr(ax), N.ptr(ay), N.ptr(hdr), N.ptr(score),
+                                   N.ptr(parent), N.ptr(target), N.ptr(peak)))
+    return score, parent, target, peak
+
+
+host_chain_kernel = chain_host
+
+
+class DeviceChainBatch:
+    """Chaining calls resident in HBM (torch tensors) plus outputs and workspace."""
+
+    def __init__(self, off, ax, ay, hdr, device):
+        import torch
+        self.n_calls = len(off) - 1
+        self.n_anchors = int(off[-1])
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.off = t(np.ascontiguousarray(off, dtype=np.int64))
+        self.ax = t(np.ascontiguousarray(ax, dtype=np.uint64).view(np.int64))
+        self.ay = t(np.ascontiguousarray(ay, dtype=np.uint64).view(np.int64))
+        self.hdr = t(np.ascontiguousarray(hdr, dtype=N.CHAIN_CALL_DTYPE).view(np.uint8))
+        n = max(self.n_anchors, 1)
+        self.score, self.parent, self.target, self.peak = (torch.empty(n, dtype=torch.int32, device=device)
+                                                           for _ in range(4))
+        self.work_bytes = N.lib().gbx_chain_workspace_bytes(self.n_calls, self.n_anchors)
+        self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
+
+    def run(self, stream=None):
+        N.check(N.lib().gbx_chain_device(self.n_calls, self.n_anchors, self.off.data_ptr(), self.ax.data_ptr(),
+                                         self.ay.data_ptr(), self.hdr.data_ptr(), self.score.data_ptr(),
+                                         self.parent.data_ptr(), self.target.data_ptr(), self.peak.data_ptr(),
+                                         self.work.data_ptr(), self.work_bytes, stream))
+
+    def results(self):
+        k = self.n_anchors
+        return tuple(a[:k].cpu().numpy() for a in (self.score, self.parent, self.target, self.peak))

@@ -305,4 +305,66 @@ int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t
     return GBX_OK;
 }
 
+/* ------------------------------------------------------------------- chain */
+size_t gbx_chain_workspace_bytes(int64_t n_calls, int64_t n_anchors) { return chain_workspace_bytes(n_calls, n_anchors); }
+
+int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor_off,
+                     const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
+                     int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
+                     void *d_work, size_t work_bytes, void *stream)
+{
+    if (n_calls < 0 || n_anchors < 0) { set_error("gbx_chain_device: bad argument"); return GBX_ERR_ARG; }
+    if (n_calls == 0) return GBX_OK;
+    if (!d_anchor_off || !d_ax || !d_ay || !d_hdr || !d_score || !d_parent || !d_work) {
+        set_error("gbx_chain_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return chain_launch(n_calls, n_anchors, d_anchor_off, d_ax, d_ay, d_hdr, d_score, d_parent, d_target, d_peak,
+                        d_work, work_bytes, (hipStream_t)stream);
+}
+
+int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *ax, const uint64_t *ay,
+                   const gbx_chain_call *hdr, int32_t *score, int32_t *parent, int32_t *target, int32_t *peak)
+{
+    if (n_calls < 0) { set_error("gbx_chain_host: bad argument"); return GBX_ERR_ARG; }
+    if (n_calls == 0) return GBX_OK;
+    if (!anchor_off || !hdr || !score || !parent) { set_error("gbx_chain_host: null pointer"); return GBX_ERR_ARG; }
+    if (anchor_off[0] != 0) { set_error("gbx_chain_host: anchor_off[0] must be 0"); return GBX_ERR_ARG; }
+    for (int64_t c = 0; c < n_calls; ++c) {
+        const int64_t n = anchor_off[c + 1] - anchor_off[c];
+        if (n < 0) { set_error("gbx_chain_host: anchor_off not monotone at call %lld", (long long)c); return GBX_ERR_ARG; }
+        if (n > 0x7fffffffLL) { set_error("gbx_chain_host: call %lld has more than 2^31 anchors", (long long)c); return GBX_ERR_UNSUPPORTED; }
+    }
+    const int64_t na = anchor_off[n_calls];
+    if (na > 0 && (!ax || !ay)) { set_error("gbx_chain_host: null anchors"); return GBX_ERR_ARG; }
+    int rc = require_device();
+    if (rc) return rc;
+    DevBuf doff, dx, dy, dh, ds, dp, dt, dk, dw;
+    const size_t wb = chain_workspace_bytes(n_calls, na);
+    if ((rc = doff.alloc((n_calls + 1) * 8)) || (rc = dx.alloc(na * 8)) || (rc = dy.alloc(na * 8)) ||
+        (rc = dh.alloc(n_calls * sizeof(gbx_chain_call))) || (rc = ds.alloc(na * 4)) || (rc = dp.alloc(na * 4)) ||
+        (rc = dt.alloc(na * 4)) || (rc = dk.alloc(na * 4)) || (rc = dw.alloc(wb)))
+        return rc;
+    hipStream_t s = nullptr;
+    GBX_HIP(hipMemcpyAsync(doff.p, anchor_off, (n_calls + 1) * 8, hipMemcpyHostToDevice, s));
+    if (na) {
+        GBX_HIP(hipMemcpyAsync(dx.p, ax, na * 8, hipMemcpyHostToDevice, s));
+        GBX_HIP(hipMemcpyAsync(dy.p, ay, na * 8, hipMemcpyHostToDevice, s));
+    }
+    GBX_HIP(hipMemcpyAsync(dh.p, hdr, n_calls * sizeof(gbx_chain_call), hipMemcpyHostToDevice, s));
+    rc = chain_launch(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
+                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, s);
+    if (rc) return rc;
+    if (na) {
+        GBX_HIP(hipMemcpyAsync(score, ds.p, na * 4, hipMemcpyDeviceToHost, s));
+        GBX_HIP(hipMemcpyAsync(parent, dp.p, na * 4, hipMemcpyDeviceToHost, s));
+        if (target) GBX_HIP(hipMemcpyAsync(target, dt.p, na * 4, hipMemcpyDeviceToHost, s));
+        if (peak) GBX_HIP(hipMemcpyAsync(peak, dk.p, na * 4, hipMemcpyDeviceToHost, s));
+    }
+    GBX_HIP(hipStreamSynchronize(s));
+    return GBX_OK;
+}
+
 }  // extern "C"
