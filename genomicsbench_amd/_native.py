@@ -94,6 +94,11 @@ def _declare(L):
     L.gbx_bsw_extend_host.argtypes = [C.POINTER(BswParams), i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     L.gbx_bsw_extend_seqpairs.argtypes = [C.POINTER(BswParams), vp, i64, vp, i64, vp, i64]
     L.gbx_bsw_extend_device.argtypes = [C.POINTER(BswParams), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    if hasattr(L, "gbx_phmm_forward_host"):
+        L.gbx_phmm_workspace_bytes.argtypes = [i64, C.c_int32]
+        L.gbx_phmm_workspace_bytes.restype = sz
+        L.gbx_phmm_forward_host.argtypes = [i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]
+        L.gbx_phmm_forward_device.argtypes = [i64] + [vp] * 12 + [C.c_int32, vp, vp, sz, vp]
     if hasattr(L, "gbx_chain_host"):
         L.gbx_chain_workspace_bytes.argtypes = [i64, i64]
         L.gbx_chain_workspace_bytes.restype = sz

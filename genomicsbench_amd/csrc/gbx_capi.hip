@@ -367,4 +367,105 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
     return GBX_OK;
 }
 
+/* -------------------------------------------------------------------- phmm */
+int gbx_phmm_init(void)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    return phmm_init_tables();
+}
+
+size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int32_t max_hap_len) { return phmm_workspace_bytes(n_pairs, max_hap_len); }
+
+int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const int32_t *d_pair_hap,
+                            const int64_t *d_read_off, const int32_t *d_read_len,
+                            const uint8_t *d_rs, const uint8_t *d_q, const uint8_t *d_i, const uint8_t *d_d,
+                            const uint8_t *d_c,
+                            const int64_t *d_hap_off, const int32_t *d_hap_len, const uint8_t *d_hap,
+                            int32_t max_hap_len, double *d_out, void *d_work, size_t work_bytes, void *stream)
+{
+    if (n_pairs < 0 || max_hap_len < 0 || max_hap_len > GBX_PHMM_MAX_HAPLEN) {
+        set_error("gbx_phmm_forward_device: bad argument");
+        return GBX_ERR_ARG;
+    }
+    if (n_pairs == 0) return GBX_OK;
+    if (!d_pair_read || !d_pair_hap || !d_read_off || !d_read_len || !d_rs || !d_q || !d_i || !d_d || !d_c ||
+        !d_hap_off || !d_hap_len || !d_hap || !d_out || !d_work) {
+        set_error("gbx_phmm_forward_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return phmm_launch(n_pairs, d_pair_read, d_pair_hap, d_read_off, d_read_len, d_rs, d_q, d_i, d_d, d_c,
+                       d_hap_off, d_hap_len, d_hap, max_hap_len, d_out, d_work, work_bytes, (hipStream_t)stream);
+}
+
+int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
+                          int64_t n_reads, const int64_t *read_off, const int32_t *read_len, int64_t read_bytes,
+                          const uint8_t *rs, const uint8_t *q, const uint8_t *i, const uint8_t *d, const uint8_t *c,
+                          int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
+                          const uint8_t *hap, double *out)
+{
+    if (n_pairs < 0 || n_reads < 0 || n_haps < 0 || read_bytes < 0 || hap_bytes < 0) {
+        set_error("gbx_phmm_forward_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    if (n_pairs == 0) return GBX_OK;
+    if (!pair_read || !pair_hap || !read_off || !read_len || !rs || !q || !i || !d || !c || !hap_off || !hap_len ||
+        !hap || !out) {
+        set_error("gbx_phmm_forward_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int max_h = 1;
+    for (int64_t k = 0; k < n_reads; ++k)
+        if (read_len[k] < 0 || read_off[k] < 0 || read_off[k] + read_len[k] > read_bytes) {
+            set_error("gbx_phmm_forward_host: read %lld lies outside the arena", (long long)k);
+            return GBX_ERR_ARG;
+        }
+    for (int64_t k = 0; k < n_haps; ++k) {
+        if (hap_len[k] < 0 || hap_off[k] < 0 || hap_off[k] + hap_len[k] > hap_bytes) {
+            set_error("gbx_phmm_forward_host: haplotype %lld lies outside the arena", (long long)k);
+            return GBX_ERR_ARG;
+        }
+        if (hap_len[k] > GBX_PHMM_MAX_HAPLEN) {
+            set_error("gbx_phmm_forward_host: haplotype %lld longer than GBX_PHMM_MAX_HAPLEN", (long long)k);
+            return GBX_ERR_UNSUPPORTED;
+        }
+        if (hap_len[k] > max_h) max_h = hap_len[k];
+    }
+    for (int64_t k = 0; k < n_pairs; ++k)
+        if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) {
+            set_error("gbx_phmm_forward_host: pair %lld names a read/haplotype out of range", (long long)k);
+            return GBX_ERR_ARG;
+        }
+    int rc = require_device();
+    if (rc) return rc;
+    DevBuf dpr, dph, dro, drl, drs, dq, di, dd, dc, dho, dhl, dh, dout, dw;
+    const size_t wb = phmm_workspace_bytes(n_pairs, max_h);
+    if ((rc = dpr.alloc(n_pairs * 4)) || (rc = dph.alloc(n_pairs * 4)) || (rc = dro.alloc(n_reads * 8)) ||
+        (rc = drl.alloc(n_reads * 4)) || (rc = drs.alloc(read_bytes)) || (rc = dq.alloc(read_bytes)) ||
+        (rc = di.alloc(read_bytes)) || (rc = dd.alloc(read_bytes)) || (rc = dc.alloc(read_bytes)) ||
+        (rc = dho.alloc(n_haps * 8)) || (rc = dhl.alloc(n_haps * 4)) || (rc = dh.alloc(hap_bytes)) ||
+        (rc = dout.alloc(n_pairs * 8)) || (rc = dw.alloc(wb)))
+        return rc;
+    hipStream_t s = nullptr;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        if (bytes) GBX_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
+        return GBX_OK;
+    };
+    if ((rc = up(dpr, pair_read, n_pairs * 4)) || (rc = up(dph, pair_hap, n_pairs * 4)) ||
+        (rc = up(dro, read_off, n_reads * 8)) || (rc = up(drl, read_len, n_reads * 4)) ||
+        (rc = up(drs, rs, read_bytes)) || (rc = up(dq, q, read_bytes)) || (rc = up(di, i, read_bytes)) ||
+        (rc = up(dd, d, read_bytes)) || (rc = up(dc, c, read_bytes)) || (rc = up(dho, hap_off, n_haps * 8)) ||
+        (rc = up(dhl, hap_len, n_haps * 4)) || (rc = up(dh, hap, hap_bytes)))
+        return rc;
+    rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), dro.as<int64_t>(), drl.as<int32_t>(),
+                     drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
+                     dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb, s);
+    if (rc) return rc;
+    GBX_HIP(hipMemcpyAsync(out, dout.p, n_pairs * 8, hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    return GBX_OK;
+}
+
 }  // extern "C"

@@ -25,6 +25,8 @@ def _L():
         _lib.gbx_gen_chain_count.restype = i64
         _lib.gbx_gen_chain_fill.argtypes = [u64, i64, i64, vp, vp]
         _lib.gbx_gen_chain_fill.restype = None
+        _lib.gbx_gen_phmm_batch.argtypes = [u64, i64, C.c_int] + [vp] * 10
+        _lib.gbx_gen_phmm_batch.restype = None
     return _lib
 
 
@@ -70,3 +72,32 @@ def gen_chain(n_calls, seed, first=0, n_override=None):
     hdr["bw"] = 500
     hdr["n_segs"] = 1
     return off, ax, ay, hdr
+
+
+def gen_phmm(n_batches, seed, first=0):
+    """phmm 'large' = (20_000 batches, seed 3001).  Returns a PhmmBatchSet (flat arenas + pair list)."""
+    from ..phmm import PhmmBatchSet
+    L = _L()
+    nr = np.zeros(n_batches, dtype=np.int32)
+    nh = np.zeros(n_batches, dtype=np.int32)
+    one = lambda a, k: C.c_void_p(a.ctypes.data + a.itemsize * int(k))
+    for b in range(n_batches):
+        L.gbx_gen_phmm_batch(seed, first + b, 0, one(nr, b), one(nh, b), *([None] * 8))
+    roff = np.zeros(n_batches + 1, dtype=np.int64); np.cumsum(nr, out=roff[1:])
+    hoff = np.zeros(n_batches + 1, dtype=np.int64); np.cumsum(nh, out=hoff[1:])
+    read_len = np.zeros(int(roff[-1]), dtype=np.int32)
+    hap_len = np.zeros(int(hoff[-1]), dtype=np.int32)
+    t1, t2 = C.c_int32(), C.c_int32()
+    for b in range(n_batches):
+        L.gbx_gen_phmm_batch(seed, first + b, 1, C.byref(t1), C.byref(t2), one(read_len, roff[b]),
+                             one(hap_len, hoff[b]), *([None] * 6))
+    read_off = np.zeros(len(read_len) + 1, dtype=np.int64); np.cumsum(read_len, out=read_off[1:])
+    hap_off = np.zeros(len(hap_len) + 1, dtype=np.int64); np.cumsum(hap_len, out=hap_off[1:])
+    rs, q, qi, qd, qc = (np.zeros(int(read_off[-1]) + 8, dtype=np.uint8) for _ in range(5))
+    hap = np.zeros(int(hap_off[-1]) + 8, dtype=np.uint8)
+    tl, th = np.zeros(128, np.int32), np.zeros(16, np.int32)
+    for b in range(n_batches):
+        ro, ho = read_off[roff[b]], hap_off[hoff[b]]
+        L.gbx_gen_phmm_batch(seed, first + b, 2, C.byref(t1), C.byref(t2), _p(tl), _p(th), one(rs, ro), one(q, ro),
+                             one(qi, ro), one(qd, ro), one(qc, ro), one(hap, ho))
+    return PhmmBatchSet(nr, nh, read_off[:-1].copy(), read_len, rs, q, qi, qd, qc, hap_off[:-1].copy(), hap_len, hap)

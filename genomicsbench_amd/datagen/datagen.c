@@ -146,3 +146,61 @@ void gbx_gen_chain_fill(uint64_t seed, int64_t call, int64_t n, uint64_t *ax, ui
     for (int64_t k = 0; k < n; ++k) { ax[k] = tmp[2 * k]; ay[k] = tmp[2 * k + 1]; }
     free(tmp);
 }
+
+/* ------------------------------------------------------------------ phmm
+ * batch b: num_reads ~ U[1,120], num_haps ~ U[2,16]; a backbone of U[150,450]
+ * bases; every haplotype = backbone with 1 % SNPs and 0.5 % single-base indels;
+ * reads are 151 bp (10 % shorter, U[30,151]) sampled from a random haplotype
+ * with 1 % substitution errors; 0.1 % 'N' everywhere; q ~ U[2,41] (stored
+ * already normalised as the driver does: minus 33, q clamped >= 6,
+ * PairHMMUnitTest.cpp:89-93,110-113), i,d ~ U[40,50], c = 10.
+ * mode 0: counts only; mode 1: + lengths; mode 2: + bytes.
+ */
+static const char BASES[4] = {'A', 'C', 'G', 'T'};
+void gbx_gen_phmm_batch(uint64_t seed, int64_t batch, int mode, int32_t *n_reads, int32_t *n_haps,
+                        int32_t *read_len, int32_t *hap_len,
+                        char *rs, char *q, char *qi, char *qd, char *qc, char *hap)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)batch);
+    const int nr = 1 + (int)rng_below(&r, 120), nh = 2 + (int)rng_below(&r, 15);
+    *n_reads = nr; *n_haps = nh;
+    if (mode == 0) return;
+    char backbone[512];
+    const int lb = 150 + (int)rng_below(&r, 301);
+    for (int k = 0; k < lb; ++k) backbone[k] = BASES[rng_below(&r, 4)];
+    char haps[16][480];
+    int hl[16];
+    for (int h = 0; h < nh; ++h) {
+        int o = 0;
+        for (int k = 0; k < lb && o < 470; ++k) {
+            double u = rng_unif(&r);
+            if (u < 0.0025) continue;                                  /* deletion */
+            char b = backbone[k];
+            if (u < 0.0125) b = BASES[rng_below(&r, 4)];               /* SNP (may be silent) */
+            if (rng_below(&r, 1000) == 0) b = 'N';
+            haps[h][o++] = b;
+            if (rng_unif(&r) < 0.0025) haps[h][o++] = BASES[rng_below(&r, 4)];   /* insertion */
+        }
+        if (o < 8) { while (o < 8) haps[h][o++] = BASES[rng_below(&r, 4)]; }
+        hl[h] = o; hap_len[h] = o;
+        if (mode == 2) { memcpy(hap, haps[h], (size_t)o); hap += o; }
+    }
+    for (int k = 0; k < nr; ++k) {
+        const int h = (int)rng_below(&r, (uint32_t)nh);
+        int len = rng_below(&r, 10) == 0 ? 30 + (int)rng_below(&r, 122) : 151;
+        if (len > hl[h]) len = hl[h];
+        const int start = (int)rng_below(&r, (uint32_t)(hl[h] - len + 1));
+        read_len[k] = len;
+        for (int j = 0; j < len; ++j) {
+            char b = haps[h][start + j];
+            const uint32_t e = rng_below(&r, 1000);
+            if (e < 10) b = BASES[rng_below(&r, 4)];
+            else if (e == 10) b = 'N';
+            int qq = 2 + (int)rng_below(&r, 40); if (qq < 6) qq = 6;
+            const int ii = 40 + (int)rng_below(&r, 11), dd = 40 + (int)rng_below(&r, 11);
+            if (mode == 2) { rs[j] = b; q[j] = (char)qq; qi[j] = (char)ii; qd[j] = (char)dd; qc[j] = 10; }
+        }
+        if (mode == 2) { rs += len; q += len; qi += len; qd += len; qc += len; }
+    }
+}

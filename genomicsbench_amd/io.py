@@ -1,6 +1,7 @@
 """Readers / writers for the reference benchmarks' on-disk formats.
 
 bsw   : 3 text lines per pair (h0, target digits 0-4, query digits 0-4)   R/benchmarks/bsw/main_banded.cpp:131-185
+phmm  : per batch `num_reads num_haps`, reads `bases q i d c` (Phred+33), haplotypes        R/benchmarks/phmm/PairHMMUnitTest.cpp:95-140
 chain : `n avg_qspan max_dist_x max_dist_y bw n_segs`, n lines `x y`, `EOR`  R/benchmarks/chain/src/host_data_io.cpp:13-60
 """
 import gzip
@@ -91,3 +92,52 @@ def write_chain_returns(path_or_file, off, score, parent):
         f.write("EOR\n")
     if f is not path_or_file:
         f.close()
+
+
+# ---------------------------------------------------------------------------- phmm
+def write_phmm_batches(path, bs):
+    """Quality tracks are stored normalised (minus 33, q >= 6); the file carries Phred+33 ASCII."""
+    asc = lambda a: (a + 33).astype(np.uint8).tobytes().decode()
+    with _open(path, "w") as f:
+        r = h = 0
+        for b in range(len(bs.n_reads)):
+            f.write("%d %d\n" % (bs.n_reads[b], bs.n_haps[b]))
+            for _ in range(bs.n_reads[b]):
+                o, n = int(bs.read_off[r]), int(bs.read_len[r])
+                f.write("%s %s %s %s %s\n" % (bs.rs[o:o + n].tobytes().decode(), asc(bs.q[o:o + n]),
+                                              asc(bs.qi[o:o + n]), asc(bs.qd[o:o + n]), asc(bs.qc[o:o + n])))
+                r += 1
+            for _ in range(bs.n_haps[b]):
+                o, n = int(bs.hap_off[h]), int(bs.hap_len[h])
+                f.write("%s\n" % bs.hap[o:o + n].tobytes().decode())
+                h += 1
+
+
+def read_phmm_batches(path):
+    """read_testfile / read_batch: whitespace-separated tokens; normalize(): max(min, ch-33), q min 6."""
+    from .phmm import PhmmBatchSet
+    with _open(path, "r") as f:
+        toks = f.read().split()
+    p = 0
+    nr, nh, rl, hl = [], [], [], []
+    rs, q, qi, qd, qc, hp = [], [], [], [], [], []
+    norm = lambda s, lo: np.maximum(np.frombuffer(s.encode(), dtype=np.uint8).astype(np.int32) - 33, lo).astype(np.uint8)
+    while p + 2 <= len(toks):
+        a, b = int(toks[p]), int(toks[p + 1])
+        p += 2
+        nr.append(a)
+        nh.append(b)
+        for _ in range(a):
+            rs.append(np.frombuffer(toks[p].encode(), dtype=np.uint8))
+            q.append(norm(toks[p + 1], 6)); qi.append(norm(toks[p + 2], 0))
+            qd.append(norm(toks[p + 3], 0)); qc.append(norm(toks[p + 4], 0))
+            rl.append(len(toks[p]))
+            p += 5
+        for _ in range(b):
+            hp.append(np.frombuffer(toks[p].encode(), dtype=np.uint8))
+            hl.append(len(toks[p]))
+            p += 1
+    cat = lambda xs: np.concatenate(xs + [np.zeros(8, np.uint8)]) if xs else np.zeros(8, np.uint8)
+    roff = np.concatenate([[0], np.cumsum(rl)])[:-1] if rl else np.zeros(0, np.int64)
+    hoff = np.concatenate([[0], np.cumsum(hl)])[:-1] if hl else np.zeros(0, np.int64)
+    return PhmmBatchSet(nr, nh, roff, rl, cat(rs), cat(q), cat(qi), cat(qd), cat(qc), hoff, hl, cat(hp))

@@ -165,6 +165,36 @@ int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor
                      int32_t *d_target, int32_t *d_peak,
                      void *d_work, size_t work_bytes, void *stream);
 
+/* -------------------------------------------------------------------- phmm
+ * GATK/GKL Pair-HMM forward log10-likelihoods.
+ * Replaces  void initPairHMM()                                     R/benchmarks/phmm/PairHMMUnitTest.cpp:84,193
+ *           void computelikelihoodsboth(testcase*, double*, int)   R/benchmarks/phmm/PairHMMUnitTest.cpp:86,245
+ *           (C++-mangled symbols of libgkl_pairhmm_c.so; `testcase` = pairhmm_common.h:20-24)
+ * Reads live in one arena per track (bases rs and the four quality tracks q,i,d,c share
+ * read_off/read_len; qualities already Phred-33 as the driver normalises them,
+ * PairHMMUnitTest.cpp:89-93,110-113), haplotypes in another; pair p = (read pair_read[p],
+ * haplotype pair_hap[p]).  out[p] = log10 likelihood (fp32 pass, fp64 redo below 1e-28f,
+ * pairhmm_common.h:16).  Tolerance vs the CPU path: 1e-5 relative.
+ */
+#define GBX_PHMM_MAX_HAPLEN 32768     /* MAX_HAP_LENGTH, PairHMMUnitTest.h:36 */
+
+int gbx_phmm_init(void);              /* builds + uploads the probability tables (initPairHMM) */
+
+int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
+                          int64_t n_reads, const int64_t *read_off, const int32_t *read_len, int64_t read_bytes,
+                          const uint8_t *rs, const uint8_t *q, const uint8_t *i, const uint8_t *d, const uint8_t *c,
+                          int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
+                          const uint8_t *hap, double *out);
+
+size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int32_t max_hap_len);
+int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const int32_t *d_pair_hap,
+                            const int64_t *d_read_off, const int32_t *d_read_len,
+                            const uint8_t *d_rs, const uint8_t *d_q, const uint8_t *d_i, const uint8_t *d_d,
+                            const uint8_t *d_c,
+                            const int64_t *d_hap_off, const int32_t *d_hap_len, const uint8_t *d_hap,
+                            int32_t max_hap_len, double *d_out,
+                            void *d_work, size_t work_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,20 @@ void oracle_chain(int64_t n_calls, const int64_t *anchor_off,
                   int32_t *score, int32_t *parent, int32_t *target, int32_t *peak,
                   int nthreads, int64_t *pairs_evaluated);
 
+/* phmm: GKL compute_full_prob<float|double> + computelikelihoodsboth policy (parity UNPINNED, see phmm_oracle.c) */
+void   oracle_phmm_init(void);
+double oracle_phmm_pair(int rslen, int haplen, const char *rs, const char *hap, const char *q,
+                        const char *qi, const char *qd, const char *qc, int *used_double);
+double oracle_phmm_pair_f64(int rslen, int haplen, const char *rs, const char *hap, const char *q,
+                            const char *qi, const char *qd, const char *qc);
+void   oracle_phmm_forward(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
+                           const int64_t *read_off, const int32_t *read_len,
+                           const char *rs, const char *q, const char *qi, const char *qd, const char *qc,
+                           const int64_t *hap_off, const int32_t *hap_len, const char *hap,
+                           double *out, int nthreads, int64_t *n_double);
+const float  *oracle_phmm_mm_table_f(void);
+const double *oracle_phmm_mm_table_d(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,3 +83,29 @@ def chain_ref(off, ax, ay, hdr, nthreads=1):
     score, parent, target, peak = (np.zeros(n, dtype=np.int32) for _ in range(4))
     L.ref_chain(*_chain_args(off, ax, ay, hdr, score, parent, target, peak), C.c_int(nthreads))
     return score, parent, target, peak
+
+
+def phmm_oracle(bs, nthreads=1, return_ndouble=False):
+    """oracle_phmm_forward over a PhmmBatchSet -> float64[n_pairs] (and the count of fp64 fallbacks)."""
+    out = np.zeros(bs.n_pairs, dtype=np.float64)
+    nd = C.c_int64(0)
+    f = oracle_lib().oracle_phmm_forward
+    f.restype = None
+    f(C.c_int64(bs.n_pairs), _p(bs.pair_read), _p(bs.pair_hap), _p(bs.read_off), _p(bs.read_len), _p(bs.rs),
+      _p(bs.q), _p(bs.qi), _p(bs.qd), _p(bs.qc), _p(bs.hap_off), _p(bs.hap_len), _p(bs.hap), _p(out),
+      C.c_int(nthreads), C.byref(nd))
+    return (out, nd.value) if return_ndouble else out
+
+
+def phmm_pair(rs, hap, q, qi, qd, qc, f64_only=False):
+    """One pair from python byte strings / uint8 arrays (already normalised qualities)."""
+    L = oracle_lib()
+    b = lambda a: bytes(bytearray(np.asarray(a, dtype=np.uint8).tolist())) if not isinstance(a, (bytes, str)) else (
+        a.encode() if isinstance(a, str) else a)
+    rs, hap, q, qi, qd, qc = b(rs), b(hap), b(q), b(qi), b(qd), b(qc)
+    if f64_only:
+        L.oracle_phmm_pair_f64.restype = C.c_double
+        return L.oracle_phmm_pair_f64(len(rs), len(hap), rs, hap, q, qi, qd, qc)
+    L.oracle_phmm_pair.restype = C.c_double
+    ud = C.c_int(0)
+    return L.oracle_phmm_pair(len(rs), len(hap), rs, hap, q, qi, qd, qc, C.byref(ud)), ud.value
