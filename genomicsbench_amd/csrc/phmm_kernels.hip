@@ -33,10 +33,11 @@ constexpr int MM_USED = ((QUAL_LIMIT - 1) * QUAL_LIMIT) / 2 + QUAL_LIMIT;   // e
 constexpr int NPCLS = 6;                                      // RPL 1,2,3,4,6,8(+tiles)
 constexpr int TILED_BLOCKS = 256;                             // wave slots that own a scratch row
 
-__device__ float d_ph2pr_f[QUAL_LIMIT];
-__device__ double d_ph2pr_d[QUAL_LIMIT];
-__device__ float d_mm_f[MM_USED];
-__device__ double d_mm_d[MM_USED];
+// probability tables in device memory (one hipMalloc per device, filled by upload_tables)
+struct DevTables {
+    const float *ph2pr_f, *mm_f;
+    const double *ph2pr_d, *mm_d;
+};
 
 __host__ __device__ inline int class_of_rows(int R)
 {
@@ -45,13 +46,17 @@ __host__ __device__ inline int class_of_rows(int R)
 
 template <typename T> struct Tab;
 template <> struct Tab<float> {
-    __device__ static float ph2pr(int x) { return d_ph2pr_f[x]; }
-    __device__ static float mm(int x) { return d_mm_f[x]; }
+    const float *ph, *mmt;
+    __device__ explicit Tab(const DevTables &t) : ph(t.ph2pr_f), mmt(t.mm_f) {}
+    __device__ float ph2pr(int x) const { return ph[x]; }
+    __device__ float mm(int x) const { return mmt[x]; }
     __device__ static float init() { return ldexpf(1.f, 120); }
 };
 template <> struct Tab<double> {
-    __device__ static double ph2pr(int x) { return d_ph2pr_d[x]; }
-    __device__ static double mm(int x) { return d_mm_d[x]; }
+    const double *ph, *mmt;
+    __device__ explicit Tab(const DevTables &t) : ph(t.ph2pr_d), mmt(t.mm_d) {}
+    __device__ double ph2pr(int x) const { return ph[x]; }
+    __device__ double mm(int x) const { return mmt[x]; }
     __device__ static double init() { return ldexp(1.0, 1020); }
 };
 
@@ -145,6 +150,7 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
     const int ntiles = (R + TILE - 1) / TILE;
     const int rows0 = R - (ntiles - 1) * TILE;              // tile 0 takes the remainder, later tiles are full
     const T zero = (T)0, one = (T)1;
+    const Tab<T> tab(A.tab);
     const T yinit = Tab<T>::init() / (T)H;                   // Y[0][c], every column
     T result = zero;
 
@@ -175,11 +181,11 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
                 const int _i = A.qi[ro + r] & 127, _d = A.qd[ro + r] & 127, _c = A.qc[ro + r] & 127;
                 const int _q = A.q[ro + r] & 127;
                 const int mn = min(_i, _d), mx = max(_i, _d);
-                pMM[k] = Tab<T>::mm(((mx * (mx + 1)) >> 1) + mn);
-                pGap[k] = one - Tab<T>::ph2pr(_c);
-                pMX[k] = Tab<T>::ph2pr(_i); pXX[k] = Tab<T>::ph2pr(_c);
-                pMY[k] = Tab<T>::ph2pr(_d); pYY[k] = Tab<T>::ph2pr(_c);
-                const T e = Tab<T>::ph2pr(_q);
+                pMM[k] = tab.mm(((mx * (mx + 1)) >> 1) + mn);
+                pGap[k] = one - tab.ph2pr(_c);
+                pMX[k] = tab.ph2pr(_i); pXX[k] = tab.ph2pr(_c);
+                pMY[k] = tab.ph2pr(_d); pYY[k] = tab.ph2pr(_c);
+                const T e = tab.ph2pr(_q);
                 rch[k] = A.rs[ro + r];
                 pm[k] = one - e;                                         // prior when the bases match
                 px[k] = rch[k] == 'N' ? one - e : e / (T)3;              // otherwise ('N' always matches)
@@ -339,20 +345,27 @@ const HostTables &host_tables()
     return t;
 }
 
-int upload_tables()
+int upload_tables(DevTables *out)
 {
     static std::mutex mu;
-    static std::vector<int> done;
+    static std::vector<std::pair<int, DevTables>> done;
     int dev = 0;
     GBX_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    for (int d : done) if (d == dev) return GBX_OK;
+    for (auto &d : done) if (d.first == dev) { *out = d.second; return GBX_OK; }
     const HostTables &t = host_tables();
-    GBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_ph2pr_f), t.ph_f.data(), sizeof(float) * QUAL_LIMIT));
-    GBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_ph2pr_d), t.ph_d.data(), sizeof(double) * QUAL_LIMIT));
-    GBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_mm_f), t.mm_f.data(), sizeof(float) * MM_USED));
-    GBX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_mm_d), t.mm_d.data(), sizeof(double) * MM_USED));
-    done.push_back(dev);
+    const size_t bf = sizeof(float) * (QUAL_LIMIT + MM_USED), bd = sizeof(double) * (QUAL_LIMIT + MM_USED);
+    char *buf = nullptr;
+    GBX_HIP(hipMalloc((void **)&buf, bf + bd + 64));
+    double *dd = (double *)buf;                    // doubles first (alignment)
+    float *df = (float *)(buf + bd);
+    GBX_HIP(hipMemcpy(dd, t.ph_d.data(), sizeof(double) * QUAL_LIMIT, hipMemcpyHostToDevice));
+    GBX_HIP(hipMemcpy(dd + QUAL_LIMIT, t.mm_d.data(), sizeof(double) * MM_USED, hipMemcpyHostToDevice));
+    GBX_HIP(hipMemcpy(df, t.ph_f.data(), sizeof(float) * QUAL_LIMIT, hipMemcpyHostToDevice));
+    GBX_HIP(hipMemcpy(df + QUAL_LIMIT, t.mm_f.data(), sizeof(float) * MM_USED, hipMemcpyHostToDevice));
+    DevTables d = {df, df + QUAL_LIMIT, dd, dd + QUAL_LIMIT};
+    done.emplace_back(dev, d);
+    *out = d;
     return GBX_OK;
 }
 
@@ -372,7 +385,7 @@ size_t phmm_workspace_bytes(int64_t n_pairs, int max_hap_len)
     return 64 * sizeof(int32_t) + (size_t)n_pairs * 2 * sizeof(int32_t) + 64 + (size_t)TILED_BLOCKS * scratch_stride_bytes(max_hap_len);
 }
 
-int phmm_init_tables() { return upload_tables(); }
+int phmm_init_tables() { DevTables t; return upload_tables(&t); }
 
 const float *phmm_host_mm_table_f(int *n) { if (n) *n = MM_USED; return host_tables().mm_f.data(); }
 
@@ -385,9 +398,10 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     if (n_pairs == 0) return GBX_OK;
     if (n_pairs > 0x7fffffffLL - 1024) { set_error("phmm: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
     if (work_bytes < phmm_workspace_bytes(n_pairs, max_hap_len)) { set_error("phmm: workspace too small"); return GBX_ERR_ARG; }
-    int rc = upload_tables();
+    DevTables tabs;
+    int rc = upload_tables(&tabs);
     if (rc) return rc;
-    PhmmArgs A = {pair_read, pair_hap, read_off, read_len, rs, q, qi, qd, qc, hap_off, hap_len, hap, out};
+    PhmmArgs A = {pair_read, pair_hap, read_off, read_len, rs, q, qi, qd, qc, hap_off, hap_len, hap, out, tabs};
     int32_t *wi = (int32_t *)d_work;
     PhmmWork W;
     W.counts = wi; W.cursors = wi + 8; W.next = wi + 16; W.dcount = wi + 24;

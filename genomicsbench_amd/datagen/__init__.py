@@ -27,6 +27,8 @@ def _L():
         _lib.gbx_gen_chain_fill.restype = None
         _lib.gbx_gen_phmm_batch.argtypes = [u64, i64, C.c_int] + [vp] * 10
         _lib.gbx_gen_phmm_batch.restype = None
+        _lib.gbx_gen_poa_window.argtypes = [u64, i64, C.c_int, vp, vp, vp]
+        _lib.gbx_gen_poa_window.restype = None
     return _lib
 
 
@@ -101,3 +103,24 @@ def gen_phmm(n_batches, seed, first=0):
         L.gbx_gen_phmm_batch(seed, first + b, 2, C.byref(t1), C.byref(t2), _p(tl), _p(th), one(rs, ro), one(q, ro),
                              one(qi, ro), one(qd, ro), one(qc, ro), one(hap, ho))
     return PhmmBatchSet(nr, nh, read_off[:-1].copy(), read_len, rs, q, qi, qd, qc, hap_off[:-1].copy(), hap_len, hap)
+
+
+def gen_poa(n_windows, seed, first=0):
+    """poa 'large' = (6_000 windows, seed 4001).  Returns a PoaWindowSet."""
+    from ..poa import PoaWindowSet
+    L = _L()
+    nr = np.zeros(n_windows, dtype=np.int32)
+    one = lambda a, k: C.c_void_p(a.ctypes.data + a.itemsize * int(k))
+    for w in range(n_windows):
+        L.gbx_gen_poa_window(seed, first + w, 0, one(nr, w), None, None)
+    wf = np.zeros(n_windows + 1, dtype=np.int64); np.cumsum(nr, out=wf[1:])
+    lens = np.zeros(int(wf[-1]), dtype=np.int32)
+    t = C.c_int32()
+    for w in range(n_windows):
+        L.gbx_gen_poa_window(seed, first + w, 1, C.byref(t), one(lens, wf[w]), None)
+    off = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=off[1:])
+    arena = np.zeros(int(off[-1]) + 8, dtype=np.uint8)
+    tl = np.zeros(64, np.int32)
+    for w in range(n_windows):
+        L.gbx_gen_poa_window(seed, first + w, 2, C.byref(t), _p(tl), one(arena, off[wf[w]]))
+    return PoaWindowSet(wf, off[:-1].copy(), lens, arena)

@@ -204,3 +204,34 @@ void gbx_gen_phmm_batch(uint64_t seed, int64_t batch, int mode, int32_t *n_reads
         if (mode == 2) { rs += len; q += len; qi += len; qd += len; qc += len; }
     }
 }
+
+/* ------------------------------------------------------------------- poa
+ * window w: a 500-bp backbone ~U{ACGT}; 20-40 reads = backbone with 6 %
+ * substitutions, 4 % insertions, 4 % deletions, each read trimmed by up to 30
+ * bases at either end (lengths ~ 450-560).  mode 0: count; 1: lengths; 2: bytes.
+ */
+void gbx_gen_poa_window(uint64_t seed, int64_t window, int mode, int32_t *n_reads, int32_t *read_len, char *out)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)window);
+    const int nr = 20 + (int)rng_below(&r, 21);
+    *n_reads = nr;
+    if (mode == 0) return;
+    char backbone[500];
+    for (int k = 0; k < 500; ++k) backbone[k] = BASES[rng_below(&r, 4)];
+    char buf[1024];
+    for (int k = 0; k < nr; ++k) {
+        const int a = (int)rng_below(&r, 31), b = 500 - (int)rng_below(&r, 31);
+        int o = 0;
+        for (int j = a; j < b && o < 1000; ++j) {
+            const uint32_t u = rng_below(&r, 100);
+            if (u < 4) continue;                                             /* deletion */
+            char ch = backbone[j];
+            if (u < 10) ch = BASES[(rng_below(&r, 3) + 1 + (uint32_t)(strchr("ACGT", ch) - "ACGT")) & 3];   /* substitution */
+            buf[o++] = ch;
+            if (rng_below(&r, 100) < 4) buf[o++] = BASES[rng_below(&r, 4)];  /* insertion */
+        }
+        read_len[k] = o;
+        if (mode == 2) { memcpy(out, buf, (size_t)o); out += o; }
+    }
+}

@@ -1,0 +1,62 @@
+"""Host mirror of the reference poa interface (spoa calls at R/benchmarks/poa/msa_spoa_omp.cpp:184-252).
+
+A window ("Batch" in the driver, :42-47) is a list of sequences; the product computes one consensus
+string per window on the GPU through libgbx.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class PoaParams(C.Structure):
+    _fields_ = [("m", C.c_int8), ("n", C.c_int8), ("g", C.c_int8), ("e", C.c_int8), ("q", C.c_int8), ("c", C.c_int8),
+                ("pad_", C.c_int8 * 2)]
+
+
+def make_params(m=2, x=4, o1=4, e1=2, o2=24, e2=1):
+    """Driver CLI semantics (-m, -x, -o a,b, -e a,b): g = -(o1+e1), e = -e1, q = -(o2+e2), c = -e2."""
+    return PoaParams(m, -x, -(o1 + e1), -e1, -(o2 + e2), -e2)
+
+
+class PoaWindowSet:
+    def __init__(self, win_first_seq, seq_off, seq_len, arena):
+        self.win_first_seq = np.ascontiguousarray(win_first_seq, dtype=np.int64)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        self.seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        self.arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        self.n_windows = len(self.win_first_seq) - 1
+        self.n_seqs = len(self.seq_len)
+
+    @staticmethod
+    def from_lists(windows):
+        """windows: list of lists of python strings."""
+        lens = [len(s) for w in windows for s in w]
+        wf = np.concatenate([[0], np.cumsum([len(w) for w in windows])]).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        arena = np.frombuffer(("".join(s for w in windows for s in w) + "\\0" * 8).encode(), dtype=np.uint8).copy()
+        return PoaWindowSet(wf, off[:-1], lens, arena)
+
+    def window(self, w):
+        a, b = int(self.win_first_seq[w]), int(self.win_first_seq[w + 1])
+        return [self.arena[self.seq_off[s]:self.seq_off[s] + self.seq_len[s]].tobytes().decode() for s in range(a, b)]
+
+    def take(self, lo, hi):
+        a, b = int(self.win_first_seq[lo]), int(self.win_first_seq[hi])
+        return PoaWindowSet(self.win_first_seq[lo:hi + 1] - a, self.seq_off[a:b], self.seq_len[a:b], self.arena)
+
+    @property
+    def default_stride(self):
+        return int(2 * (self.seq_len.max() if self.n_seqs else 0) + 64)
+
+
+def consensus_host(params, ws, stride=None):
+    """gbx_poa_consensus_host -> list of consensus strings (one per window)."""
+    stride = stride or ws.default_stride
+    cons = np.zeros((max(ws.n_windows, 1), stride), dtype=np.uint8)
+    clen = np.zeros(max(ws.n_windows, 1), dtype=np.int32)
+    N.check(N.lib().gbx_poa_consensus_host(C.byref(params), ws.n_windows, N.ptr(ws.win_first_seq), ws.n_seqs,
+                                           N.ptr(ws.seq_off), N.ptr(ws.seq_len), N.ptr(ws.arena), ws.arena.size,
+                                           N.ptr(cons), N.ptr(clen), stride))
+    return [cons[w, :clen[w]].tobytes().decode() for w in range(ws.n_windows)]

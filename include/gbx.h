@@ -195,6 +195,33 @@ int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const i
                             int32_t max_hap_len, double *d_out,
                             void *d_work, size_t work_bytes, void *stream);
 
+/* --------------------------------------------------------------------- poa
+ * Partial-order-alignment consensus (spoa).
+ * Replaces, at whole-window granularity, the driver's per-window loop
+ *   spoa::createAlignmentEngine(kNW, m, n, g, e, q, c)   R/benchmarks/poa/msa_spoa_omp.cpp:189-190
+ *   spoa::createGraph()                                   :237
+ *   AlignmentEngine::align(seq, graph)                    :242
+ *   Graph::add_alignment(alignment, seq)                  :247
+ *   Graph::generate_consensus()                           :252
+ * Window w owns sequences [win_first_seq[w], win_first_seq[w+1]); sequence s is
+ * arena[seq_off[s] .. seq_off[s]+seq_len[s]).
+ */
+typedef struct gbx_poa_params {
+    int8_t m, n;      /* match score (2) and mismatch score (-4), msa_spoa_omp.cpp:157-158 */
+    int8_t g, e;      /* first gap piece: open(-6 = o1+e1) / extend(-2), :184 */
+    int8_t q, c;      /* second gap piece: open(-25 = o2+e2) / extend(-1) */
+    int8_t pad_[2];
+} gbx_poa_params;
+
+void gbx_poa_default_params(gbx_poa_params *p);
+
+/* cons: n_windows rows of cons_stride bytes (not NUL-terminated), cons_len[w] = consensus length
+ * (if it exceeds cons_stride the row is truncated and the call returns GBX_ERR_UNSUPPORTED). */
+int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                           const char *arena, int64_t arena_bytes,
+                           char *cons, int32_t *cons_len, int64_t cons_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,13 @@ void   oracle_phmm_forward(int64_t n_pairs, const int32_t *pair_read, const int3
 const float  *oracle_phmm_mm_table_f(void);
 const double *oracle_phmm_mm_table_d(void);
 
+/* poa: spoa v3 NW convex/affine alignment + graph + heaviest-bundle consensus (parity UNPINNED, see poa_oracle.c) */
+int  oracle_poa_window(const gbx_poa_params *P, int n_seqs, const char *const *seqs, const int32_t *lens,
+                       char *cons, int64_t cons_cap, int64_t *stats /* nodes, edges, DP cells */);
+void oracle_poa_consensus(const gbx_poa_params *P, int64_t n_windows, const int64_t *win_first_seq,
+                          const int64_t *seq_off, const int32_t *seq_len, const char *arena,
+                          char *cons, int32_t *cons_len, int64_t cons_stride, int nthreads, int64_t *cells);
+
 #ifdef __cplusplus
 }
 #endif

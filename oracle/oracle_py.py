@@ -109,3 +109,17 @@ def phmm_pair(rs, hap, q, qi, qd, qc, f64_only=False):
     L.oracle_phmm_pair.restype = C.c_double
     ud = C.c_int(0)
     return L.oracle_phmm_pair(len(rs), len(hap), rs, hap, q, qi, qd, qc, C.byref(ud)), ud.value
+
+
+def poa_oracle(params, ws, nthreads=1, stride=None, return_cells=False):
+    """oracle_poa_consensus over a PoaWindowSet -> list of consensus strings."""
+    stride = stride or ws.default_stride
+    cons = np.zeros((max(ws.n_windows, 1), stride), dtype=np.uint8)
+    clen = np.zeros(max(ws.n_windows, 1), dtype=np.int32)
+    cells = C.c_int64(0)
+    f = oracle_lib().oracle_poa_consensus
+    f.restype = None
+    f(C.byref(params), C.c_int64(ws.n_windows), _p(ws.win_first_seq), _p(ws.seq_off), _p(ws.seq_len), _p(ws.arena),
+      _p(cons), _p(clen), C.c_int64(stride), C.c_int(nthreads), C.byref(cells))
+    out = [cons[w, :min(clen[w], stride)].tobytes().decode() for w in range(ws.n_windows)]
+    return (out, cells.value) if return_cells else out
