@@ -66,6 +66,7 @@ struct PhmmArgs {
     const uint8_t *rs, *q, *qi, *qd, *qc;
     const int64_t *hap_off; const int32_t *hap_len; const uint8_t *hap;
     double *out;
+    DevTables tab;
 };
 
 struct PhmmWork {
@@ -262,11 +263,7 @@ __global__ void __launch_bounds__(64) phmm_f32_kernel(PhmmArgs A, PhmmWork W, in
     float *scr = (float *)(W.scratch + (int64_t)(blockIdx.x % TILED_BLOCKS) * W.scratch_stride);
     float *scr1 = scr + W.scratch_stride / (2 * sizeof(float));
     const float log_init = log10f(ldexpf(1.f, 120));
-    for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&W.next[cls], 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= cnt) break;
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
         const int pair = order[slot];
         const float r = phmm_pair<float, RPL>(A, pair, scr, scr1);
         if (lane == 0) {
@@ -284,11 +281,7 @@ __global__ void __launch_bounds__(64) phmm_f64_kernel(PhmmArgs A, PhmmWork W)
     double *scr = (double *)(W.scratch + (int64_t)(blockIdx.x % TILED_BLOCKS) * W.scratch_stride);
     double *scr1 = scr + W.scratch_stride / (2 * sizeof(double));
     const double log_init = log10(ldexp(1.0, 1020));
-    for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&W.next[7], 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= cnt) break;
+    for (int slot = blockIdx.x; slot < cnt; slot += gridDim.x) {
         const int pair = W.dlist[slot];
         const double r = phmm_pair<double, RPL>(A, pair, scr, scr1);
         if (lane == 0) A.out[pair] = log10(r) - log_init;
