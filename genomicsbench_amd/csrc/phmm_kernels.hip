@@ -198,9 +198,11 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
         }
         const int steps = lanes_used * RPL + H - 1;
         // row above the tile as seen by lane 0 / slot 0: `b*` = its column s+1 (DP index), `sd*` = column s
+        // (only lane 0 sits under the tile boundary; every other lane's slot 0 starts with DP column 0 = zeros,
+        //  so that rows which have not started yet keep computing exact zeros)
         T bM = zero, bX = zero, bY = first ? yinit : zero;
-        T sdM = zero, sdX = zero, sdY = first ? yinit : zero;            // DP column 0 of the row above
-        if (!first) { bM = top[1]; bX = top[(H + 1) + 1]; bY = top[2 * (H + 1) + 1]; sdY = zero; }
+        T sdM = zero, sdX = zero, sdY = (first && lane == 0) ? yinit : zero;   // DP column 0 of the row above
+        if (!first) { bM = top[1]; bX = top[(H + 1) + 1]; bY = top[2 * (H + 1) + 1]; }
         int hcur = hap[0], hnxt = hap[min(1, H - 1)];
         T acc = zero;
 

@@ -7,11 +7,15 @@ from genomicsbench_amd.phmm import DevicePhmmBatchSet, PhmmBatchSet, forward_hos
 from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
-RTOL = 1e-5          # BASELINE.json north_star: "within 1e-5 relative for phmm float"
+# BASELINE.json north_star: "within 1e-5 relative for phmm float".  The reference computes
+# log10f(result) - log10f(2^120) in float32, where log10f(result) ~ 36: one float ulp there is 3.8e-6
+# ABSOLUTE, so two correct implementations (GKL's own AVX and scalar builds included) can differ by that
+# much on a log-likelihood of any magnitude.  The bound is therefore 1e-5 relative with |want| floored at 1.
+RTOL = 1e-5
 
 
 def assert_close(got, want):
-    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
     k = int(np.argmax(err))
     assert np.isfinite(got).all(), "non-finite results"
     assert err[k] <= RTOL, "max rel err %.3g at pair %d: got %.9g want %.9g" % (err[k], k, got[k], want[k])
