@@ -177,7 +177,10 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
             // a dummy slot of tile 0 reproduces DP row 0: M=0, X=0, Y=INIT/H at every column
             pMM[k] = zero; pGap[k] = zero; pMX[k] = zero; pXX[k] = zero; pMY[k] = zero; pYY[k] = one;
             pm[k] = zero; px[k] = zero; rch[k] = 0;
-            T y0 = sig < pad ? yinit : zero;
+            // DP row 0 holds Y = INIT/H from DP column 0 on and nothing before it: dummy slot sig shows that
+            // value from step sig on (switched on in the step loop), so that the real rows below keep
+            // computing exact zeros until their own first column arrives.
+            T y0 = (sig < pad && sig == 0) ? yinit : zero;
             if (real) {
                 const int _i = A.qi[ro + r] & 127, _d = A.qd[ro + r] & 127, _c = A.qc[ro + r] & 127;
                 const int _q = A.q[ro + r] & 127;
@@ -193,7 +196,7 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
                 y0 = zero;
             }
             cM[k] = zero; cX[k] = zero; cY[k] = y0;                      // DP column 0
-            vM[k] = zero; vX[k] = zero; vY[k] = y0;
+            vM[k] = zero; vX[k] = zero; vY[k] = zero;
             hc[k] = 0;
         }
         const int steps = lanes_used * RPL + H - 1;
@@ -207,6 +210,11 @@ __device__ T phmm_pair(const PhmmArgs &A, int pair, T *scr0, T *scr1)
         T acc = zero;
 
         for (int s = 0; s < steps; ++s) {
+            if (pad > 1) {                                               // switch dummy slot s on (lane 0 only)
+#pragma unroll
+                for (int k = 1; k < RPL - 1; ++k)
+                    if (k < pad && s == k) cY[k] = lane == 0 ? yinit : cY[k];
+            }
             // values of the slot above slot 0 (previous lane's bottom slot, or the tile boundary in lane 0)
             T nM = shr1(zero, cM[RPL - 1]);
             T nX = shr1(zero, cX[RPL - 1]);
