@@ -15,9 +15,12 @@ RTOL = 1e-5
 
 
 def assert_close(got, want):
+    fin = np.isfinite(want)
+    # a read far longer than the haplotype underflows even the fp64 pass: both sides must say -inf
+    assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin]), "non-finite pattern differs"
+    got, want = got[fin], want[fin]
     err = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
     k = int(np.argmax(err))
-    assert np.isfinite(got).all(), "non-finite results"
     assert err[k] <= RTOL, "max rel err %.3g at pair %d: got %.9g want %.9g" % (err[k], k, got[k], want[k])
 
 
@@ -50,9 +53,9 @@ def test_generated_batches():
 def test_row_classes_and_tiles():
     """Read lengths across every rows-per-lane class, incl. reads longer than one 512-row tile."""
     rng = np.random.default_rng(1)
-    reads, haps = [], [rand_seq(rng, 37), rand_seq(rng, 200, "ACGTN"), rand_seq(rng, 451)]
+    reads, haps = [], [rand_seq(rng, 37), rand_seq(rng, 200, "ACGTN"), rand_seq(rng, 451), rand_seq(rng, 1300)]
     for R in (1, 2, 3, 63, 64, 65, 127, 128, 129, 151, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512, 513, 700, 1100):
-        src = (haps[2] * 4)[: R]
+        src = haps[3][7: 7 + R]
         reads.append("".join(c if rng.random() > 0.03 else "ACGT"[int(rng.integers(4))] for c in src))
     bs = make_set(reads, haps, seed=2)
     assert_close(forward_host(bs), O.phmm_oracle(bs, 8))
