@@ -94,6 +94,14 @@ def _declare(L):
     L.gbx_bsw_extend_host.argtypes = [C.POINTER(BswParams), i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     L.gbx_bsw_extend_seqpairs.argtypes = [C.POINTER(BswParams), vp, i64, vp, i64, vp, i64]
     L.gbx_bsw_extend_device.argtypes = [C.POINTER(BswParams), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    if hasattr(L, "gbx_poa_consensus_host"):
+        L.gbx_poa_default_params.argtypes = [vp]
+        L.gbx_poa_default_params.restype = None
+        L.gbx_poa_plan_host.argtypes = [i64, vp, vp, vp]
+        L.gbx_poa_workspace_bytes.argtypes = [vp]
+        L.gbx_poa_workspace_bytes.restype = sz
+        L.gbx_poa_consensus_host.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64]
+        L.gbx_poa_consensus_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, sz, vp]
     if hasattr(L, "gbx_phmm_forward_host"):
         L.gbx_phmm_workspace_bytes.argtypes = [i64, C.c_int32]
         L.gbx_phmm_workspace_bytes.restype = sz

@@ -468,4 +468,131 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     return GBX_OK;
 }
 
+/* --------------------------------------------------------------------- poa */
+void gbx_poa_default_params(gbx_poa_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->m = 2; p->n = -4; p->g = -6; p->e = -2; p->q = -25; p->c = -1;   /* msa_spoa_omp.cpp:156-162,184 */
+}
+
+int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int32_t *seq_len, gbx_poa_plan *plan)
+{
+    if (n_windows < 0 || !plan || (n_windows > 0 && (!win_first_seq || !seq_len))) {
+        set_error("gbx_poa_plan_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    int lmax = 1, smax = 1;
+    int64_t bmax = 1;
+    for (int64_t w = 0; w < n_windows; ++w) {
+        const int64_t a = win_first_seq[w], b = win_first_seq[w + 1];
+        if (b < a) { set_error("gbx_poa_plan_host: win_first_seq not monotone at window %lld", (long long)w); return GBX_ERR_ARG; }
+        if (b - a > GBX_POA_MAX_SEQS_PER_WINDOW) {
+            set_error("gbx_poa_plan_host: window %lld has more than %d sequences", (long long)w, GBX_POA_MAX_SEQS_PER_WINDOW);
+            return GBX_ERR_UNSUPPORTED;
+        }
+        int64_t bases = 0;
+        for (int64_t s = a; s < b; ++s) {
+            if (seq_len[s] < 0) { set_error("gbx_poa_plan_host: negative sequence length"); return GBX_ERR_ARG; }
+            if (seq_len[s] > lmax) lmax = seq_len[s];
+            bases += seq_len[s];
+        }
+        if (b - a > smax) smax = (int)(b - a);
+        if (bases > bmax) bmax = bases;
+    }
+    plan->max_seq_len = lmax;
+    plan->max_seqs_per_window = smax < 4 ? 4 : smax;
+    int64_t cap = (int64_t)6 * lmax + 256;                 /* typical windows stay below ~3x the read length */
+    if (bmax + 8 < cap) cap = bmax + 8;
+    plan->node_cap = (int32_t)cap;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    else (void)hipGetLastError();
+    int64_t slots = (int64_t)cus * 4;
+    if (n_windows < slots) slots = n_windows > 0 ? n_windows : 1;
+    plan->n_slots = (int32_t)slots;
+    return GBX_OK;
+}
+
+size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan)
+{
+    if (!plan) return 0;
+    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots;
+}
+
+int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows,
+                             const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
+                             const char *d_arena, char *d_cons, int32_t *d_cons_len, int32_t *d_status,
+                             int64_t cons_stride, void *d_work, size_t work_bytes, void *stream)
+{
+    if (!p || !plan || n_windows < 0 || cons_stride <= 0) { set_error("gbx_poa_consensus_device: bad argument"); return GBX_ERR_ARG; }
+    if (n_windows == 0) return GBX_OK;
+    if (!d_win_first_seq || !d_seq_off || !d_seq_len || !d_arena || !d_cons || !d_cons_len || !d_status || !d_work) {
+        set_error("gbx_poa_consensus_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return poa_launch(p, n_windows, d_win_first_seq, d_seq_off, d_seq_len, (const uint8_t *)d_arena, plan->max_seq_len,
+                      plan->max_seqs_per_window, plan->node_cap, plan->n_slots, (uint8_t *)d_cons, d_cons_len, d_status,
+                      cons_stride, d_work, work_bytes, (hipStream_t)stream);
+}
+
+int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                           const char *arena, int64_t arena_bytes,
+                           char *cons, int32_t *cons_len, int64_t cons_stride)
+{
+    if (!p || n_windows < 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0) {
+        set_error("gbx_poa_consensus_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    if (n_windows == 0) return GBX_OK;
+    if (!win_first_seq || !seq_off || !seq_len || !arena || !cons || !cons_len) {
+        set_error("gbx_poa_consensus_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    if (win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs) {
+        set_error("gbx_poa_consensus_host: win_first_seq must span [0, n_seqs]");
+        return GBX_ERR_ARG;
+    }
+    for (int64_t s = 0; s < n_seqs; ++s)
+        if (seq_len[s] < 0 || seq_off[s] < 0 || seq_off[s] + seq_len[s] > arena_bytes) {
+            set_error("gbx_poa_consensus_host: sequence %lld lies outside the arena", (long long)s);
+            return GBX_ERR_ARG;
+        }
+    int rc = require_device();
+    if (rc) return rc;
+    gbx_poa_plan plan;
+    if ((rc = gbx_poa_plan_host(n_windows, win_first_seq, seq_len, &plan))) return rc;
+    const size_t wb = gbx_poa_workspace_bytes(&plan);
+    DevBuf dwf, doff, dlen, dar, dcons, dcl, dst, dw;
+    if ((rc = dwf.alloc((n_windows + 1) * 8)) || (rc = doff.alloc(n_seqs * 8)) || (rc = dlen.alloc(n_seqs * 4)) ||
+        (rc = dar.alloc(arena_bytes)) || (rc = dcons.alloc(n_windows * cons_stride)) || (rc = dcl.alloc(n_windows * 4)) ||
+        (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
+        return rc;
+    hipStream_t s = nullptr;
+    GBX_HIP(hipMemcpyAsync(dwf.p, win_first_seq, (n_windows + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_seqs) {
+        GBX_HIP(hipMemcpyAsync(doff.p, seq_off, n_seqs * 8, hipMemcpyHostToDevice, s));
+        GBX_HIP(hipMemcpyAsync(dlen.p, seq_len, n_seqs * 4, hipMemcpyHostToDevice, s));
+    }
+    if (arena_bytes) GBX_HIP(hipMemcpyAsync(dar.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
+    rc = poa_launch(p, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
+                    plan.max_seq_len, plan.max_seqs_per_window, plan.node_cap, plan.n_slots, dcons.as<uint8_t>(),
+                    dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, s);
+    if (rc) return rc;
+    std::vector<int32_t> status(n_windows);
+    GBX_HIP(hipMemcpyAsync(cons, dcons.p, n_windows * cons_stride, hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipMemcpyAsync(cons_len, dcl.p, n_windows * 4, hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipMemcpyAsync(status.data(), dst.p, n_windows * 4, hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (status[w]) {
+            set_error("gbx_poa_consensus_host: window %lld exceeded a device capacity (status bits 0x%x, see GBX_POA_ST_*)",
+                      (long long)w, status[w]);
+            return GBX_ERR_UNSUPPORTED;
+        }
+    return GBX_OK;
+}
+
 }  // extern "C"

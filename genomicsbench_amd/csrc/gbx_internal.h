@@ -52,4 +52,11 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
                 double *out, void *d_work, size_t work_bytes, hipStream_t s);
 
+// ---- poa (poa_kernels.hip)
+size_t poa_slot_bytes(int ncap, int deg, int lmax);
+int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
+               const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
+               uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
+               void *d_work, size_t work_bytes, hipStream_t s);
+
 }  // namespace gbx

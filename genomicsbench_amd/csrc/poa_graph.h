@@ -160,7 +160,7 @@ PG_HD void poa_add_alignment(PoaGraph &g, const uint8_t *seq, int len)
     const int np = g.n_path;
     if (np == 0) {
         poa_add_chain(g, seq, 0, len);
-        poa_topo_sort(g);
+        if (g.err == 0) poa_topo_sort(g);
         return;
     }
     int first_pos = -1, last_pos = -1;
@@ -176,6 +176,7 @@ PG_HD void poa_add_alignment(PoaGraph &g, const uint8_t *seq, int len)
     for (int t = np - 1; t >= 0; --t) {
         const int pos = g.path_pos[t];
         if (pos == -1) continue;
+        if (g.err) return;                                   // a capacity was exceeded: the window is abandoned
         const int node = g.path_node[t];
         const int code = g.coder[seq[pos]];
         int id;
@@ -209,6 +210,7 @@ PG_HD void poa_add_alignment(PoaGraph &g, const uint8_t *seq, int len)
         prev_w = 1;
     }
     if (tail != -1) poa_add_edge(g, head, tail, prev_w + 1);
+    if (g.err) return;
     poa_topo_sort(g);
 }
 

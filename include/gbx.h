@@ -215,12 +215,39 @@ typedef struct gbx_poa_params {
 
 void gbx_poa_default_params(gbx_poa_params *p);
 
-/* cons: n_windows rows of cons_stride bytes (not NUL-terminated), cons_len[w] = consensus length
- * (if it exceeds cons_stride the row is truncated and the call returns GBX_ERR_UNSUPPORTED). */
+/* Capacities of the device path for a set of windows (computed from host metadata). */
+typedef struct gbx_poa_plan {
+    int32_t max_seq_len;          /* longest sequence                                    */
+    int32_t max_seqs_per_window;  /* bounds the fan-in / fan-out of a graph node          */
+    int32_t node_cap;             /* graph nodes per window the workspace can hold       */
+    int32_t n_slots;              /* windows processed concurrently (one wavefront each) */
+} gbx_poa_plan;
+
+#define GBX_POA_MAX_SEQS_PER_WINDOW 255
+#define GBX_POA_MAX_LETTERS_PER_COLUMN 8
+
+/* per-window status bits written by the device path (0 = ok) */
+#define GBX_POA_ST_NODES   1   /* node_cap exceeded                      */
+#define GBX_POA_ST_DEGREE  2   /* fan-in/out above max_seqs_per_window   */
+#define GBX_POA_ST_LETTERS 4   /* more than 8 distinct letters aligned   */
+#define GBX_POA_ST_STACK   8
+#define GBX_POA_ST_CONS    16  /* consensus longer than cons_stride      */
+
+int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int32_t *seq_len, gbx_poa_plan *plan);
+size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan);
+
+/* cons: n_windows rows of cons_stride bytes (not NUL-terminated), cons_len[w] = consensus length.
+ * Returns GBX_ERR_UNSUPPORTED (and names the first window) if any window overflowed a capacity. */
 int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
                            int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
                            const char *arena, int64_t arena_bytes,
                            char *cons, int32_t *cons_len, int64_t cons_stride);
+
+/* Device-resident entry; d_status[w] receives the GBX_POA_ST_* bits. */
+int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows,
+                             const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
+                             const char *d_arena, char *d_cons, int32_t *d_cons_len, int32_t *d_status,
+                             int64_t cons_stride, void *d_work, size_t work_bytes, void *stream);
 
 #ifdef __cplusplus
 }

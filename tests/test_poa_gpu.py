@@ -1,0 +1,71 @@
+"""GPU parity tests for poa: HIP kernel (through the C-ABI) vs the oracle, exact consensus strings."""
+import numpy as np
+import pytest
+
+from genomicsbench_amd import _native as N
+from genomicsbench_amd.datagen import gen_poa
+from genomicsbench_amd.poa import PoaWindowSet, consensus_host, make_params
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def diff(got, want):
+    bad = [w for w in range(len(want)) if got[w] != want[w]]
+    assert not bad, "%d/%d windows differ; first %d: got %s... want %s..." % (
+        len(bad), len(want), bad[0], got[bad[0]][:60], want[bad[0]][:60])
+
+
+def test_known_answers():
+    ws = PoaWindowSet.from_lists([["ACGTACGTAC"] * 3, ["ACGTACGTAC", "ACGTACGTAC", "ACGAACGTAC"],
+                                  ["ACGTACGTAC", "ACGTCGTAC", "ACGTACGTAC"], ["AAAA", "AATAA", "AATAA"], ["ACGT"],
+                                  ["A", "C", "A"], ["GATTACA", "GATTACA", "GATTTACA", "GATTACA"]])
+    p = make_params()
+    got = consensus_host(p, ws)
+    assert got == ["ACGTACGTAC", "ACGTACGTAC", "ACGTACGTAC", "AATAA", "ACGT", "A", "GATTACA"]
+    diff(got, O.poa_oracle(p, ws))
+
+
+def random_windows(seed, n, max_len, max_reads, alphabet="ACGTN"):
+    rng = np.random.default_rng(seed)
+    wins = []
+    for _ in range(n):
+        base = "".join(rng.choice(list(alphabet), int(rng.integers(5, max_len))))
+        reads = []
+        for _ in range(int(rng.integers(1, max_reads + 1))):
+            r = [c for c in base if rng.random() > 0.08]
+            r = [c if rng.random() > 0.08 else "ACGT"[int(rng.integers(4))] for c in r]
+            for _ in range(int(rng.integers(0, 4))):
+                r.insert(int(rng.integers(0, len(r) + 1)), "ACGT"[int(rng.integers(4))])
+            reads.append("".join(r) or "A")
+        wins.append(reads)
+    return PoaWindowSet.from_lists(wins)
+
+
+@pytest.mark.parametrize("max_len", [40, 200, 300, 600, 900])
+def test_random_small_windows_every_column_class(max_len):
+    """Sequence lengths across every columns-per-lane class (4/8/12/16) incl. ragged and tiny reads."""
+    ws = random_windows(max_len, 24, max_len, 7)
+    p = make_params()
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws, 4))
+
+
+def test_generated_windows():
+    ws = gen_poa(48, 4001)
+    p = make_params()
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws, 8))
+
+
+def test_affine_scoring_and_shard_equivalence():
+    ws = gen_poa(16, 9)
+    pa = make_params(o2=4, e2=2)
+    full = consensus_host(pa, ws)
+    diff(full, O.poa_oracle(pa, ws, 8))
+    assert consensus_host(pa, ws.take(0, 5)) + consensus_host(pa, ws.take(5, 16)) == full
+
+
+def test_linear_gap_mode_is_rejected():
+    ws = gen_poa(1, 1)
+    with pytest.raises(N.GbxError) as e:
+        consensus_host(make_params(o1=0, e1=2), ws)          # g >= e -> spoa's linear subtype
+    assert e.value.code == N.GBX_ERR_UNSUPPORTED
