@@ -60,3 +60,44 @@ def consensus_host(params, ws, stride=None):
                                            N.ptr(ws.seq_off), N.ptr(ws.seq_len), N.ptr(ws.arena), ws.arena.size,
                                            N.ptr(cons), N.ptr(clen), stride))
     return [cons[w, :clen[w]].tobytes().decode() for w in range(ws.n_windows)]
+
+
+class PoaPlan(C.Structure):
+    _fields_ = [("max_seq_len", C.c_int32), ("max_seqs_per_window", C.c_int32), ("node_cap", C.c_int32),
+                ("n_slots", C.c_int32)]
+
+
+class DevicePoaWindowSet:
+    """A PoaWindowSet resident in HBM (torch tensors) + outputs, per-window status and the workspace."""
+
+    def __init__(self, ws, device, stride=None):
+        import torch
+        self.ws = ws
+        self.n_windows = ws.n_windows
+        self.stride = stride or ws.default_stride
+        self.plan = PoaPlan()
+        N.check(N.lib().gbx_poa_plan_host(ws.n_windows, N.ptr(ws.win_first_seq), N.ptr(ws.seq_len), C.byref(self.plan)))
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.win_first_seq, self.seq_off, self.seq_len = t(ws.win_first_seq), t(ws.seq_off), t(ws.seq_len)
+        self.arena = t(np.concatenate([ws.arena, np.zeros(16, np.uint8)]))
+        n = max(self.n_windows, 1)
+        self.cons = torch.zeros((n, self.stride), dtype=torch.uint8, device=device)
+        self.cons_len = torch.zeros(n, dtype=torch.int32, device=device)
+        self.status = torch.zeros(n, dtype=torch.int32, device=device)
+        self.work_bytes = N.lib().gbx_poa_workspace_bytes(C.byref(self.plan))
+        self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
+
+    def run(self, params, stream=None):
+        N.check(N.lib().gbx_poa_consensus_device(C.byref(params), C.byref(self.plan), self.n_windows,
+                                                 self.win_first_seq.data_ptr(), self.seq_off.data_ptr(),
+                                                 self.seq_len.data_ptr(), self.arena.data_ptr(), self.cons.data_ptr(),
+                                                 self.cons_len.data_ptr(), self.status.data_ptr(), self.stride,
+                                                 self.work.data_ptr(), self.work_bytes, stream))
+
+    def results(self):
+        cons = self.cons.cpu().numpy()
+        clen = self.cons_len.cpu().numpy()
+        st = self.status.cpu().numpy()
+        if st[:self.n_windows].any():
+            raise N.GbxError(N.GBX_ERR_UNSUPPORTED, "window %d overflowed a device capacity" % int(np.nonzero(st)[0][0]))
+        return [cons[w, :clen[w]].tobytes().decode() for w in range(self.n_windows)]
