@@ -1,0 +1,67 @@
+// poa — GPU driver with the CLI of R/benchmarks/poa/msa_spoa_omp.cpp:
+//   poa -s <input.fasta> -t <threads> [-m N] [-x N] [-o a[,b]] [-e a[,b]] [-n N]
+// Input (msa_spoa_omp.cpp:82-116): 2 lines per record; a header whose 2nd character is '0' opens a new window.
+// --print writes ">Consensus_sequence\n<seq>" per window like the reference's PRINT_OUTPUT build (:281-286).
+#include <fstream>
+#include "driver_common.h"
+
+int main(int argc, char **argv)
+{
+    std::string seq_file = "seq.fa";
+    int m = 2, x = -4, o1 = -4, e1 = -2, o2 = -24, e2 = -1, threads = 1;
+    bool print = false;
+    if (argc == 1) { fprintf(stderr, "usage: ./poa -s input.fasta -t <num_threads> > cons.fasta\n"); return EXIT_FAILURE; }
+    for (int i = 1; i < argc; ++i) {
+        char *s;
+        if (!strcmp(argv[i], "-m") && i + 1 < argc) m = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-x") && i + 1 < argc) x = 0 - atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-o") && i + 1 < argc) { o1 = 0 - (int)strtol(argv[++i], &s, 10); if (*s == ',') o2 = 0 - (int)strtol(s + 1, &s, 10); }
+        else if (!strcmp(argv[i], "-e") && i + 1 < argc) { e1 = 0 - (int)strtol(argv[++i], &s, 10); if (*s == ',') e2 = 0 - (int)strtol(s + 1, &s, 10); }
+        else if (!strcmp(argv[i], "-n") && i + 1 < argc) ++i;
+        else if (!strcmp(argv[i], "-s") && i + 1 < argc) seq_file = argv[++i];
+        else if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--print")) print = true;
+        else if (!strcmp(argv[i], "-h")) { fprintf(stderr, "usage: ./poa -s input.fasta -t <num_threads>\n"); return 0; }
+    }
+    (void)threads;
+    gbx_poa_params P;
+    gbx_poa_default_params(&P);
+    P.m = (int8_t)m; P.n = (int8_t)x; P.g = (int8_t)(o1 + e1); P.e = (int8_t)e1; P.q = (int8_t)(o2 + e2); P.c = (int8_t)e2;
+    std::ifstream in(seq_file);
+    if (!in.is_open()) { fprintf(stderr, "cannot open %s\n", seq_file.c_str()); return EXIT_FAILURE; }
+    // readFile(): header, sequence, header, ...; seq[1]=='0' on a header starts the next window
+    std::vector<int64_t> win_first(1, 0), seq_off;
+    std::vector<int32_t> seq_len;
+    std::string arena, line;
+    bool have = (bool)std::getline(in, line);
+    while (have && !in.eof()) {
+        if (line.size() > 1 && line[1] == '0') {
+            for (;;) {
+                std::string s;
+                if (!std::getline(in, s)) { have = false; break; }
+                seq_off.push_back((int64_t)arena.size()); seq_len.push_back((int32_t)s.size()); arena += s;
+                if (!std::getline(in, line)) { have = false; break; }
+                if (line.size() > 1 && line[1] == '0') break;
+            }
+            win_first.push_back((int64_t)seq_len.size());
+        } else have = (bool)std::getline(in, line);
+    }
+    const int64_t nw = (int64_t)win_first.size() - 1, ns = (int64_t)seq_len.size();
+    fprintf(stderr, "Number of batches: %lld\n", (long long)nw);
+    int lmax = 1;
+    for (int v : seq_len) lmax = v > lmax ? v : lmax;
+    const int64_t stride = 2 * (int64_t)lmax + 64;
+    std::vector<char> cons((size_t)(nw > 0 ? nw : 1) * stride);
+    std::vector<int32_t> clen((size_t)nw + 1);
+    arena.resize(arena.size() + 8);
+    print_device_banner();
+    const double t0 = now_s();
+    die_on(gbx_poa_consensus_host(&P, nw, win_first.data(), ns, seq_off.data(), seq_len.data(), arena.data(),
+                                  (int64_t)arena.size(), cons.data(), clen.data(), stride), "gbx_poa_consensus_host");
+    const double dt = now_s() - t0;
+    if (print)
+        for (int64_t w = 0; w < nw; ++w) printf(">Consensus_sequence\n%.*s\n", clen[w], cons.data() + w * stride);
+    fprintf(stderr, "Runtime: %.2f\n", dt);
+    fprintf(stderr, "{\"benchmark\":\"poa\",\"windows\":%lld,\"sequences\":%lld,\"seconds\":%.6f}\n", (long long)nw, (long long)ns, dt);
+    return 0;
+}

@@ -2,6 +2,7 @@
 
 bsw   : 3 text lines per pair (h0, target digits 0-4, query digits 0-4)   R/benchmarks/bsw/main_banded.cpp:131-185
 phmm  : per batch `num_reads num_haps`, reads `bases q i d c` (Phred+33), haplotypes        R/benchmarks/phmm/PairHMMUnitTest.cpp:95-140
+poa   : FASTA-like, 2 lines per record; a header whose 2nd character is '0' opens a new window        R/benchmarks/poa/msa_spoa_omp.cpp:82-116
 chain : `n avg_qspan max_dist_x max_dist_y bw n_segs`, n lines `x y`, `EOR`  R/benchmarks/chain/src/host_data_io.cpp:13-60
 """
 import gzip
@@ -141,3 +142,27 @@ def read_phmm_batches(path):
     roff = np.concatenate([[0], np.cumsum(rl)])[:-1] if rl else np.zeros(0, np.int64)
     hoff = np.concatenate([[0], np.cumsum(hl)])[:-1] if hl else np.zeros(0, np.int64)
     return PhmmBatchSet(nr, nh, roff, rl, cat(rs), cat(q), cat(qi), cat(qd), cat(qc), hoff, hl, cat(hp))
+
+
+# ----------------------------------------------------------------------------- poa
+def write_poa_windows(path, ws):
+    with _open(path, "w") as f:
+        for w in range(ws.n_windows):
+            for k, s in enumerate(ws.window(w)):
+                f.write(">%d\n%s\n" % (k, s))
+
+
+def read_poa_windows(path):
+    """readFile(): strictly 2 lines per record; header[1] == '0' starts a new window."""
+    from .poa import PoaWindowSet
+    with _open(path, "r") as f:
+        lines = f.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    wins = []
+    for k in range(0, len(lines) - 1, 2):
+        if len(lines[k]) > 1 and lines[k][1] == "0":
+            wins.append([])
+        if wins:
+            wins[-1].append(lines[k + 1])
+    return PoaWindowSet.from_lists(wins)
