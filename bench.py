@@ -19,8 +19,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-CLASS_OF_KERNEL = {"bsw_rows_16x2": (1, 32), "bsw_rows_16x4": (33, 64), "bsw_rows_16x8": (65, 128),
-                   "bsw_rows_16x16": (129, 256), "bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)}
+# query-length range handled by each row kernel (csrc/bsw_kernels.hip: cls_of)
+CLASS_OF_KERNEL = {"bsw_rows_16x%d" % c: (lo, hi) for c, lo, hi in
+                   [(1, 1, 16), (2, 17, 32), (3, 33, 48), (4, 49, 64), (5, 65, 80), (6, 81, 96), (7, 97, 112),
+                    (8, 113, 128), (10, 129, 160), (12, 161, 192), (16, 193, 256)]}
+CLASS_OF_KERNEL.update({"bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)})
 
 
 def cpu_baseline(batch, params, max_pairs):

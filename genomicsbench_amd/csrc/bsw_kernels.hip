@@ -29,8 +29,10 @@ namespace {
 constexpr int NEG = -(1 << 29);
 constexpr int BIGJ = 1 << 20;
 
-// qlen classes -> kernel shapes
-constexpr int NCLS = 6;      // 0:(16,2) 1:(16,4) 2:(16,8) 3:(16,16) 4:(64,16) 5:LDS general
+// qlen classes -> kernel shapes: classes 0..10 = (LPP 16, CPL 1,2,3,4,5,6,7,8,10,12,16), 11 = (64,16), 12 = LDS kernel
+constexpr int NCLS = 13;
+constexpr int NTB = 32;                     // target-length buckets per class (width 16), longest first
+constexpr int NBIN = NCLS * NTB;            // 416 bins: pairs are binned by (class, descending target length)
 constexpr int REG_SCORE_LIMIT = 1 << 20;   // register kernels pack (h<<10|j) in 31 bits
 
 struct BswDev {
@@ -46,20 +48,24 @@ struct BswPairs {
     gbx_bsw_result *out;
 };
 
-// workspace layout (ints): [0..NCLS) counts, [8..8+NCLS) cursors, [16] bad-pair count,
-// then order[n]
+// workspace layout (ints): counts[512] | cursors[512] | base[512] (exclusive prefix of counts) | misc[512] | order[n]
+//   misc[0] = bad-pair count
+constexpr int WS_HDR = 2048;
 struct BswWork {
-    int32_t *counts, *cursors, *bad, *order;
+    int32_t *counts, *cursors, *base, *bad, *order;
 };
 
 __host__ __device__ inline int cls_of(int qlen, int bound)
 {
-    if (qlen > 1024 || bound >= REG_SCORE_LIMIT) return 5;
-    if (qlen <= 32) return 0;
-    if (qlen <= 64) return 1;
-    if (qlen <= 128) return 2;
-    if (qlen <= 256) return 3;
-    return 4;
+    if (qlen > 1024 || bound >= REG_SCORE_LIMIT) return 12;
+    if (qlen > 256) return 11;
+    if (qlen <= 128) return (qlen - 1) >> 4;          // CPL 1..8  -> classes 0..7
+    return qlen <= 160 ? 8 : qlen <= 192 ? 9 : 10;    // CPL 10, 12, 16
+}
+__host__ __device__ inline int bin_of(int cls, int tlen)
+{
+    const int tb = tlen >> 4;
+    return cls * NTB + (NTB - 1 - (tb < NTB - 1 ? tb : NTB - 1));
 }
 
 __device__ inline int imax3(int a, int b, int c) { return max(max(a, b), c); }
@@ -71,14 +77,22 @@ __device__ inline int dpp(int old, int x)
 }
 
 // ---- group primitives -----------------------------------------------------
-// inclusive prefix max over the LPP lanes of a group (identity NEG)
+// mov_dpp with an undefined `old` and bound_ctrl:1 (out-of-row lanes read 0) lets the compiler fold the
+// move into the consumer (v_max_i32_dpp): one VALU op per scan / reduce step.
+template <int CTRL, int ROWMASK = 0xf>
+__device__ inline int dppz(int x)
+{
+    return __builtin_amdgcn_mov_dpp(x, CTRL, ROWMASK, 0xf, true);
+}
+
+// inclusive prefix max over the LPP lanes of a group, for values >= 0 (0 is the fill)
 template <int LPP>
 __device__ inline int group_scan_max(int x)
 {
-    x = max(x, dpp<0x111>(NEG, x));
-    x = max(x, dpp<0x112>(NEG, x));
-    x = max(x, dpp<0x114>(NEG, x));
-    x = max(x, dpp<0x118>(NEG, x));
+    x = max(x, dppz<0x111>(x));
+    x = max(x, dppz<0x112>(x));
+    x = max(x, dppz<0x114>(x));
+    x = max(x, dppz<0x118>(x));
     if (LPP >= 32) x = max(x, dpp<0x142, 0xa>(NEG, x));   // row_bcast15 -> rows 1,3
     if (LPP >= 64) x = max(x, dpp<0x143, 0xc>(NEG, x));   // row_bcast31 -> rows 2,3
     return x;
@@ -98,10 +112,10 @@ template <int LPP>
 __device__ inline int group_allmax(int x)
 {
     if (LPP == 16) {
-        x = max(x, dpp<0x121>(x, x));                     // row_ror:1,2,4,8
-        x = max(x, dpp<0x122>(x, x));
-        x = max(x, dpp<0x124>(x, x));
-        x = max(x, dpp<0x128>(x, x));
+        x = max(x, dppz<0x121>(x));                       // row_ror:1,2,4,8 (every lane has a source)
+        x = max(x, dppz<0x122>(x));
+        x = max(x, dppz<0x124>(x));
+        x = max(x, dppz<0x128>(x));
         return x;
     }
     x = max(x, dpp<0x111>(x, x));
@@ -117,18 +131,20 @@ __device__ inline int group_allmax(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-// ---- classify / bin pairs by query length ----------------------------------
-// Degenerate pairs (len 0) are answered here; bad pairs (negative or too long)
-// get -1 outputs and bump work.bad.
-__global__ void __launch_bounds__(256) bsw_classify_kernel(BswDev prm, BswPairs P, int64_t n, BswWork W, int pass)
+// ---- classify / bin pairs by (query-length class, descending target length) ----------------
+// Degenerate pairs (len 0) are answered here; bad pairs (negative or too long) get -1 outputs
+// and bump work.bad.  pass 0: histogram; bsw_scan_kernel; pass 1: scatter into order[].
+// Handing pairs out longest-first makes the static round-robin over groups an LPT schedule.
+constexpr int CLS_THREADS = 1024;
+__global__ void __launch_bounds__(CLS_THREADS) bsw_classify_kernel(BswDev prm, BswPairs P, int64_t n, BswWork W, int pass)
 {
-    __shared__ int lcount[NCLS];
-    __shared__ int lbase[NCLS];
+    __shared__ int lcount[NBIN];
+    __shared__ int lbase[NBIN];
     const int tid = threadIdx.x;
-    if (tid < NCLS) lcount[tid] = 0;
+    for (int b = tid; b < NBIN; b += CLS_THREADS) lcount[b] = 0;
     __syncthreads();
-    const int64_t k = (int64_t)blockIdx.x * 256 + tid;
-    int cls = -1, slot = 0;
+    const int64_t k = (int64_t)blockIdx.x * CLS_THREADS + tid;
+    int bin = -1, slot = 0;
     if (k < n) {
         const int qlen = P.len2[k], tlen = P.len1[k], h0 = P.h0[k];
         if (qlen < 0 || tlen < 0 || qlen > GBX_BSW_MAX_QLEN || tlen > GBX_BSW_MAX_TLEN) {
@@ -149,22 +165,37 @@ __global__ void __launch_bounds__(256) bsw_classify_kernel(BswDev prm, BswPairs 
             }
         } else {
             const int bound = max(h0, 0) + qlen * max(prm.max_mat, 0);
-            cls = cls_of(qlen, bound);
-            slot = atomicAdd(&lcount[cls], 1);
+            bin = bin_of(cls_of(qlen, bound), tlen);
+            slot = atomicAdd(&lcount[bin], 1);
         }
     }
     __syncthreads();
     if (pass == 0) {
-        if (tid < NCLS && lcount[tid]) atomicAdd(&W.counts[tid], lcount[tid]);
+        for (int b = tid; b < NBIN; b += CLS_THREADS)
+            if (lcount[b]) atomicAdd(&W.counts[b], lcount[b]);
         return;
     }
-    if (tid < NCLS) {
-        int base = 0;
-        for (int c = 0; c < tid; ++c) base += W.counts[c];
-        lbase[tid] = lcount[tid] ? base + atomicAdd(&W.cursors[tid], lcount[tid]) : 0;
-    }
+    for (int b = tid; b < NBIN; b += CLS_THREADS)
+        lbase[b] = lcount[b] ? W.base[b] + atomicAdd(&W.cursors[b], lcount[b]) : 0;
     __syncthreads();
-    if (cls >= 0) W.order[lbase[cls] + slot] = (int)k;
+    if (bin >= 0) W.order[lbase[bin] + slot] = (int)k;
+}
+
+// exclusive prefix of the bin counts (one block)
+__global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
+{
+    __shared__ int tmp[512];
+    const int tid = threadIdx.x;
+    const int v = tid < NBIN ? W.counts[tid] : 0;
+    tmp[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) {
+        const int add = tid >= d ? tmp[tid - d] : 0;
+        __syncthreads();
+        tmp[tid] += add;
+        __syncthreads();
+    }
+    if (tid <= NBIN) W.base[tid] = tmp[tid] - v;       // base[NBIN] = total
 }
 
 // ---- register-resident row kernel ------------------------------------------
@@ -182,8 +213,8 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
     const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
     int next = blockIdx.x * GROUPS_PER_BLOCK + tid / LPP;
 
-    int cnt = W.counts[cls], first = 0;
-    for (int c = 0; c < cls; ++c) first += W.counts[c];
+    const int first = W.base[cls * NTB];
+    const int cnt = W.base[(cls + 1) * NTB] - first;
     const int32_t *order = W.order + first;
 
     const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
@@ -259,12 +290,19 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         const int t8 = t << 3;
         const bool t4 = t == 4;
 
-        int M[CPL], Ein[CPL], Fl[CPL], Hc[CPL];
+        int M[CPL], Ein[CPL], Fl[CPL], Hc[CPL], sv[CPL];
+        if (__any(t4)) {                                                // an ambiguous target base somewhere in the wave
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) sv[c] = t4 ? P4[c] : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) sv[c] = __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+        }
         int lf = NEG;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const bool p = (c >= lo) & (c < hi);
-            const int s = t4 ? P4[c] : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+            const int s = sv[c];
             const int hsv = Hs[c];
             const int m = (p & (hsv != 0)) ? hsv + s : 0;              // :196
             const int ein = p ? Ev[c] : 0;
@@ -342,8 +380,8 @@ __global__ void __launch_bounds__(64) bsw_lds_kernel(BswDev prm, BswPairs P, Bsw
 {
     extern __shared__ int lds[];
     const int lane = threadIdx.x;
-    int cnt = W.counts[cls], first = 0;
-    for (int c = 0; c < cls; ++c) first += W.counts[c];
+    const int first = W.base[cls * NTB];
+    const int cnt = W.base[(cls + 1) * NTB] - first;
     const int32_t *order = W.order + first;
     const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
 
@@ -481,7 +519,7 @@ int make_dev_params(const gbx_bsw_params *p, BswDev *d)
 
 size_t bsw_workspace_bytes(int64_t n)
 {
-    return (size_t)(32 + (n > 0 ? n : 0)) * sizeof(int32_t);
+    return (size_t)(WS_HDR + (n > 0 ? n : 0)) * sizeof(int32_t);
 }
 
 int bsw_launch(const gbx_bsw_params *p, int64_t n,
@@ -498,13 +536,14 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     if (rc) return rc;
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
     int32_t *wi = (int32_t *)d_work;
-    BswWork W = {wi, wi + 8, wi + 16, wi + 32};
-    GBX_HIP(hipMemsetAsync(d_work, 0, 32 * sizeof(int32_t), s));
-    const int cblocks = (int)((n + 255) / 256);
+    BswWork W = {wi, wi + 512, wi + 1024, wi + 1536, wi + WS_HDR};
+    GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s));
+    const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
         Stage st("bsw_classify", s);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(256), 0, s, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(256), 0, s, dev, P, n, W, 1);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 0);
+        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(512), 0, s, W);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 1);
     }
 
     int dev_id = 0, cus = 256;
@@ -516,11 +555,15 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         int64_t cap = (int64_t)cus * blocks_per_cu;
         return (int)(want < cap ? want : cap);
     };
-    { Stage st("bsw_rows_16x2", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 2>), dim3(grid_for(16, 8)), dim3(256), 0, s, dev, P, W, 0); }
-    { Stage st("bsw_rows_16x4", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 4>), dim3(grid_for(16, 8)), dim3(256), 0, s, dev, P, W, 1); }
-    { Stage st("bsw_rows_16x8", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 8>), dim3(grid_for(16, 6)), dim3(256), 0, s, dev, P, W, 2); }
-    { Stage st("bsw_rows_16x16", s); hipLaunchKernelGGL((bsw_rows_kernel<16, 16>), dim3(grid_for(16, 3)), dim3(256), 0, s, dev, P, W, 3); }
-    { Stage st("bsw_rows_64x16", s); hipLaunchKernelGGL((bsw_rows_kernel<64, 16>), dim3(grid_for(4, 3)), dim3(256), 0, s, dev, P, W, 4); }
+#define GBX_ROWS(CPL_, BPC_, CLS_)                                                                                         \
+    {                                                                                                                      \
+        Stage st("bsw_rows_16x" #CPL_, s);                                                                                 \
+        hipLaunchKernelGGL((bsw_rows_kernel<16, CPL_>), dim3(grid_for(16, BPC_)), dim3(256), 0, s, dev, P, W, CLS_);       \
+    }
+    GBX_ROWS(1, 8, 0) GBX_ROWS(2, 8, 1) GBX_ROWS(3, 8, 2) GBX_ROWS(4, 8, 3) GBX_ROWS(5, 6, 4) GBX_ROWS(6, 6, 5)
+    GBX_ROWS(7, 6, 6) GBX_ROWS(8, 6, 7) GBX_ROWS(10, 4, 8) GBX_ROWS(12, 4, 9) GBX_ROWS(16, 3, 10)
+#undef GBX_ROWS
+    { Stage st("bsw_rows_64x16", s); hipLaunchKernelGGL((bsw_rows_kernel<64, 16>), dim3(grid_for(4, 3)), dim3(256), 0, s, dev, P, W, 11); }
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         static bool attr_set = false;
@@ -530,7 +573,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         }
         int blocks = (int)(n < (int64_t)cus * 2 ? n : (int64_t)cus * 2);
         Stage st("bsw_lds", s);
-        hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, 5);
+        hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, 12);
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;
