@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: bsw 'large' GCUPS on N MI355X (BASELINE.json).
+"""bench.py — headline benchmark: bsw 'large' GCUPS on N MI355X (BASELINE.json), one JSON line on rank 0.
 
-A step = one pass of the bsw hot path (gbx_bsw_extend_device: classify + every row kernel)
-over this rank's shard of the synthetic bsw-large pair set, inputs resident in HBM.
-Pairs are independent, so ranks shard them with no data-path collective ("weak": per-GPU
-work fixed).  value = nominal DP cells (sum len1*len2, main_banded.cpp:183) of ALL ranks
-per second of the slowest rank, in GCUPS.
+    python bench.py [--gpus N --steps K --warmup W]            # bsw large (the headline metric)
+    python bench.py --kernel chain|phmm|poa                    # the other three DP kernels, same JSON shape
+
+A step = one pass of the kernel's hot path (every launch of the *_device entry point) over this
+rank's shard of the synthetic dataset, inputs resident in HBM.  Work units are independent, so ranks
+shard them with no data-path collective ("weak": per-GPU work fixed); value = units of ALL ranks per
+second of the slowest rank.  Per-kernel durations come from HIP events recorded around every launch on
+the launch stream inside the timed region (gbx_profile_begin/end).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -19,41 +23,185 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# query-length range handled by each row kernel (csrc/bsw_kernels.hip: cls_of)
-CLASS_OF_KERNEL = {"bsw_rows_16x%d" % c: (lo, hi) for c, lo, hi in
-                   [(1, 1, 16), (2, 17, 32), (3, 33, 48), (4, 49, 64), (5, 65, 80), (6, 81, 96), (7, 97, 112),
-                    (8, 113, 128), (10, 129, 160), (12, 161, 192), (16, 193, 256)]}
-CLASS_OF_KERNEL.update({"bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)})
+
+# query-length range handled by each bsw row kernel (csrc/bsw_kernels.hip: cls_of)
+BSW_CLASS = {"bsw_rows_16x%d" % c: (lo, hi) for c, lo, hi in
+             [(1, 1, 16), (2, 17, 32), (3, 33, 48), (4, 49, 64), (5, 65, 80), (6, 81, 96), (7, 97, 112),
+              (8, 113, 128), (10, 129, 160), (12, 161, 192), (16, 193, 256)]}
+BSW_CLASS.update({"bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)})
+PHMM_CLASS = {"phmm_f32_rpl1": (1, 64), "phmm_f32_rpl2": (65, 128), "phmm_f32_rpl3": (129, 192),
+              "phmm_f32_rpl4": (193, 256), "phmm_f32_rpl6": (257, 384), "phmm_f32_rpl8": (385, 1 << 30)}
 
 
-def cpu_baseline(batch, params, max_pairs):
-    """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
-    else the oracle restatement (kind 'port'); all host cores; bounded sample of the same workload."""
-    from oracle import oracle_py as O
-    cores = os.cpu_count() or 1
-    n = min(batch.n, max_pairs)
-    sample = batch.slice(0, n)
-    kind = "port"
-    t0 = time.perf_counter()
-    ref = O.ref_lib("bsw")
-    if ref is not None and hasattr(ref, "ref_bsw_getscores16_mt"):
-        import ctypes as C
-        out = np.zeros((n, 6), dtype=np.int32)
-        secs = C.c_double(0.0)
-        best = None
-        for _ in range(3):      # median-free: best of 3, the driver's own timed region (objects built outside)
-            ref.ref_bsw_getscores16_mt(*O._bsw_args(params, sample, out), C.c_int32(512), C.c_int32(cores),
-                                       C.byref(secs))
-            best = secs.value if best is None else min(best, secs.value)
-        kind = "reference"
-        dt = best
-    else:
-        O.bsw_oracle(params, sample, cores)
+# ------------------------------------------------------------------------------------------ workloads
+class BswWork:
+    metric, unit, dtype = "bsw_large_gcups", "GCUPS", "int32"
+
+    def __init__(self, args, rank, dev):
+        from genomicsbench_amd.bsw import DeviceBswBatch, make_params
+        from genomicsbench_amd.datagen import gen_bsw
+        self.n = args.size or 2_000_000
+        self.params = make_params()
+        self.batch = gen_bsw(self.n, 1002, first=rank * self.n)
+        self.d = DeviceBswBatch(self.batch, dev)
+        self.units = float(self.batch.nominal_cells)
+        self.workload = ("bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), "
+                         "nominal cells = sum len1*len2" % self.n)
+        self.extra = {"pairs_per_gpu": self.n, "nominal_cells_per_gpu": self.batch.nominal_cells}
+
+    def run(self, stream):
+        self.d.run(self.params, stream)
+
+    def roofline_bytes(self, kernel):
+        b = self.batch
+        lo, hi = BSW_CLASS.get(kernel, (1, 1 << 30))
+        sel = (b.len2 >= lo) & (b.len2 <= hi)
+        units = float((b.len1[sel].astype(np.int64) * b.len2[sel]).sum())
+        return int(b.len1[sel].astype(np.int64).sum() + b.len2[sel].astype(np.int64).sum() + 36 * sel.sum()), units
+
+    def cpu_baseline(self, max_units):
+        """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
+        else the oracle restatement (kind 'port'); all host cores; bounded sample of the same workload."""
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        n = min(self.batch.n, max_units or 2_000_000)
+        sample = self.batch.slice(0, n)
+        ref = O.ref_lib("bsw")
+        if ref is not None and hasattr(ref, "ref_bsw_getscores16_mt"):
+            out = np.zeros((n, 6), dtype=np.int32)
+            secs, best = C.c_double(0.0), None
+            for _ in range(3):      # best of 3; the driver's own timed region (objects are built outside it)
+                ref.ref_bsw_getscores16_mt(*O._bsw_args(self.params, sample, out), C.c_int32(512), C.c_int32(cores),
+                                           C.byref(secs))
+                best = secs.value if best is None else min(best, secs.value)
+            kind, dt, what = "reference", best, "reference AVX2 getScores16 -b 512, one object per thread"
+        else:
+            t0 = time.perf_counter()
+            O.bsw_oracle(self.params, sample, cores)
+            kind, dt, what = "port", time.perf_counter() - t0, "oracle/bsw_oracle.c scalar restatement, OpenMP"
+        return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+                "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" % (n, what, dt)}
+
+
+class ChainWork:
+    metric, unit, dtype = "chain_large_gcups", "GCUPS", "int32+f64"
+
+    def __init__(self, args, rank, dev):
+        from genomicsbench_amd.chain import DeviceChainBatch
+        from genomicsbench_amd.datagen import gen_chain
+        self.n = args.size or 10_000
+        self.case = gen_chain(self.n, 2001, first=rank * self.n)
+        self.d = DeviceChainBatch(*self.case, dev)
+        self.units = None                                   # evaluated predecessor pairs: read from the device counter
+        self.workload = ("chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), "
+                         "cell = evaluated predecessor pair" % self.n)
+        self.extra = {"calls_per_gpu": self.n, "anchors_per_gpu": int(self.case[0][-1])}
+
+    def run(self, stream):
+        self.d.run(stream)
+
+    def finish(self, stream):
+        self.units = float(self.d.evaluated_pairs(stream))
+        self.extra["evaluated_pairs_per_gpu"] = int(self.units)
+
+    def roofline_bytes(self, kernel):
+        return 40 * int(self.case[0][-1]), self.units        # 16 B anchor + 4x4 B outputs + 8 B re-read of score/parent
+
+    def cpu_baseline(self, max_units):
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        n = min(self.n, max_units or 2000)
+        off, ax, ay, hdr = self.case
+        sub = (off[:n + 1], ax[:off[n]], ay[:off[n]], hdr[:n])
+        ref = O.ref_lib("chain")
+        t0 = time.perf_counter()
+        if ref is not None:
+            O.chain_ref(*sub, nthreads=cores)
+            kind, what = "reference", "reference host_chain_kernel (chain_dp), OpenMP dynamic"
+        else:
+            O.chain_oracle(*sub, nthreads=cores)
+            kind, what = "port", "oracle/chain_oracle.c, OpenMP dynamic"
         dt = time.perf_counter() - t0
-    return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
-            "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" %
-                      (n, "reference AVX2 getScores16 -b 512, one object per thread" if kind == "reference"
-                       else "oracle/bsw_oracle.c scalar restatement, OpenMP", dt)}
+        pairs = O.chain_oracle(*sub, nthreads=cores, return_pairs=True)[4]
+        return {"value": pairs / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+                "sample": "first %d calls of the rank-0 shard (%d evaluated pairs), %s, %.2f s" % (n, pairs, what, dt)}
+
+
+class PhmmWork:
+    metric, unit, dtype = "phmm_large_gcups", "GCUPS", "f32"
+
+    def __init__(self, args, rank, dev):
+        from genomicsbench_amd.datagen import gen_phmm
+        from genomicsbench_amd.phmm import DevicePhmmBatchSet
+        self.n = args.size or 20_000
+        self.bs = gen_phmm(self.n, 3001, first=rank * self.n)
+        self.d = DevicePhmmBatchSet(self.bs, dev)
+        self.units = float(self.bs.cells)
+        self.workload = ("phmm large: %d synthetic GATK batches per GPU (seed 3001), %d read x haplotype pairs, "
+                         "cell = rslen*haplen; fp32 with fp64 redo below 1e-28" % (self.n, self.bs.n_pairs))
+        self.extra = {"batches_per_gpu": self.n, "pairs_per_gpu": self.bs.n_pairs, "cells_per_gpu": self.bs.cells}
+
+    def run(self, stream):
+        self.d.run(stream)
+
+    def roofline_bytes(self, kernel):
+        bs = self.bs
+        lo, hi = PHMM_CLASS.get(kernel, (1, 1 << 30))
+        rl, hl = bs.read_len[bs.pair_read].astype(np.int64), bs.hap_len[bs.pair_hap].astype(np.int64)
+        sel = (rl >= lo) & (rl <= hi)
+        return int((5 * rl[sel] + hl[sel] + 8).sum()), float((rl[sel] * hl[sel]).sum())
+
+    def cpu_baseline(self, max_units):
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        sub = self.bs.take_batches(0, min(self.n, max_units or 400))
+        t0 = time.perf_counter()
+        O.phmm_oracle(sub, cores)
+        dt = time.perf_counter() - t0
+        return {"value": sub.cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+                "sample": "first %d batches (%d pairs), oracle/phmm_oracle.c scalar fp32+fp64 redo, OpenMP, %.2f s "
+                          "(GKL is an empty submodule: no reference build)" % (len(sub.n_reads), sub.n_pairs, dt)}
+
+
+class PoaWork:
+    metric, unit, dtype = "poa_large_gcups", "GCUPS", "int32"
+
+    def __init__(self, args, rank, dev):
+        from genomicsbench_amd.datagen import gen_poa
+        from genomicsbench_amd.poa import DevicePoaWindowSet, make_params
+        self.n = args.size or 6_000
+        self.params = make_params()
+        self.ws = gen_poa(self.n, 4001, first=rank * self.n)
+        self.d = DevicePoaWindowSet(self.ws, dev)
+        self.units = None                                   # graph nodes x sequence length, device counter
+        self.workload = ("poa large: %d synthetic 500-bp consensus windows per GPU (seed 4001), "
+                         "cell = graph node x sequence position per alignment" % self.n)
+        self.extra = {"windows_per_gpu": self.n, "sequences_per_gpu": self.ws.n_seqs,
+                      "workspace_gb": round(self.d.work_bytes / 1e9, 2)}
+
+    def run(self, stream):
+        self.d.run(self.params, stream)
+
+    def finish(self, stream):
+        self.units = float(self.d.cells(stream))
+        self.extra["dp_cells_per_gpu"] = int(self.units)
+
+    def roofline_bytes(self, kernel):
+        return int(self.units * 32), self.units             # 5 x 4 B written + ~12 B of predecessor rows read per cell
+
+    def cpu_baseline(self, max_units):
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        sub = self.ws.take(0, min(self.n, max_units or 256))
+        t0 = time.perf_counter()
+        _, cells = O.poa_oracle(self.params, sub, cores, return_cells=True)
+        dt = time.perf_counter() - t0
+        return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+                "sample": "first %d windows, oracle/poa_oracle.c scalar spoa restatement, OpenMP, %.2f s "
+                          "(spoa is an empty submodule: no reference build)" % (sub.n_windows, dt)}
+
+
+WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork}
 
 
 def main():
@@ -61,16 +209,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=2_000_000, help="pairs per GPU (bsw 'large' = 2M, seed 1002)")
-    ap.add_argument("--cpu-pairs", type=int, default=2_000_000, help="pairs in the CPU-baseline sample")
+    ap.add_argument("--kernel", choices=sorted(WORKLOADS), default="bsw")
+    ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows); 0 = 'large'")
+    ap.add_argument("--pairs", type=int, default=0, help="alias of --size for bsw")
+    ap.add_argument("--cpu-units", type=int, default=0, help="units in the CPU-baseline sample (0 = kernel default)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.pairs:
+        args.size = args.pairs
 
     import torch
     import torch.distributed as dist
     from genomicsbench_amd import _native as N
-    from genomicsbench_amd.bsw import DeviceBswBatch, make_params
-    from genomicsbench_amd.datagen import gen_bsw
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,54 +239,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    params = make_params()
-    batch = gen_bsw(args.pairs, 1002, first=rank * args.pairs)       # this rank's shard
-    dbatch = DeviceBswBatch(batch, dev)
+    work = WORKLOADS[args.kernel](args, rank, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     for _ in range(args.warmup):
-        dbatch.run(params, stream)
+        work.run(stream)
     barrier()
     N.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dbatch.run(params, stream)
+        work.run(stream)
     barrier()
     dt = time.perf_counter() - t0
     stages = N.profile_end()
+    if hasattr(work, "finish"):
+        work.finish(stream)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    cells = torch.tensor([float(batch.nominal_cells)], dtype=torch.float64, device=dev)
+    units = torch.tensor([work.units], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cells, op=dist.ReduceOp.SUM)
-    dt_max, total_cells = float(t.item()), float(cells.item())
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    dt_max, total_units = float(t.item()), float(units.item())
 
     if rank == 0:
-        # roofline of the dominant kernel: algorithmic bytes of the pairs it processes / its mean duration
+        # roofline of the dominant kernel: algorithmic bytes of the units it processes / its mean duration
         name, (ms_sum, launches) = max(stages.items(), key=lambda kv: kv[1][0])
-        lo, hi = CLASS_OF_KERNEL.get(name, (1, 1 << 30))
-        sel = (batch.len2 >= lo) & (batch.len2 <= hi)
-        alg_bytes = int(batch.len1[sel].astype(np.int64).sum() + batch.len2[sel].astype(np.int64).sum() + 36 * sel.sum())
         k_ms = ms_sum / max(launches, 1)
+        alg_bytes, k_units = work.roofline_bytes(name)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        cfg = {"workload": work.workload,
+               "parallelism": "units sharded over %d rank(s), no data-path collective" % world}
+        cfg.update(work.extra)
         line = {
-            "metric": "bsw_large_gcups", "value": total_cells * args.steps / dt_max / 1e9, "unit": "GCUPS",
+            "metric": work.metric, "value": total_units * args.steps / dt_max / 1e9, "unit": work.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), "
-                                   "nominal cells = sum len1*len2" % args.pairs,
-                       "pairs_per_gpu": args.pairs, "nominal_cells_per_gpu": batch.nominal_cells,
-                       "parallelism": "pairs sharded over %d rank(s), no data-path collective" % world},
+            "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "cells_per_s_dominant_kernel": float((batch.len1[sel].astype(np.int64) * batch.len2[sel]).sum()) / (k_ms * 1e-3)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
             "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
         }
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(batch, params, args.cpu_pairs)
+            line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -101,6 +101,7 @@ def _declare(L):
         L.gbx_poa_workspace_bytes.argtypes = [vp]
         L.gbx_poa_workspace_bytes.restype = sz
         L.gbx_poa_consensus_host.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, i64]
+        L.gbx_poa_cells.argtypes = [vp, vp, C.POINTER(C.c_int64), vp]
         L.gbx_poa_consensus_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, sz, vp]
     if hasattr(L, "gbx_phmm_forward_host"):
         L.gbx_phmm_workspace_bytes.argtypes = [i64, C.c_int32]
@@ -112,6 +113,7 @@ def _declare(L):
         L.gbx_chain_workspace_bytes.restype = sz
         L.gbx_chain_host.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.gbx_chain_device.argtypes = [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.gbx_chain_evaluated_pairs.argtypes = [vp, C.POINTER(C.c_int64), vp]
 
 
 def check(rc):

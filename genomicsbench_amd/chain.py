@@ -55,3 +55,9 @@ class DeviceChainBatch:
     def results(self):
         k = self.n_anchors
         return tuple(a[:k].cpu().numpy() for a in (self.score, self.parent, self.target, self.peak))
+
+    def evaluated_pairs(self, stream=None):
+        """Predecessor pairs visited by the last run() (device-side counter)."""
+        v = C.c_int64(0)
+        N.check(N.lib().gbx_chain_evaluated_pairs(self.work.data_ptr(), C.byref(v), stream))
+        return v.value

@@ -555,10 +555,20 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         int64_t cap = (int64_t)cus * blocks_per_cu;
         return (int)(want < cap ? want : cap);
     };
+    // the grid is the number of blocks that are resident at once (occupancy query), so that the static
+    // round-robin over the longest-first list starts every group on the longest pairs together
 #define GBX_ROWS(CPL_, BPC_, CLS_)                                                                                         \
     {                                                                                                                      \
+        static int bpc = 0;                                                                                                \
+        if (!bpc) {                                                                                                        \
+            int q = 0;                                                                                                     \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, bsw_rows_kernel<16, CPL_>, 256, 0) != hipSuccess || q < 1) { \
+                (void)hipGetLastError(); q = BPC_;                                                                         \
+            }                                                                                                              \
+            bpc = q > 8 ? 8 : q;                                                                                           \
+        }                                                                                                                  \
         Stage st("bsw_rows_16x" #CPL_, s);                                                                                 \
-        hipLaunchKernelGGL((bsw_rows_kernel<16, CPL_>), dim3(grid_for(16, BPC_)), dim3(256), 0, s, dev, P, W, CLS_);       \
+        hipLaunchKernelGGL((bsw_rows_kernel<16, CPL_>), dim3(grid_for(16, bpc)), dim3(256), 0, s, dev, P, W, CLS_);        \
     }
     GBX_ROWS(1, 8, 0) GBX_ROWS(2, 8, 1) GBX_ROWS(3, 8, 2) GBX_ROWS(4, 8, 3) GBX_ROWS(5, 6, 4) GBX_ROWS(6, 6, 5)
     GBX_ROWS(7, 6, 6) GBX_ROWS(8, 6, 7) GBX_ROWS(10, 4, 8) GBX_ROWS(12, 4, 9) GBX_ROWS(16, 3, 10)

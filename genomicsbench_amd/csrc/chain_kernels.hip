@@ -57,6 +57,7 @@ struct ChainWork {
     int32_t *cursors;   // [NBUCKET]
     int32_t *next;      // work cursor
     int32_t *order;     // [n_calls] calls, longest bucket first
+    unsigned long long *evaluated;   // predecessor pairs visited (the benchmark's "cell")
 };
 
 __device__ inline int bucket_of(int64_t n)
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
         int st = 0;
+        unsigned long long visited = 0;
         for (int i = 0; i < n; ++i) {
             const uint64_t ri = x[i], yi = y[i];
             const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 const unsigned long long brk = __ballot(bump && nl > max_skip);
                 const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
                 const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
+                visited += __builtin_popcountll(__ballot(valid) & (bl >= 63 ? ~0ull : ((2ull << bl) - 1)));
                 const unsigned long long imp = __ballot(improving) & before;
                 if (imp) {
                     const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
@@ -190,6 +193,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
+        if (lane == 0) atomicAdd(W.evaluated, visited);
     }
 }
 
@@ -201,6 +205,15 @@ size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors)
     return (size_t)(3 * NBUCKET + (n_calls > 0 ? n_calls : 0) + 2 * (n_anchors > 0 ? n_anchors : 0) + 16) * sizeof(int32_t);
 }
 
+int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s)
+{
+    unsigned long long v = 0;
+    GBX_HIP(hipMemcpyAsync(&v, (const char *)d_work + (2 * NBUCKET + 2) * sizeof(int32_t), sizeof(v), hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    *pairs = (int64_t)v;
+    return GBX_OK;
+}
+
 int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
                  int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
@@ -210,7 +223,8 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     if (n_calls > 0x7fffffffLL - 1024) { set_error("chain: more than 2^31 calls"); return GBX_ERR_UNSUPPORTED; }
     if (work_bytes < chain_workspace_bytes(n_calls, n_anchors)) { set_error("chain: workspace too small"); return GBX_ERR_ARG; }
     int32_t *wi = (int32_t *)d_work;
-    ChainWork W = {wi, wi + NBUCKET, wi + 2 * NBUCKET, wi + 3 * NBUCKET};
+    // [counts | cursors | next, evaluated(u64 at +2) | order[n_calls] | spare planes]
+    ChainWork W = {wi, wi + NBUCKET, wi + 2 * NBUCKET, wi + 3 * NBUCKET, (unsigned long long *)(wi + 2 * NBUCKET + 2)};
     int32_t *spare = wi + 3 * NBUCKET + n_calls + 8;
     if (!d_target) d_target = spare;
     if (!d_peak) d_peak = spare + n_anchors;

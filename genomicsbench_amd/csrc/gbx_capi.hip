@@ -516,7 +516,19 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
 size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan)
 {
     if (!plan) return 0;
-    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots;
+    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots + 64;
+}
+
+int gbx_poa_cells(const gbx_poa_plan *plan, const void *d_work, int64_t *cells, void *stream)
+{
+    if (!plan || !d_work || !cells) { set_error("gbx_poa_cells: null pointer"); return GBX_ERR_ARG; }
+    return poa_read_cells(d_work, gbx_poa_workspace_bytes(plan) - 64, cells, (hipStream_t)stream);
+}
+
+int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream)
+{
+    if (!d_work || !pairs) { set_error("gbx_chain_evaluated_pairs: null pointer"); return GBX_ERR_ARG; }
+    return chain_read_evaluated(d_work, pairs, (hipStream_t)stream);
 }
 
 int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows,

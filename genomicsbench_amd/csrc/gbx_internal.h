@@ -42,6 +42,9 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
                  void *d_work, size_t work_bytes, hipStream_t s);
 
+int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s);
+int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s);
+
 // ---- phmm (phmm_kernels.hip)
 size_t phmm_workspace_bytes(int64_t n_pairs, int max_hap_len);
 int phmm_init_tables();

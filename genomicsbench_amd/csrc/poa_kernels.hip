@@ -61,6 +61,7 @@ struct PoaArgs {
     const uint8_t *arena;
     uint8_t *cons; int32_t *cons_len; int32_t *status; int64_t cons_stride;
     char *work; int64_t slot_bytes;
+    unsigned long long *cells;        // DP cells (graph nodes x sequence length, summed over alignments)
     int ncap, deg, lmax;
     PoaScore S;
     Mat2 Tc1, Tc2, Tc4, Tc8;          // (T^CPL)^(1,2,4,8): uniform factors of the row_shr scan steps
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     int32_t *mat = (int32_t *)(slot + L.mat);
 
+    unsigned long long cells = 0;
     for (int64_t w = blockIdx.x; w < A.n_windows; w += gridDim.x) {
         poa_graph_reset(g);
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
@@ -247,6 +249,7 @@ __global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
                 const int64_t plane = (int64_t)(g.n_nodes + 1) * (len + 1);
                 PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, len + 1};
                 int mi, mj;
+                cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 poa_dp<CPL>(g, M, A, seq, len, mi, mj);
                 poa_traceback(g, M, A.S, seq, mi, mj);
             }
@@ -258,12 +261,22 @@ __global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
         if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
         if ((threadIdx.x & 63) == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
     }
+    if ((threadIdx.x & 63) == 0) atomicAdd(A.cells, cells);
 }
 
 }  // namespace
 
 // workspace = slots * slot_bytes
 size_t poa_slot_bytes(int ncap, int deg, int lmax) { return (size_t)make_layout(ncap, deg, lmax).total; }
+
+int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s)
+{
+    unsigned long long v = 0;
+    GBX_HIP(hipMemcpyAsync(&v, (const char *)d_work + slots_bytes, sizeof(v), hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    *cells = (int64_t)v;
+    return GBX_OK;
+}
 
 int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
@@ -276,14 +289,16 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
     if (S.g >= S.e) { set_error("poa: linear gap mode (g >= e) is not supported by the device path"); return GBX_ERR_UNSUPPORTED; }
     if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }          // affine == convex with both pieces equal
     const SlotLayout L = make_layout(ncap, deg, lmax);
-    if (work_bytes < (size_t)L.total * (size_t)n_slots) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
+    if (work_bytes < (size_t)L.total * (size_t)n_slots + 64) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
+    unsigned long long *d_cells = (unsigned long long *)((char *)d_work + (size_t)L.total * (size_t)n_slots);
+    GBX_HIP(hipMemsetAsync(d_cells, 0, 8, s));
     int cpl = lmax <= 256 ? 4 : lmax <= 512 ? 8 : lmax <= 768 ? 12 : 16;
     const Mat2 T = {S.e, S.g, S.q, S.c};
     const Mat2 Tc = mp_pow(T, cpl);
     PoaArgs A;
     A.n_windows = n_windows; A.win_first_seq = d_win_first_seq; A.seq_off = d_seq_off; A.seq_len = d_seq_len;
     A.arena = d_arena; A.cons = d_cons; A.cons_len = d_cons_len; A.status = d_status; A.cons_stride = cons_stride;
-    A.work = (char *)d_work; A.slot_bytes = L.total; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
+    A.work = (char *)d_work; A.slot_bytes = L.total; A.cells = d_cells; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
     A.Tc1 = Tc; A.Tc2 = mp_mul(Tc, Tc); A.Tc4 = mp_mul(A.Tc2, A.Tc2); A.Tc8 = mp_mul(A.Tc4, A.Tc4);
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
     Stage st("poa_window", s);

@@ -101,3 +101,9 @@ class DevicePoaWindowSet:
         if st[:self.n_windows].any():
             raise N.GbxError(N.GBX_ERR_UNSUPPORTED, "window %d overflowed a device capacity" % int(np.nonzero(st)[0][0]))
         return [cons[w, :clen[w]].tobytes().decode() for w in range(self.n_windows)]
+
+    def cells(self, stream=None):
+        """DP cells of the last run() (device-side counter)."""
+        v = C.c_int64(0)
+        N.check(N.lib().gbx_poa_cells(C.byref(self.plan), self.work.data_ptr(), C.byref(v), stream))
+        return v.value

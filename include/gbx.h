@@ -165,6 +165,10 @@ int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor
                      int32_t *d_target, int32_t *d_peak,
                      void *d_work, size_t work_bytes, void *stream);
 
+/* Work counter of the last gbx_chain_device call on this workspace: predecessor pairs (i,j) visited,
+ * `continue`d ones included, those after the max_skip break excluded (the benchmark's "cell"). */
+int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream);
+
 /* -------------------------------------------------------------------- phmm
  * GATK/GKL Pair-HMM forward log10-likelihoods.
  * Replaces  void initPairHMM()                                     R/benchmarks/phmm/PairHMMUnitTest.cpp:84,193
@@ -235,6 +239,10 @@ typedef struct gbx_poa_plan {
 
 int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int32_t *seq_len, gbx_poa_plan *plan);
 size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan);
+
+/* DP cells of the last gbx_poa_consensus_device call on this workspace: sum over alignments of
+ * graph nodes x sequence length. */
+int gbx_poa_cells(const gbx_poa_plan *plan, const void *d_work, int64_t *cells, void *stream);
 
 /* cons: n_windows rows of cons_stride bytes (not NUL-terminated), cons_len[w] = consensus length.
  * Returns GBX_ERR_UNSUPPORTED (and names the first window) if any window overflowed a capacity. */
