@@ -19,8 +19,8 @@
 //            prefix-max for "sc > max_f", and n_skip as a walk reflected at 0
 //            (prefix sum + prefix min); first lane with n_skip > max_skip breaks;
 //   phase 4  targets[parents[j]] = i for the lanes before the break (:89).
-// Calls are handed out longest-first from an atomic cursor (the longest call
-// bounds the kernel's makespan).
+// Calls are handed out longest-first, round-robin over the resident wavefronts
+// (the longest call bounds the kernel's makespan).
 #include "gbx_internal.h"
 
 namespace gbx {
@@ -88,11 +88,9 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     const int lane = threadIdx.x;
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
 
-    for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(W.next, 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= n_calls) break;
+    // static round-robin over the longest-first list (an LPT schedule); everything derived from `slot`
+    // stays wave-uniform
+    for (int slot = blockIdx.x; slot < n_calls; slot += gridDim.x) {
         const int call = W.order[slot];
         const int64_t o = off[call];
         const int n = (int)(off[call + 1] - o);
