@@ -500,14 +500,14 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
         if (bases > bmax) bmax = bases;
     }
     plan->max_seq_len = lmax;
-    plan->max_seqs_per_window = smax < 4 ? 4 : smax;
+    plan->max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);     /* multiple of 4: 16-byte aligned edge rows */
     int64_t cap = (int64_t)6 * lmax + 256;                 /* typical windows stay below ~3x the read length */
     if (bmax + 8 < cap) cap = bmax + 8;
     plan->node_cap = (int32_t)cap;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     else (void)hipGetLastError();
-    int64_t slots = (int64_t)cus * 4;
+    int64_t slots = (int64_t)cus * 10;      /* LDS (15 KB per wave) admits 10 waves per CU */
     if (n_windows < slots) slots = n_windows > 0 ? n_windows : 1;
     plan->n_slots = (int32_t)slots;
     return GBX_OK;
@@ -516,13 +516,13 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
 size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan)
 {
     if (!plan) return 0;
-    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots + 64;
+    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots + 128;
 }
 
 int gbx_poa_cells(const gbx_poa_plan *plan, const void *d_work, int64_t *cells, void *stream)
 {
     if (!plan || !d_work || !cells) { set_error("gbx_poa_cells: null pointer"); return GBX_ERR_ARG; }
-    return poa_read_cells(d_work, gbx_poa_workspace_bytes(plan) - 64, cells, (hipStream_t)stream);
+    return poa_read_cells(d_work, gbx_poa_workspace_bytes(plan) - 128, cells, (hipStream_t)stream);
 }
 
 int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream)

@@ -26,8 +26,17 @@
 
 namespace gbx {
 
-constexpr int POA_NEG_INF = INT32_MIN + 1024;      // spoa kNegativeInfinity
+// DP cells are stored as int16.  spoa's kNegativeInfinity (INT32_MIN + 1024) only ever appears as an exact
+// sentinel (row 0 of F/O, column 0 of E/Q) that loses every max() and fails every equality test against a
+// real score; -32000 plays the same role as long as real scores stay above -30000, which the host plan
+// guarantees (it rejects windows whose worst-case score could go lower).
+typedef int16_t poa_cell_t;
+constexpr int POA_NEG_INF = -32000;
+constexpr int POA_COL0 = 7;                        // column j lives at index j + 7: column 1 is 16-byte aligned
+PG_HD int poa_row_stride(int len) { return 8 + ((len + 15) / 16) * 16; }
 constexpr int POA_ALN_CAP = 7;                     // aligned nodes per node (8 distinct letters per column)
+constexpr int POA_ALN_STRIDE = 8;                  // row stride of the aligned-node lists (16-byte aligned rows)
+struct alignas(16) PoaInt4 { int32_t v[4]; };      // one 16-byte load of four list entries
 
 // error bits (per window)
 constexpr int POA_ERR_NODES = 1;                   // node capacity exceeded
@@ -44,15 +53,18 @@ struct PoaGraph {
     uint8_t *in_cnt;        // [ncap]
     uint8_t *out_cnt;       // [ncap]
     uint8_t *aln_cnt;       // [ncap]
-    int32_t *in_src;        // [ncap*deg] source node of in-edge k (insertion order)
-    int32_t *in_wt;         // [ncap*deg] total weight of in-edge k
-    int32_t *out_dst;       // [ncap*deg] destination of out-edge k (insertion order)
-    uint8_t *out_slot;      // [ncap*deg] position of that edge in the destination's in-list
-    int32_t *aln;           // [ncap*POA_ALN_CAP] aligned node ids (insertion order)
+    // Edge lists, insertion order.  The first four entries of a node are "hot" ([ncap*4], 16 bytes per node,
+    // neighbouring nodes share cache lines); entries 4..deg-1 are "cold" ([ncap*(deg-4)], rarely touched).
+    int32_t *in_src, *in_src_x;     // source node of in-edge k
+    int32_t *in_wt, *in_wt_x;       // total weight of in-edge k
+    int32_t *out_dst, *out_dst_x;   // destination of out-edge k
+    uint8_t *out_slot, *out_slot_x; // position of that out-edge in the destination's in-list
+    int32_t *aln;           // [ncap*POA_ALN_STRIDE] aligned node ids (insertion order), 16-byte aligned rows
     int32_t *r2n, *n2r;     // [ncap] topological order
     // scratch
     uint8_t *mark, *check;  // [ncap]
-    int32_t *stack;         // [stk_cap]
+    int32_t *stack;         // [stk_cap] DFS stack of the topological sort (LDS on the GPU when it fits)
+    int32_t *cons_path;     // [ncap] heaviest-bundle path (consensus backtrack)
     int32_t *score, *pred;  // [ncap]
     int32_t *path_node, *path_pos;   // [aln_path_cap] alignment, stored in traceback (reverse) order
     // letters
@@ -60,7 +72,14 @@ struct PoaGraph {
     uint8_t *decoder;       // [256]
     // counters (kept in registers by the caller between calls)
     int n_nodes, n_codes, n_path, err;
+    int path_lo, path_hi;   // smallest / largest sequence position on the alignment path (set by poa_traceback)
 };
+
+#define PG_EDGE(hot, cold, n, k) ((k) < 4 ? (hot)[(int64_t)(n) * 4 + (k)] : (cold)[(int64_t)(n) * (g.deg - 4) + ((k) - 4)])
+#define PG_IN_SRC(g, n, k) PG_EDGE((g).in_src, (g).in_src_x, n, k)
+#define PG_IN_WT(g, n, k) PG_EDGE((g).in_wt, (g).in_wt_x, n, k)
+#define PG_OUT_DST(g, n, k) PG_EDGE((g).out_dst, (g).out_dst_x, n, k)
+#define PG_OUT_SLOT(g, n, k) PG_EDGE((g).out_slot, (g).out_slot_x, n, k)
 
 PG_HD void poa_graph_reset(PoaGraph &g)
 {
@@ -82,11 +101,11 @@ PG_HD void poa_add_edge(PoaGraph &g, int b, int e, int w)
 {
     const int oc = g.out_cnt[b];
     for (int k = 0; k < oc; ++k)
-        if (g.out_dst[b * g.deg + k] == e) { g.in_wt[e * g.deg + g.out_slot[b * g.deg + k]] += w; return; }
+        if (PG_OUT_DST(g, b, k) == e) { PG_IN_WT(g, e, PG_OUT_SLOT(g, b, k)) += w; return; }
     const int ic = g.in_cnt[e];
     if (oc >= g.deg || ic >= g.deg) { g.err |= POA_ERR_DEGREE; return; }
-    g.out_dst[b * g.deg + oc] = e; g.out_slot[b * g.deg + oc] = (uint8_t)ic; g.out_cnt[b] = (uint8_t)(oc + 1);
-    g.in_src[e * g.deg + ic] = b; g.in_wt[e * g.deg + ic] = w; g.in_cnt[e] = (uint8_t)(ic + 1);
+    PG_OUT_DST(g, b, oc) = e; PG_OUT_SLOT(g, b, oc) = (uint8_t)ic; g.out_cnt[b] = (uint8_t)(oc + 1);
+    PG_IN_SRC(g, e, ic) = b; PG_IN_WT(g, e, ic) = w; g.in_cnt[e] = (uint8_t)(ic + 1);
 }
 
 // Graph::add_sequence: a fresh chain for seq[begin,end); returns its first node or -1
@@ -103,7 +122,10 @@ PG_HD int poa_add_chain(PoaGraph &g, const uint8_t *seq, int begin, int end)
     return first;
 }
 
-// Graph::topological_sort (iterative DFS; aligned nodes are emitted side by side)
+// Graph::topological_sort (iterative DFS; aligned nodes are emitted side by side).
+// Everything a visit needs (marks, degrees, the first four in-edges and aligned nodes) is loaded up
+// front, independent of each other, so a visit costs about two memory round trips on the GPU.
+// Requires g.deg % 4 == 0 (16-byte aligned in-edge rows).
 PG_HD void poa_topo_sort(PoaGraph &g)
 {
     const int n = g.n_nodes;
@@ -114,21 +136,23 @@ PG_HD void poa_topo_sort(PoaGraph &g)
         g.stack[sp++] = i;
         while (sp) {
             const int id = g.stack[sp - 1];
+            const int mk = g.mark[id], ic = g.in_cnt[id], ac = g.aln_cnt[id];
+            const bool chk = g.check[id] != 0;
+            const PoaInt4 e4 = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
+            const PoaInt4 a4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
+            const PoaInt4 b4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
             bool valid = true;
-            if (g.mark[id] != 2) {
-                const int ic = g.in_cnt[id];
+            if (mk != 2) {
                 for (int k = 0; k < ic; ++k) {
-                    const int b = g.in_src[id * g.deg + k];
+                    const int b = k < 4 ? e4.v[k] : PG_IN_SRC(g, id, k);
                     if (g.mark[b] != 2) {
                         if (sp >= g.stk_cap) { g.err |= POA_ERR_STACK; return; }
                         g.stack[sp++] = b; valid = false;
                     }
                 }
-                const bool chk = g.check[id] != 0;
-                const int ac = g.aln_cnt[id];
                 if (chk) {
                     for (int k = 0; k < ac; ++k) {
-                        const int a = g.aln[id * POA_ALN_CAP + k];
+                        const int a = k < 4 ? a4.v[k] : b4.v[k - 4];
                         if (g.mark[a] != 2) {
                             if (sp >= g.stk_cap) { g.err |= POA_ERR_STACK; return; }
                             g.stack[sp++] = a; g.check[a] = 0; valid = false;
@@ -139,7 +163,7 @@ PG_HD void poa_topo_sort(PoaGraph &g)
                     g.mark[id] = 2;
                     if (chk) {
                         g.n2r[id] = nr; g.r2n[nr++] = id;
-                        for (int k = 0; k < ac; ++k) { const int a = g.aln[id * POA_ALN_CAP + k]; g.n2r[a] = nr; g.r2n[nr++] = a; }
+                        for (int k = 0; k < ac; ++k) { const int a = k < 4 ? a4.v[k] : b4.v[k - 4]; g.n2r[a] = nr; g.r2n[nr++] = a; }
                     }
                 } else g.mark[id] = 1;
             }
@@ -188,7 +212,7 @@ PG_HD void poa_add_alignment(PoaGraph &g, const uint8_t *seq, int len)
             int found = -1;
             const int ac = g.aln_cnt[node];
             for (int k = 0; k < ac; ++k) {
-                const int a = g.aln[node * POA_ALN_CAP + k];
+                const int a = g.aln[node * POA_ALN_STRIDE + k];
                 if (g.code[a] == code) { found = a; break; }
             }
             if (found == -1) {
@@ -196,12 +220,12 @@ PG_HD void poa_add_alignment(PoaGraph &g, const uint8_t *seq, int len)
                 if (ac + 1 > POA_ALN_CAP) { g.err |= POA_ERR_LETTERS; }
                 else {
                     for (int k = 0; k < ac; ++k) {
-                        const int a = g.aln[node * POA_ALN_CAP + k];
-                        g.aln[id * POA_ALN_CAP + g.aln_cnt[id]] = a; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
-                        g.aln[a * POA_ALN_CAP + g.aln_cnt[a]] = id; g.aln_cnt[a] = (uint8_t)(g.aln_cnt[a] + 1);
+                        const int a = g.aln[node * POA_ALN_STRIDE + k];
+                        g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = a; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
+                        g.aln[a * POA_ALN_STRIDE + g.aln_cnt[a]] = id; g.aln_cnt[a] = (uint8_t)(g.aln_cnt[a] + 1);
                     }
-                    g.aln[id * POA_ALN_CAP + g.aln_cnt[id]] = node; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
-                    g.aln[node * POA_ALN_CAP + ac] = id; g.aln_cnt[node] = (uint8_t)(ac + 1);
+                    g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = node; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
+                    g.aln[node * POA_ALN_STRIDE + ac] = id; g.aln_cnt[node] = (uint8_t)(ac + 1);
                 }
             } else id = found;
         }
@@ -220,10 +244,10 @@ PG_HD int poa_branch_completion(PoaGraph &g, int rank)
     const int node_id = g.r2n[rank];
     const int oc = g.out_cnt[node_id];
     for (int k = 0; k < oc; ++k) {
-        const int t = g.out_dst[node_id * g.deg + k];
+        const int t = PG_OUT_DST(g, node_id, k);
         const int ic = g.in_cnt[t];
         for (int z = 0; z < ic; ++z) {
-            const int b = g.in_src[t * g.deg + z];
+            const int b = PG_IN_SRC(g, t, z);
             if (b != node_id) g.score[b] = -1;
         }
     }
@@ -233,7 +257,7 @@ PG_HD int poa_branch_completion(PoaGraph &g, int rank)
         int sc = -1, pr = -1;
         const int ic = g.in_cnt[id];
         for (int k = 0; k < ic; ++k) {
-            const int b = g.in_src[id * g.deg + k], w = g.in_wt[id * g.deg + k];
+            const int b = PG_IN_SRC(g, id, k), w = PG_IN_WT(g, id, k);
             if (g.score[b] == -1) continue;
             if (sc < w || (sc == w && g.score[pr] <= g.score[b])) { sc = w; pr = b; }
         }
@@ -256,7 +280,7 @@ PG_HD int poa_consensus(PoaGraph &g, uint8_t *out, int cap)
         int sc = -1, pr = -1;
         const int ic = g.in_cnt[id];
         for (int k = 0; k < ic; ++k) {
-            const int b = g.in_src[id * g.deg + k], w = g.in_wt[id * g.deg + k];
+            const int b = PG_IN_SRC(g, id, k), w = PG_IN_WT(g, id, k);
             if (sc < w || (sc == w && g.score[pr] <= g.score[b])) { sc = w; pr = b; }
         }
         if (pr != -1) sc += g.score[pr];
@@ -264,67 +288,85 @@ PG_HD int poa_consensus(PoaGraph &g, uint8_t *out, int cap)
         if (g.score[max_id] < sc) max_id = id;
     }
     while (g.out_cnt[max_id] != 0) max_id = poa_branch_completion(g, g.n2r[max_id]);
-    // backtrack into the stack array, then emit reversed
+    // backtrack, then emit reversed
     int len = 0;
-    while (g.pred[max_id] != -1) { g.stack[len++] = max_id; max_id = g.pred[max_id]; if (len >= g.stk_cap) { g.err |= POA_ERR_STACK; break; } }
-    g.stack[len++] = max_id;
+    while (g.pred[max_id] != -1) { g.cons_path[len++] = max_id; max_id = g.pred[max_id]; if (len >= g.ncap) { g.err |= POA_ERR_STACK; break; } }
+    g.cons_path[len++] = max_id;
     if (len > cap) g.err |= POA_ERR_CONS;
-    for (int k = 0; k < len && k < cap; ++k) out[k] = g.decoder[g.code[g.stack[len - 1 - k]]];
+    for (int k = 0; k < len && k < cap; ++k) out[k] = g.decoder[g.code[g.cons_path[len - 1 - k]]];
     return len;
 }
 
 // DP matrices of one alignment: (n_nodes+1) rows x W = len+1 columns, row-major
 struct PoaMatrices {
-    int32_t *H, *F, *E, *O, *Q;
-    int W;
+    poa_cell_t *H, *F, *E, *O, *Q;
+    int Wp;                                       // row stride in cells (poa_row_stride)
 };
 
 struct PoaScore { int m, n, g, e, q, c; };
 
+// Row descriptors of the current topological order, indexed by rank r (DP row r+1); stored in
+// g.score / g.pred, which are free until the consensus:
+//   rd_pred[r] = DP row of the node's first in-edge source (0 = the virtual start row)
+//   rd_info[r] = letter | in-degree << 8 | sink << 16
+PG_HD void poa_rowdesc_one(PoaGraph &g, int r)
+{
+    const int node = g.r2n[r];
+    const int ic = g.in_cnt[node];
+    g.score[r] = ic ? g.n2r[PG_IN_SRC(g, node, 0)] + 1 : 0;
+    g.pred[r] = (int)g.decoder[g.code[node]] | (ic << 8) | ((g.out_cnt[node] == 0) << 16);
+}
+
 // Backtrack of SisdAlignmentEngine::align for kNW with affine/convex gaps; fills g.path_* in
 // traceback order (the reference reverses it afterwards; poa_add_alignment reads it backwards).
+// Needs the row descriptors.  All candidate cells of a step are read up front (independent loads),
+// then the reference's priority order (diagonal, vertical F/H/O/H, horizontal E/H/Q/H) is applied.
 PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int max_i, int max_j)
 {
     g.n_path = 0;
     if (max_i == -1 && max_j == -1) return;
-    const int W = M.W;
+    const int Wp = M.Wp;
+    const int32_t *rd_pred = g.score, *rd_info = g.pred;
     int i = max_i, j = max_j, prev_i = 0, prev_j = 0, np = 0;
-#define PG_AT(A, a, b) (A)[(int64_t)(a) * W + (b)]
-#define PG_PUSH(nd, ps) do { if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = (ps); } ++np; } while (0)
+#define PG_AT(A, a, b) ((int)(A)[(int64_t)(a) * Wp + (b) + POA_COL0])
+    int plo = -1, phi = -1;                      // positions come out in descending order
+#define PG_PUSH(nd, ps) do { const int ps_ = (ps); if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = ps_; } \
+                             if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; } while (0)
     while (!(i == 0 && j == 0)) {
         const int Hij = PG_AT(M.H, i, j);
         bool found = false, ext_left = false, ext_up = false;
-        if (i != 0 && j != 0) {
-            const int node = g.r2n[i - 1];
-            const int mc = g.decoder[g.code[node]] == seq[j - 1] ? S.m : S.n;
-            const int ic = g.in_cnt[node];
-            for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
-                const int pi = ic ? g.n2r[g.in_src[node * g.deg + p]] + 1 : 0;
-                if (Hij == PG_AT(M.H, pi, j - 1) + mc) { prev_i = pi; prev_j = j - 1; found = true; }
+        int node = -1, ic = 0, p0 = 0;
+        if (i != 0) { p0 = rd_pred[i - 1]; const int info = rd_info[i - 1]; ic = (info >> 8) & 0xff; node = g.r2n[i - 1];
+            if (j != 0) {
+                const int mc = (info & 0xff) == seq[j - 1] ? S.m : S.n;
+                for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                    if (Hij == PG_AT(M.H, pi, j - 1) + mc) { prev_i = pi; prev_j = j - 1; found = true; }
+                }
             }
-        }
-        if (!found && i != 0) {
-            const int node = g.r2n[i - 1];
-            const int ic = g.in_cnt[node];
-            for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
-                const int pi = ic ? g.n2r[g.in_src[node * g.deg + p]] + 1 : 0;
-                const bool c1 = Hij == PG_AT(M.F, pi, j) + S.e;
-                const bool c2 = !c1 && Hij == PG_AT(M.H, pi, j) + S.g;
-                const bool c3 = !c1 && !c2 && Hij == PG_AT(M.O, pi, j) + S.c;
-                const bool c4 = !c1 && !c2 && !c3 && Hij == PG_AT(M.H, pi, j) + S.q;
-                ext_up = ext_up || c1 || c3;
-                if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; }
+            if (!found) {
+                for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                    const int fv = PG_AT(M.F, pi, j), hv = PG_AT(M.H, pi, j), ov = PG_AT(M.O, pi, j);
+                    const bool c1 = Hij == fv + S.e;
+                    const bool c2 = !c1 && Hij == hv + S.g;
+                    const bool c3 = !c1 && !c2 && Hij == ov + S.c;
+                    const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
+                    ext_up = ext_up || c1 || c3;
+                    if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; }
+                }
             }
         }
         if (!found && j != 0) {
-            const bool c1 = Hij == PG_AT(M.E, i, j - 1) + S.e;
-            const bool c2 = !c1 && Hij == PG_AT(M.H, i, j - 1) + S.g;
-            const bool c3 = !c1 && !c2 && Hij == PG_AT(M.Q, i, j - 1) + S.c;
-            const bool c4 = !c1 && !c2 && !c3 && Hij == PG_AT(M.H, i, j - 1) + S.q;
+            const int ev = PG_AT(M.E, i, j - 1), hv = PG_AT(M.H, i, j - 1), qv = PG_AT(M.Q, i, j - 1);
+            const bool c1 = Hij == ev + S.e;
+            const bool c2 = !c1 && Hij == hv + S.g;
+            const bool c3 = !c1 && !c2 && Hij == qv + S.c;
+            const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
             ext_left = c1 || c3;
             if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; }
         }
-        PG_PUSH(i == prev_i ? -1 : g.r2n[i - 1], j == prev_j ? -1 : j - 1);
+        PG_PUSH(i == prev_i ? -1 : node, j == prev_j ? -1 : j - 1);
         i = prev_i; j = prev_j;
         if (ext_left) {
             for (;;) {
@@ -336,19 +378,21 @@ PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, c
             for (;;) {
                 bool stop = false;
                 prev_i = 0;
-                const int node = g.r2n[i - 1];
-                const int ic = g.in_cnt[node];
-                for (int p = 0; p < ic; ++p) {
-                    const int pi = g.n2r[g.in_src[node * g.deg + p]] + 1;
-                    const bool s1 = PG_AT(M.F, i, j) == PG_AT(M.H, pi, j) + S.g;
-                    const bool s2 = !s1 && PG_AT(M.F, i, j) == PG_AT(M.F, pi, j) + S.e;
-                    const bool s3 = !s1 && !s2 && PG_AT(M.O, i, j) == PG_AT(M.H, pi, j) + S.q;
-                    const bool s4 = !s1 && !s2 && !s3 && PG_AT(M.O, i, j) == PG_AT(M.O, pi, j) + S.c;
+                const int nd = g.r2n[i - 1];
+                const int icu = (rd_info[i - 1] >> 8) & 0xff;
+                const int fij = PG_AT(M.F, i, j), oij = PG_AT(M.O, i, j);
+                for (int p = 0; p < icu; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, nd, p)] + 1 : rd_pred[i - 1];
+                    const int hv = PG_AT(M.H, pi, j);
+                    const bool s1 = fij == hv + S.g;
+                    const bool s2 = !s1 && fij == PG_AT(M.F, pi, j) + S.e;
+                    const bool s3 = !s1 && !s2 && oij == hv + S.q;
+                    const bool s4 = !s1 && !s2 && !s3 && oij == PG_AT(M.O, pi, j) + S.c;
                     // `stop = c1 || .. || (stop = c3) || ..`: the last assignment evaluated wins
                     if (s1) stop = true; else if (s2) stop = false; else stop = s3;
                     if (s1 || s2 || s3 || s4) { prev_i = pi; break; }
                 }
-                PG_PUSH(node, -1);
+                PG_PUSH(nd, -1);
                 i = prev_i;
                 if (stop || i == 0) break;
             }
@@ -358,6 +402,7 @@ PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, c
 #undef PG_AT
 #undef PG_PUSH
     g.n_path = np <= g.aln_path_cap ? np : 0;
+    g.path_lo = plo; g.path_hi = phi;
 }
 
 }  // namespace gbx

@@ -63,14 +63,15 @@ struct PoaArgs {
     char *work; int64_t slot_bytes;
     unsigned long long *cells;        // DP cells (graph nodes x sequence length, summed over alignments)
     int ncap, deg, lmax;
+    int lds_marks;                    // 1: mark/check/DFS stack live in LDS (dynamic shared memory)
     PoaScore S;
-    Mat2 Tc1, Tc2, Tc4, Tc8;          // (T^CPL)^(1,2,4,8): uniform factors of the row_shr scan steps
+    Mat2 Tc[2][4];                    // [CPL 8 | CPL 16][(T^CPL)^(1,2,4,8)]: uniform factors of the row_shr scan steps
 };
 
 // byte offsets of the arrays inside one workspace slot
 struct SlotLayout {
-    int64_t code, in_cnt, out_cnt, aln_cnt, out_slot, mark, check, decoder, coder;
-    int64_t in_src, in_wt, out_dst, aln, r2n, n2r, stack, score, pred, path_node, path_pos, mat, total;
+    int64_t code, in_cnt, out_cnt, aln_cnt, out_slot, out_slot_x, mark, check, decoder, coder;
+    int64_t in_src, in_wt, out_dst, in_src_x, in_wt_x, out_dst_x, aln, r2n, n2r, stack, score, pred, path_node, path_pos, mat, total;
     int stk_cap, path_cap;
 };
 
@@ -84,39 +85,75 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
     L.stk_cap = ncap * 4 + 64;
     L.path_cap = ncap + lmax + 8;
     L.code = take(ncap); L.in_cnt = take(ncap); L.out_cnt = take(ncap); L.aln_cnt = take(ncap);
-    L.out_slot = take((int64_t)ncap * deg); L.mark = take(ncap); L.check = take(ncap);
+    L.out_slot = take((int64_t)ncap * 4); L.out_slot_x = take((int64_t)ncap * (deg - 4) + 16); L.mark = take(ncap); L.check = take(ncap);
     L.decoder = take(256); L.coder = take(512);
-    L.in_src = take((int64_t)ncap * deg * 4); L.in_wt = take((int64_t)ncap * deg * 4);
-    L.out_dst = take((int64_t)ncap * deg * 4); L.aln = take((int64_t)ncap * POA_ALN_CAP * 4);
+    L.in_src = take((int64_t)ncap * 16); L.in_wt = take((int64_t)ncap * 16); L.out_dst = take((int64_t)ncap * 16);
+    L.in_src_x = take((int64_t)ncap * (deg - 4) * 4 + 16); L.in_wt_x = take((int64_t)ncap * (deg - 4) * 4 + 16);
+    L.out_dst_x = take((int64_t)ncap * (deg - 4) * 4 + 16); L.aln = take((int64_t)ncap * POA_ALN_STRIDE * 4 + 64);
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
-    L.mat = take((int64_t)(ncap + 1) * (lmax + 1) * 5 * 4);
+    L.mat = take((int64_t)(ncap + 1) * poa_row_stride(lmax) * 5 * (int64_t)sizeof(poa_cell_t) + 64);
     L.total = align_up(o, 256);
     return L;
 }
 
 // ---- DP of one sequence against the graph: fills M, returns the best sink cell -------------
+// Row descriptors (first predecessor's row, in-degree, letter, sink flag) are built by a parallel
+// pre-pass into g.score / g.pred (free until the consensus), so the row loop starts without a
+// pointer chase.  Cells are int16 and a lane's CPL columns are one (CPL=8) or two (CPL=16) aligned
+// 16-byte vectors, so a predecessor row is read with 3 wide loads per lane and a row is written with 5.
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+template <int CPL>
+__device__ inline void load_cells(const poa_cell_t *p, int *out)
+{
+#pragma unroll
+    for (int k = 0; k < CPL / 8; ++k) {
+        const v8s t = *(const v8s *)(p + 8 * k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[8 * k + e] = t[e];
+    }
+}
+template <int CPL>
+__device__ inline void store_cells(poa_cell_t *p, const int *in)
+{
+#pragma unroll
+    for (int k = 0; k < CPL / 8; ++k) {
+        v8s t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (short)in[8 * k + e];
+        *(v8s *)(p + 8 * k) = t;
+    }
+}
+
 template <int CPL>
 __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
                        int &max_i, int &max_j)
 {
+    static_assert(CPL == 8 || CPL == 16, "a lane owns one or two 16-byte vectors of cells");
     const int lane = threadIdx.x & 63;
     const PoaScore S = A.S;
-    const int W = M.W;
+    const int Wp = M.Wp;
     const int n = g.n_nodes;
     constexpr int BLK = 64 * CPL;
+    const Mat2 *Tc = A.Tc[CPL == 8 ? 0 : 1];
     // lane-dependent max-plus matrices: Tc^(lane&15 + 1), Tc^(lane&31 + 1), Tc^lane
-    const Mat2 P16 = mp_pow(A.Tc1, (lane & 15) + 1);
-    const Mat2 P32 = mp_pow(A.Tc1, (lane & 31) + 1);
-    const Mat2 PC = mp_pow(A.Tc1, lane);
+    const Mat2 P16 = mp_pow(Tc[0], (lane & 15) + 1);
+    const Mat2 P32 = mp_pow(Tc[0], (lane & 31) + 1);
+    const Mat2 PC = mp_pow(Tc[0], lane);
 
-    // row 0 (sisd_alignment_engine `initialize`)
-    for (int j = lane; j < W; j += 64) {
+    // row 0 (sisd_alignment_engine `initialize`) and the row descriptors
+    for (int j = lane; j <= len; j += 64) {
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
-        M.E[j] = e0; M.Q[j] = q0;
-        M.F[j] = j == 0 ? 0 : POA_NEG_INF; M.O[j] = j == 0 ? 0 : POA_NEG_INF;
-        M.H[j] = j == 0 ? 0 : max(q0, e0);
+        M.E[j + POA_COL0] = (poa_cell_t)e0; M.Q[j + POA_COL0] = (poa_cell_t)q0;
+        M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
+        M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
+    }
+    int32_t *d_pred = g.score, *d_info = g.pred;       // [rank] first predecessor row | letter, in-degree, sink
+    {
+        PoaGraph &gm = const_cast<PoaGraph &>(g);
+        for (int r = lane; r < n; r += 64) poa_rowdesc_one(gm, r);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -131,46 +168,60 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
 
     int best = POA_NEG_INF;
     max_i = -1; max_j = -1;
+    int nx_pred = n ? d_pred[0] : 0, nx_info = n ? d_info[0] : 0;
     for (int r = 0; r < n; ++r) {
-        const int node = g.r2n[r], i = r + 1;
-        const int ic = g.in_cnt[node];
-        const int64_t ro = (int64_t)i * W;
-        // column 0
+        const int i = r + 1;
+        const int p0 = nx_pred, info = nx_info;
+        if (r + 1 < n) { nx_pred = d_pred[r + 1]; nx_info = d_info[r + 1]; }      // prefetch the next descriptor
+        const int letter = info & 0xff, ic = (info >> 8) & 0xff;
+        const bool sink = (info >> 16) & 1;
+        const int64_t ro = (int64_t)i * Wp + POA_COL0;                             // index of (i, 0)
+        // predecessor rows (first one from the descriptor, the others from the in-edge list)
+        const int node = ic > 1 ? g.r2n[r] : 0;
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
         for (int k = 0; k < ic; ++k) {
-            const int64_t pi = (int64_t)(g.n2r[g.in_src[node * g.deg + k]] + 1) * W;
-            po = max(po, M.O[pi]); pf = max(pf, M.F[pi]);
+            const int64_t pi = (int64_t)(k ? g.n2r[PG_IN_SRC(g, node, k)] + 1 : p0) * Wp + POA_COL0;
+            po = max(po, (int)M.O[pi]); pf = max(pf, (int)M.F[pi]);
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
-        if (lane == 0) { M.O[ro] = O0; M.F[ro] = F0; M.H[ro] = H0; M.E[ro] = POA_NEG_INF; M.Q[ro] = POA_NEG_INF; }
-        const int letter = g.decoder[g.code[node]];
+        if (lane == 0) {
+            M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
+            M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
+        }
         // (E,Q) at the first column of the block; column 1: E = H0+g, Q = H0+q (E[0] = Q[0] = -inf)
         int cE = H0 + S.g, cQ = H0 + S.q;
+        int hlast = 0;                                             // H(i, len) for the sink test
         for (int base = 0; base < len; base += BLK) {
             const int j0 = base + lane * CPL + 1;                  // lane's first column
+            const bool mine = j0 <= len;                           // the lane owns at least one real column
             if (!single) load_seq(base);
             int Fa[CPL], Oa[CPL], Ha[CPL];
             for (int p = 0; p < (ic ? ic : 1); ++p) {
-                const int64_t po_ = ic ? (int64_t)(g.n2r[g.in_src[node * g.deg + p]] + 1) * W : 0;
-                const int32_t *Hp = M.H + po_, *Fp = M.F + po_, *Op = M.O + po_;
-                int hl = j0 - 1 <= len ? Hp[j0 - 1] : 0;           // H(pred, j-1) for the lane's first column
+                const int64_t po_ = (ic ? (int64_t)(p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0) : 0) * Wp + POA_COL0;
+                int hp[CPL], fp[CPL], op[CPL];
+                if (mine) {
+                    load_cells<CPL>(M.H + po_ + j0, hp); load_cells<CPL>(M.F + po_ + j0, fp); load_cells<CPL>(M.O + po_ + j0, op);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) { hp[c] = 0; fp[c] = 0; op[c] = 0; }
+                }
+                const int hfirst = M.H[po_ + base];                // H(pred, base): left neighbour of the block
+                int hl = __builtin_amdgcn_update_dpp(hfirst, hp[CPL - 1], 0x138, 0xf, 0xf, false);
+                if (lane == 0) hl = hfirst;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const int j = j0 + c;
-                    const bool in = j <= len;
-                    const int hp = in ? Hp[j] : 0, fp = in ? Fp[j] : 0, op = in ? Op[j] : 0;
                     const int sc = sq[c] == letter ? S.m : S.n;
-                    const int f = max(hp + S.g, fp + S.e);
-                    const int o = max(hp + S.q, op + S.c);
+                    const int f = max(hp[c] + S.g, fp[c] + S.e);
+                    const int o = max(hp[c] + S.q, op[c] + S.c);
                     const int h = hl + sc;
-                    hl = hp;
+                    hl = hp[c];
                     if (p == 0) { Fa[c] = f; Oa[c] = o; Ha[c] = h; }
                     else { Fa[c] = max(Fa[c], f); Oa[c] = max(Oa[c], o); Ha[c] = max(Ha[c], h); }
                 }
             }
             int Aa[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) Aa[c] = max(Ha[c], max(Fa[c], Oa[c]));
+            for (int c = 0; c < CPL; ++c) Aa[c] = mine ? max(Ha[c], max(Fa[c], Oa[c])) : SNEG;
             // ---- pass 1: lane-local recurrence from the identity -> this lane's contribution b
             int bE = SNEG, bQ = SNEG;
 #pragma unroll
@@ -181,10 +232,10 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
             }
             // ---- inclusive scan over lanes: x[l] = max_k<=l Tc^(l-k) (x) b[k]
             int xE = bE, xQ = bQ, tE, tQ;
-            mp_apply(A.Tc1, dpp_i<0x111>(SNEG, xE), dpp_i<0x111>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-            mp_apply(A.Tc2, dpp_i<0x112>(SNEG, xE), dpp_i<0x112>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-            mp_apply(A.Tc4, dpp_i<0x114>(SNEG, xE), dpp_i<0x114>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-            mp_apply(A.Tc8, dpp_i<0x118>(SNEG, xE), dpp_i<0x118>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+            mp_apply(Tc[0], dpp_i<0x111>(SNEG, xE), dpp_i<0x111>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+            mp_apply(Tc[1], dpp_i<0x112>(SNEG, xE), dpp_i<0x112>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+            mp_apply(Tc[2], dpp_i<0x114>(SNEG, xE), dpp_i<0x114>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+            mp_apply(Tc[3], dpp_i<0x118>(SNEG, xE), dpp_i<0x118>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
             mp_apply(P16, dpp_i<0x142, 0xa>(SNEG, xE), dpp_i<0x142, 0xa>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
             mp_apply(P32, dpp_i<0x143, 0xc>(SNEG, xE), dpp_i<0x143, 0xc>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
             // (E,Q) entering this lane = previous lane's inclusive value (+) Tc^lane (x) block carry
@@ -193,35 +244,232 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
             mp_apply(PC, cE, cQ, tE, tQ);
             vE = max(vE, tE); vQ = max(vQ, tQ);
             // carry for the next block: (E,Q) leaving lane 63
-            {
+            if (!single) {
                 int oE, oQ;
-                mp_apply(A.Tc1, tE, tQ, oE, oQ);               // Tc^(lane+1) (x) carry
+                mp_apply(Tc[0], tE, tQ, oE, oQ);               // Tc^(lane+1) (x) carry
                 const int lE = max(xE, oE), lQ = max(xQ, oQ);
                 cE = __builtin_amdgcn_readlane(lE, 63); cQ = __builtin_amdgcn_readlane(lQ, 63);
             }
             // ---- pass 2: exact E, Q, H of the lane's columns; store the row
+            int Hn[CPL], En[CPL], Qn[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                const int j = j0 + c;
                 const int h = max(Aa[c], max(vE, vQ));
-                if (j <= len) {
-                    M.H[ro + j] = h; M.F[ro + j] = Fa[c]; M.O[ro + j] = Oa[c]; M.E[ro + j] = vE; M.Q[ro + j] = vQ;
-                }
+                Hn[c] = h; En[c] = vE; Qn[c] = vQ;
                 const int ne = max(h + S.g, vE + S.e), nq = max(h + S.q, vQ + S.c);
                 vE = ne; vQ = nq;
+            }
+            if (mine) {
+                store_cells<CPL>(M.H + ro + j0, Hn); store_cells<CPL>(M.F + ro + j0, Fa); store_cells<CPL>(M.O + ro + j0, Oa);
+                store_cells<CPL>(M.E + ro + j0, En); store_cells<CPL>(M.Q + ro + j0, Qn);
+            }
+            if (sink && base + BLK >= len) {                       // H(i, len) sits in this block
+                const int cl = (len - 1 - base) % CPL;
+                int hv = Hn[0];
+#pragma unroll
+                for (int c = 1; c < CPL; ++c) hv = c == cl ? Hn[c] : hv;
+                hlast = __builtin_amdgcn_readlane(hv, (len - 1 - base) / CPL);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (g.out_cnt[node] == 0) {                                // NW: best sink at the last column
-            const int v = M.H[ro + len];
-            if (best < v) { best = v; max_i = i; max_j = len; }
-        }
+        if (sink && best < hlast) { best = hlast; max_i = i; max_j = len; }       // NW: best sink at the last column
     }
 }
 
-template <int CPL>
-__global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
+// ---- Graph::add_alignment, wavefront version --------------------------------------------------
+// Same result as poa_add_alignment (poa_graph.h), reorganised so that the serial part touches memory
+// as little as possible: letter codes are assigned with ballots in order of first appearance, fresh
+// chains are written by all lanes in parallel, and the path is consumed in chunks of 64 elements whose
+// node codes / sequence codes are fetched by the lanes in parallel and handed to the (wave-uniform)
+// serial loop with v_readlane.
+__device__ inline int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+// runtime-indexed vector elements would live in scratch memory: select explicitly
+__device__ inline int pick4(const PoaInt4 &v, int k) { return k == 0 ? v.v[0] : k == 1 ? v.v[1] : k == 2 ? v.v[2] : v.v[3]; }
+
+// a fresh chain for seq[begin,end) written lane-parallel; returns its first node or -1
+__device__ int poa_add_chain_wave(PoaGraph &g, const uint8_t *seq, int begin, int end)
+{
+    if (begin >= end) return -1;
+    const int lane = threadIdx.x & 63;
+    const int L = end - begin, n0 = g.n_nodes;
+    if (n0 + L > g.ncap) { g.err |= POA_ERR_NODES; return g.ncap - 1; }
+    for (int k = lane; k < L; k += 64) {
+        const int id = n0 + k;
+        g.code[id] = (uint8_t)g.coder[seq[begin + k]];
+        g.in_cnt[id] = k > 0; g.out_cnt[id] = k < L - 1; g.aln_cnt[id] = 0;
+        if (k > 0) { PG_IN_SRC(g, id, 0) = id - 1; PG_IN_WT(g, id, 0) = 2; }
+        if (k < L - 1) { PG_OUT_DST(g, id, 0) = id + 1; PG_OUT_SLOT(g, id, 0) = 0; }
+    }
+    g.n_nodes = n0 + L;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return n0;
+}
+
+// Graph::add_edge with the first four out-edges fetched in one load
+__device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
+{
+    const int oc = g.out_cnt[b];
+    const PoaInt4 d4 = *(const PoaInt4 *)(g.out_dst + (int64_t)b * 4);
+    const int ic = g.in_cnt[e];
+    for (int k = 0; k < oc; ++k) {
+        const int d = k < 4 ? pick4(d4, k) : PG_OUT_DST(g, b, k);
+        if (d == e) { PG_IN_WT(g, e, PG_OUT_SLOT(g, b, k)) += w; return; }
+    }
+    if (oc >= g.deg || ic >= g.deg) { g.err |= POA_ERR_DEGREE; return; }
+    PG_OUT_DST(g, b, oc) = e; PG_OUT_SLOT(g, b, oc) = (uint8_t)ic; g.out_cnt[b] = (uint8_t)(oc + 1);
+    PG_IN_SRC(g, e, ic) = b; PG_IN_WT(g, e, ic) = w; g.in_cnt[e] = (uint8_t)(ic + 1);
+}
+
+// Graph::topological_sort with all of its mutable state in LDS: per node one byte (mark in bits 0-1,
+// "check aligned nodes" in bit 2), the DFS stack and the order being built (16-bit node ids).  The loop
+// issues no global stores (on gfx9 a load behind a store waits for the store's acknowledgement); the
+// order is written to r2n / n2r by all lanes at the end.  Same order as poa_topo_sort (poa_graph.h).
+constexpr int POA_LDS_STACK16 = 1024;
+
+__device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short *ord, short *stk)
+{
+    const int n = g.n_nodes;
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) st8[i] = 4;                    // mark 0, check 1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int sp = 0, nr = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((st8[i] & 3) != 0) continue;
+        stk[sp++] = (short)i;
+        while (sp) {
+            const int id = stk[sp - 1];
+            const int stv = st8[id];
+            const int ic = g.in_cnt[id], ac = g.aln_cnt[id];
+            const PoaInt4 e4 = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
+            const PoaInt4 a4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
+            const PoaInt4 b4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+            const bool chk = (stv & 4) != 0;
+            bool valid = true;
+            if ((stv & 3) != 2) {
+                for (int k = 0; k < ic; ++k) {
+                    const int b = k < 4 ? pick4(e4, k) : PG_IN_SRC(g, id, k);
+                    if ((st8[b] & 3) != 2) {
+                        if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                        stk[sp++] = (short)b; valid = false;
+                    }
+                }
+                if (chk) {
+                    for (int k = 0; k < ac; ++k) {
+                        const int a = k < 4 ? pick4(a4, k) : pick4(b4, k - 4);
+                        const int sa = st8[a];
+                        if ((sa & 3) != 2) {
+                            if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                            stk[sp++] = (short)a; st8[a] = (unsigned char)(sa & 3); valid = false;
+                        }
+                    }
+                }
+                if (valid) {
+                    st8[id] = (unsigned char)((stv & 4) | 2);
+                    if (chk) {
+                        ord[nr++] = (short)id;
+                        for (int k = 0; k < ac; ++k) ord[nr++] = (short)(k < 4 ? pick4(a4, k) : pick4(b4, k - 4));
+                    }
+                } else st8[id] = (unsigned char)((stv & 4) | 1);
+            }
+            if (valid) --sp;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+#ifdef GBX_POA_PHASE_STATS
+__device__ unsigned long long g_topo_cycles, g_topo_iters;
+#define TOPO_TIMED(g) { unsigned long long t0_ = __builtin_readcyclecounter(); POA_TOPO(g); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_topo_cycles, __builtin_readcyclecounter() - t0_); atomicAdd(&g_topo_iters, (unsigned long long)g.n_nodes); } }
+#else
+#define TOPO_TIMED(g) POA_TOPO(g);
+#endif
+// topological sort through LDS when the kernel was launched with the LDS layout, else the global-memory one
+#define POA_TOPO(g) { if (lds_st8) poa_topo_sort_lds(g, lds_st8, lds_ord, lds_stk); else poa_topo_sort(g); }
+__device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, unsigned char *lds_st8, short *lds_ord, short *lds_stk)
+{
+    if (len == 0) return;
+    const int lane = threadIdx.x & 63;
+    // letter codes, in order of first appearance in the sequence
+    for (int base = 0; base < len; base += 64) {
+        const int i = base + lane;
+        const int c = i < len ? seq[i] : -1;
+        bool unk = c >= 0 && g.coder[c] < 0;
+        unsigned long long m = __ballot(unk);
+        while (m) {
+            const int cf = rl(c, __builtin_ctzll(m));
+            g.coder[cf] = (int16_t)g.n_codes; g.decoder[g.n_codes] = (uint8_t)cf; ++g.n_codes;
+            unk = unk && c != cf;
+            m = __ballot(unk);
+        }
+    }
+    const int np = g.n_path;
+    if (np == 0) {
+        poa_add_chain_wave(g, seq, 0, len);
+        if (g.err == 0) TOPO_TIMED(g)
+        return;
+    }
+    const int first_pos = g.path_lo, last_pos = g.path_hi;
+    const int before = g.n_nodes;
+    poa_add_chain_wave(g, seq, 0, first_pos);
+    int head = before == g.n_nodes ? -1 : g.n_nodes - 1;
+    const int tail = poa_add_chain_wave(g, seq, last_pos + 1, len);
+    int prev_w = head == -1 ? 0 : 1;
+    for (int t0 = np - 1; t0 >= 0; t0 -= 64) {                 // forward order = stored order reversed
+        const int t = t0 - lane;
+        const int pos = t >= 0 ? g.path_pos[t] : -1;
+        const int node = t >= 0 ? g.path_node[t] : -1;
+        const int scode = pos >= 0 ? (int)g.coder[seq[pos]] : -1;
+        const int ncode = node >= 0 ? (int)g.code[node] : -1;
+        const int cnt = min(64, t0 + 1);
+        for (int k = 0; k < cnt; ++k) {
+            const int pos_k = rl(pos, k);
+            if (pos_k == -1) continue;
+            if (g.err) return;
+            const int node_k = rl(node, k), code = rl(scode, k), ncode_k = rl(ncode, k);
+            int id;
+            if (node_k == -1) {
+                id = poa_add_node(g, code);
+            } else if (ncode_k == code) {
+                id = node_k;
+            } else {
+                int found = -1;
+                const int ac = g.aln_cnt[node_k];
+                for (int z = 0; z < ac; ++z) {
+                    const int a = g.aln[node_k * POA_ALN_STRIDE + z];
+                    if (g.code[a] == code) { found = a; break; }
+                }
+                if (found == -1) {
+                    id = poa_add_node(g, code);
+                    if (ac + 1 > POA_ALN_CAP) { g.err |= POA_ERR_LETTERS; }
+                    else {
+                        for (int z = 0; z < ac; ++z) {
+                            const int a = g.aln[node_k * POA_ALN_STRIDE + z];
+                            g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = a; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
+                            g.aln[a * POA_ALN_STRIDE + g.aln_cnt[a]] = id; g.aln_cnt[a] = (uint8_t)(g.aln_cnt[a] + 1);
+                        }
+                        g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = node_k; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
+                        g.aln[node_k * POA_ALN_STRIDE + ac] = id; g.aln_cnt[node_k] = (uint8_t)(ac + 1);
+                    }
+                } else id = found;
+            }
+            if (head != -1) poa_add_edge_wave(g, head, id, prev_w + 1);
+            head = id;
+            prev_w = 1;
+        }
+    }
+    if (tail != -1) poa_add_edge_wave(g, head, tail, prev_w + 1);
+    if (g.err) return;
+    TOPO_TIMED(g)
+}
+
+__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
     PoaGraph g;
@@ -231,13 +479,30 @@ __global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
     g.out_slot = (uint8_t *)(slot + L.out_slot); g.mark = (uint8_t *)(slot + L.mark); g.check = (uint8_t *)(slot + L.check);
     g.decoder = (uint8_t *)(slot + L.decoder); g.coder = (int16_t *)(slot + L.coder);
     g.in_src = (int32_t *)(slot + L.in_src); g.in_wt = (int32_t *)(slot + L.in_wt);
+    g.in_src_x = (int32_t *)(slot + L.in_src_x); g.in_wt_x = (int32_t *)(slot + L.in_wt_x);
+    g.out_dst_x = (int32_t *)(slot + L.out_dst_x); g.out_slot_x = (uint8_t *)(slot + L.out_slot_x);
     g.out_dst = (int32_t *)(slot + L.out_dst); g.aln = (int32_t *)(slot + L.aln);
     g.r2n = (int32_t *)(slot + L.r2n); g.n2r = (int32_t *)(slot + L.n2r);
     g.stack = (int32_t *)(slot + L.stack); g.score = (int32_t *)(slot + L.score); g.pred = (int32_t *)(slot + L.pred);
+    g.cons_path = g.stack;                                    // the global DFS-stack area doubles as the consensus path
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int ncp = (A.ncap + 15) & ~15;
+    // serial DFS state on chip (LDS): state byte per node, order under construction, stack
+    unsigned char *lds_st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
+    short *lds_ord = (short *)(lds_raw + ncp);
+    short *lds_stk = (short *)(lds_raw + ncp + 2 * ncp);
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
-    int32_t *mat = (int32_t *)(slot + L.mat);
+    poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
 
     unsigned long long cells = 0;
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long t_dp = 0, t_tb = 0, t_add = 0, t_cons = 0;
+#define PH_T0 unsigned long long ph0_ = __builtin_readcyclecounter();
+#define PH_ACC(x) { unsigned long long ph1_ = __builtin_readcyclecounter(); x += ph1_ - ph0_; ph0_ = ph1_; }
+#else
+#define PH_T0
+#define PH_ACC(x)
+#endif
     for (int64_t w = blockIdx.x; w < A.n_windows; w += gridDim.x) {
         poa_graph_reset(g);
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
@@ -246,22 +511,39 @@ __global__ void __launch_bounds__(64) poa_kernel(PoaArgs A, SlotLayout L)
             const int len = A.seq_len[s];
             g.n_path = 0;
             if (g.n_nodes != 0 && len != 0 && g.err == 0) {
-                const int64_t plane = (int64_t)(g.n_nodes + 1) * (len + 1);
-                PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, len + 1};
+                const int wp = poa_row_stride(len);
+                const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
+                PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
-                poa_dp<CPL>(g, M, A, seq, len, mi, mj);
+                PH_T0
+                poa_dp<8>(g, M, A, seq, len, mi, mj);      // sequences longer than 512 run as several column blocks
+                PH_ACC(t_dp)
                 poa_traceback(g, M, A.S, seq, mi, mj);
+                PH_ACC(t_tb)
             }
-            if (g.err == 0) poa_add_alignment(g, seq, len);
+            {
+                PH_T0
+                if (g.err == 0) poa_add_alignment_wave(g, seq, len, lds_st8, lds_ord, lds_stk);
+                PH_ACC(t_add)
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         int clen = 0;
-        if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+        {
+            PH_T0
+            if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+            PH_ACC(t_cons)
+        }
         if ((threadIdx.x & 63) == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(A.cells, cells);
+#ifdef GBX_POA_PHASE_STATS
+    if ((threadIdx.x & 63) == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); }
+    __syncthreads();
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; }
+#endif
 }
 
 }  // namespace
@@ -289,24 +571,34 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
     if (S.g >= S.e) { set_error("poa: linear gap mode (g >= e) is not supported by the device path"); return GBX_ERR_UNSUPPORTED; }
     if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }          // affine == convex with both pieces equal
     const SlotLayout L = make_layout(ncap, deg, lmax);
-    if (work_bytes < (size_t)L.total * (size_t)n_slots + 64) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
+    if (work_bytes < (size_t)L.total * (size_t)n_slots + 128) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
     unsigned long long *d_cells = (unsigned long long *)((char *)d_work + (size_t)L.total * (size_t)n_slots);
-    GBX_HIP(hipMemsetAsync(d_cells, 0, 8, s));
-    int cpl = lmax <= 256 ? 4 : lmax <= 512 ? 8 : lmax <= 768 ? 12 : 16;
+    GBX_HIP(hipMemsetAsync(d_cells, 0, 128, s));
     const Mat2 T = {S.e, S.g, S.q, S.c};
-    const Mat2 Tc = mp_pow(T, cpl);
     PoaArgs A;
     A.n_windows = n_windows; A.win_first_seq = d_win_first_seq; A.seq_off = d_seq_off; A.seq_len = d_seq_len;
     A.arena = d_arena; A.cons = d_cons; A.cons_len = d_cons_len; A.status = d_status; A.cons_stride = cons_stride;
     A.work = (char *)d_work; A.slot_bytes = L.total; A.cells = d_cells; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
-    A.Tc1 = Tc; A.Tc2 = mp_mul(Tc, Tc); A.Tc4 = mp_mul(A.Tc2, A.Tc2); A.Tc8 = mp_mul(A.Tc4, A.Tc4);
+    for (int v = 0; v < 2; ++v) {
+        A.Tc[v][0] = mp_pow(T, v == 0 ? 8 : 16);
+        for (int k = 1; k < 4; ++k) A.Tc[v][k] = mp_mul(A.Tc[v][k - 1], A.Tc[v][k - 1]);
+    }
+    // int16 cells: every real score must stay above -30000 (poa_graph.h); worst case = one long gap
+    {
+        const int worst = -(S.q < S.g ? -S.q : -S.g) * 2 - (S.c > S.e ? -S.c : -S.e) * (ncap + lmax) - (-S.n) * 0;
+        const int worst_mis = S.n * lmax;
+        const int hi = S.m * lmax;
+        if (worst < -30000 || worst_mis < -30000 || hi > 30000) {
+            set_error("poa: scores may leave the int16 range for these capacities (nodes %d, length %d)", ncap, lmax);
+            return GBX_ERR_UNSUPPORTED;
+        }
+    }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
-    Stage st("poa_window", s);
-    switch (cpl) {
-    case 4: hipLaunchKernelGGL(poa_kernel<4>, dim3(grid), dim3(64), 0, s, A, L); break;
-    case 8: hipLaunchKernelGGL(poa_kernel<8>, dim3(grid), dim3(64), 0, s, A, L); break;
-    case 12: hipLaunchKernelGGL(poa_kernel<12>, dim3(grid), dim3(64), 0, s, A, L); break;
-    default: hipLaunchKernelGGL(poa_kernel<16>, dim3(grid), dim3(64), 0, s, A, L); break;
+    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
+    {
+        Stage st("poa_window", s);
+        hipLaunchKernelGGL(poa_kernel, dim3(grid), dim3(64), A.lds_marks ? lds_need : 0, s, A, L);
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;

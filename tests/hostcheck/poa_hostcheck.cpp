@@ -16,41 +16,42 @@ using namespace gbx;
 static void scalar_dp(PoaGraph &g, PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len, int *max_i, int *max_j)
 {
     const int W = len + 1, n = g.n_nodes;
-    M.W = W;
-    auto at = [&](int32_t *A, int i, int j) -> int32_t & { return A[(int64_t)i * W + j]; };
+    M.Wp = poa_row_stride(len);
+    const int Wp = M.Wp;
+    auto at = [&](poa_cell_t *A, int i, int j) -> poa_cell_t & { return A[(int64_t)i * Wp + j + POA_COL0]; };
     at(M.O, 0, 0) = at(M.Q, 0, 0) = at(M.F, 0, 0) = at(M.E, 0, 0) = 0;
     for (int j = 1; j < W; ++j) {
         at(M.O, 0, j) = POA_NEG_INF; at(M.Q, 0, j) = S.q + (j - 1) * S.c;
         at(M.F, 0, j) = POA_NEG_INF; at(M.E, 0, j) = S.g + (j - 1) * S.e;
     }
     at(M.H, 0, 0) = 0;
-    for (int j = 1; j < W; ++j) at(M.H, 0, j) = std::max(at(M.Q, 0, j), at(M.E, 0, j));
+    for (int j = 1; j < W; ++j) at(M.H, 0, j) = std::max<int>(at(M.Q, 0, j), at(M.E, 0, j));
     int best = POA_NEG_INF; *max_i = -1; *max_j = -1;
     for (int r = 0; r < n; ++r) {
         const int node = g.r2n[r], i = r + 1, ic = g.in_cnt[node];
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
         for (int k = 0; k < ic; ++k) {
-            const int pi = g.n2r[g.in_src[node * g.deg + k]] + 1;
-            po = std::max(po, at(M.O, pi, 0)); pf = std::max(pf, at(M.F, pi, 0));
+            const int pi = g.n2r[PG_IN_SRC(g, node, k)] + 1;
+            po = std::max<int>(po, at(M.O, pi, 0)); pf = std::max<int>(pf, at(M.F, pi, 0));
         }
         at(M.O, i, 0) = po + S.c; at(M.Q, i, 0) = POA_NEG_INF;
         at(M.F, i, 0) = pf + S.e; at(M.E, i, 0) = POA_NEG_INF;
-        at(M.H, i, 0) = std::max(at(M.O, i, 0), at(M.F, i, 0));
+        at(M.H, i, 0) = std::max<int>(at(M.O, i, 0), at(M.F, i, 0));
         const uint8_t letter = g.decoder[g.code[node]];
         for (int p = 0; p < (ic ? ic : 1); ++p) {
-            const int pi = ic ? g.n2r[g.in_src[node * g.deg + p]] + 1 : 0;
+            const int pi = ic ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : 0;
             for (int j = 1; j < W; ++j) {
-                const int f = std::max(at(M.H, pi, j) + S.g, at(M.F, pi, j) + S.e);
-                const int o = std::max(at(M.H, pi, j) + S.q, at(M.O, pi, j) + S.c);
+                const int f = std::max<int>(at(M.H, pi, j) + S.g, at(M.F, pi, j) + S.e);
+                const int o = std::max<int>(at(M.H, pi, j) + S.q, at(M.O, pi, j) + S.c);
                 const int h = at(M.H, pi, j - 1) + (letter == seq[j - 1] ? S.m : S.n);
                 if (p == 0) { at(M.F, i, j) = f; at(M.O, i, j) = o; at(M.H, i, j) = h; }
-                else { at(M.F, i, j) = std::max(at(M.F, i, j), f); at(M.O, i, j) = std::max(at(M.O, i, j), o); at(M.H, i, j) = std::max(at(M.H, i, j), h); }
+                else { at(M.F, i, j) = std::max<int>(at(M.F, i, j), f); at(M.O, i, j) = std::max<int>(at(M.O, i, j), o); at(M.H, i, j) = std::max<int>(at(M.H, i, j), h); }
             }
         }
         for (int j = 1; j < W; ++j) {
-            at(M.E, i, j) = std::max(at(M.H, i, j - 1) + S.g, at(M.E, i, j - 1) + S.e);
-            at(M.Q, i, j) = std::max(at(M.H, i, j - 1) + S.q, at(M.Q, i, j - 1) + S.c);
-            at(M.H, i, j) = std::max(at(M.H, i, j), std::max(std::max(at(M.F, i, j), at(M.E, i, j)), std::max(at(M.O, i, j), at(M.Q, i, j))));
+            at(M.E, i, j) = std::max<int>(at(M.H, i, j - 1) + S.g, at(M.E, i, j - 1) + S.e);
+            at(M.Q, i, j) = std::max<int>(at(M.H, i, j - 1) + S.q, at(M.Q, i, j - 1) + S.c);
+            at(M.H, i, j) = std::max<int>(at(M.H, i, j), std::max<int>(std::max<int>(at(M.F, i, j), at(M.E, i, j)), std::max<int>(at(M.O, i, j), at(M.Q, i, j))));
         }
         if (g.out_cnt[node] == 0 && best < at(M.H, i, W - 1)) { best = at(M.H, i, W - 1); *max_i = i; *max_j = W - 1; }
     }
@@ -60,23 +61,26 @@ extern "C" int hostcheck_poa_window(const gbx_poa_params *P, int n_seqs, const c
                                     char *cons, int cons_cap, int ncap, int deg, int64_t *stats)
 {
     int lmax = 0;
-    for (int s = 0; s < n_seqs; ++s) lmax = std::max(lmax, lens[s]);
+    for (int s = 0; s < n_seqs; ++s) lmax = std::max<int>(lmax, lens[s]);
     PoaGraph g;
+    deg = (deg + 3) & ~3;
     g.ncap = ncap; g.deg = deg; g.stk_cap = ncap * 4 + 64; g.aln_path_cap = ncap + lmax + 8;
     std::vector<uint8_t> code(ncap), icnt(ncap), ocnt(ncap), acnt(ncap), oslot((size_t)ncap * deg), mark(ncap), check(ncap), dec(256);
-    std::vector<int32_t> isrc((size_t)ncap * deg), iwt((size_t)ncap * deg), odst((size_t)ncap * deg), aln((size_t)ncap * POA_ALN_CAP),
+    std::vector<int32_t> isrc((size_t)ncap * deg), iwt((size_t)ncap * deg), odst((size_t)ncap * deg), aln((size_t)ncap * POA_ALN_STRIDE + 8),
         r2n(ncap), n2r(ncap), stack(g.stk_cap), score(ncap), pred(ncap), pn(g.aln_path_cap), pp(g.aln_path_cap);
     std::vector<int16_t> coder(256);
     g.code = code.data(); g.in_cnt = icnt.data(); g.out_cnt = ocnt.data(); g.aln_cnt = acnt.data();
     g.in_src = isrc.data(); g.in_wt = iwt.data(); g.out_dst = odst.data(); g.out_slot = oslot.data(); g.aln = aln.data();
+    std::vector<int32_t> isx((size_t)ncap * deg), iwx((size_t)ncap * deg), odx((size_t)ncap * deg); std::vector<uint8_t> osx((size_t)ncap * deg);
+    g.in_src_x = isx.data(); g.in_wt_x = iwx.data(); g.out_dst_x = odx.data(); g.out_slot_x = osx.data();
     g.r2n = r2n.data(); g.n2r = n2r.data(); g.mark = mark.data(); g.check = check.data(); g.stack = stack.data();
-    g.score = score.data(); g.pred = pred.data(); g.path_node = pn.data(); g.path_pos = pp.data();
+    g.score = score.data(); g.pred = pred.data(); std::vector<int32_t> cpath(ncap + 1); g.cons_path = cpath.data(); g.path_node = pn.data(); g.path_pos = pp.data();
     g.coder = coder.data(); g.decoder = dec.data();
     poa_graph_reset(g);
     PoaScore S = {P->m, P->n, P->g, P->e, P->q, P->c};
     if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
-    std::vector<int32_t> mat((size_t)(ncap + 1) * (lmax + 1) * 5);
-    const size_t plane = (size_t)(ncap + 1) * (lmax + 1);
+    const size_t plane = (size_t)(ncap + 1) * poa_row_stride(lmax);
+    std::vector<poa_cell_t> mat(plane * 5);
     PoaMatrices M = {mat.data(), mat.data() + plane, mat.data() + 2 * plane, mat.data() + 3 * plane, mat.data() + 4 * plane, 0};
     for (int s = 0; s < n_seqs; ++s) {
         const uint8_t *seq = (const uint8_t *)seqs[s];
@@ -84,6 +88,7 @@ extern "C" int hostcheck_poa_window(const gbx_poa_params *P, int n_seqs, const c
         if (g.n_nodes != 0 && lens[s] != 0 && g.err == 0) {
             int mi, mj;
             scalar_dp(g, M, S, seq, lens[s], &mi, &mj);
+            for (int r = 0; r < g.n_nodes; ++r) poa_rowdesc_one(g, r);
             poa_traceback(g, M, S, seq, mi, mj);
         }
         if (g.err == 0) poa_add_alignment(g, seq, lens[s]);      // same guards as poa_kernel
