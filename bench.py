@@ -164,7 +164,7 @@ class PhmmWork:
 
 
 class PoaWork:
-    metric, unit, dtype = "poa_large_gcups", "GCUPS", "int32"
+    metric, unit, dtype = "poa_large_gcups", "GCUPS", "int16"
 
     def __init__(self, args, rank, dev):
         from genomicsbench_amd.datagen import gen_poa
@@ -187,7 +187,7 @@ class PoaWork:
         self.extra["dp_cells_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        return int(self.units * 32), self.units             # 5 x 4 B written + ~12 B of predecessor rows read per cell
+        return int(self.units * 19), self.units             # 5 x 2 B written + 3 x 2 B x ~1.5 predecessor rows read per cell
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
