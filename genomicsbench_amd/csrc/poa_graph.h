@@ -309,12 +309,16 @@ struct PoaScore { int m, n, g, e, q, c; };
 // g.score / g.pred, which are free until the consensus:
 //   rd_pred[r] = DP row of the node's first in-edge source (0 = the virtual start row)
 //   rd_info[r] = letter | in-degree << 8 | sink << 16
+// and, only for the DP (the traceback overwrites them): DP rows of the 2nd and 3rd in-edge source in
+// g.path_node[r] / g.path_pos[r].
 PG_HD void poa_rowdesc_one(PoaGraph &g, int r)
 {
     const int node = g.r2n[r];
     const int ic = g.in_cnt[node];
     g.score[r] = ic ? g.n2r[PG_IN_SRC(g, node, 0)] + 1 : 0;
     g.pred[r] = (int)g.decoder[g.code[node]] | (ic << 8) | ((g.out_cnt[node] == 0) << 16);
+    g.path_node[r] = ic > 1 ? g.n2r[PG_IN_SRC(g, node, 1)] + 1 : 0;
+    g.path_pos[r] = ic > 2 ? g.n2r[PG_IN_SRC(g, node, 2)] + 1 : 0;
 }
 
 // Backtrack of SisdAlignmentEngine::align for kNW with affine/convex gaps; fills g.path_* in

@@ -168,20 +168,30 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
 
     int best = POA_NEG_INF;
     max_i = -1; max_j = -1;
-    int nx_pred = n ? d_pred[0] : 0, nx_info = n ? d_info[0] : 0;
+    const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;   // 2nd / 3rd predecessor rows (free until the traceback)
+    int nx_pred = n ? d_pred[0] : 0, nx_info = n ? d_info[0] : 0, nx_p1 = n ? d_pred1[0] : 0, nx_p2 = n ? d_pred2[0] : 0;
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
-        const int p0 = nx_pred, info = nx_info;
-        if (r + 1 < n) { nx_pred = d_pred[r + 1]; nx_info = d_info[r + 1]; }      // prefetch the next descriptor
+        const int p0 = nx_pred, info = nx_info, p1 = nx_p1, p2 = nx_p2;
+        if (r + 1 < n) { nx_pred = d_pred[r + 1]; nx_info = d_info[r + 1]; nx_p1 = d_pred1[r + 1]; nx_p2 = d_pred2[r + 1]; }   // prefetch
         const int letter = info & 0xff, ic = (info >> 8) & 0xff;
         const bool sink = (info >> 16) & 1;
         const int64_t ro = (int64_t)i * Wp + POA_COL0;                             // index of (i, 0)
-        // predecessor rows (first one from the descriptor, the others from the in-edge list)
-        const int node = ic > 1 ? g.r2n[r] : 0;
+        // predecessor rows: the first three from the descriptors, any further ones from the in-edge list
+        const int node = ic > 3 ? g.r2n[r] : 0;
+        auto pred_row = [&](int k) { return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1; };
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
-        for (int k = 0; k < ic; ++k) {
-            const int64_t pi = (int64_t)(k ? g.n2r[PG_IN_SRC(g, node, k)] + 1 : p0) * Wp + POA_COL0;
-            po = max(po, (int)M.O[pi]); pf = max(pf, (int)M.F[pi]);
+        {
+            // column 0 of up to three predecessor rows: independent loads, one round trip
+            const int64_t i0 = (int64_t)p0 * Wp + POA_COL0, i1 = (int64_t)p1 * Wp + POA_COL0, i2 = (int64_t)p2 * Wp + POA_COL0;
+            const int o0 = M.O[i0], f0 = M.F[i0], o1 = M.O[i1], f1 = M.F[i1], o2 = M.O[i2], f2 = M.F[i2];
+            if (ic > 0) { po = max(po, o0); pf = max(pf, f0); }
+            if (ic > 1) { po = max(po, o1); pf = max(pf, f1); }
+            if (ic > 2) { po = max(po, o2); pf = max(pf, f2); }
+            for (int k = 3; k < ic; ++k) {
+                const int64_t pi = (int64_t)pred_row(k) * Wp + POA_COL0;
+                po = max(po, (int)M.O[pi]); pf = max(pf, (int)M.F[pi]);
+            }
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
         if (lane == 0) {
@@ -197,7 +207,7 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
             if (!single) load_seq(base);
             int Fa[CPL], Oa[CPL], Ha[CPL];
             for (int p = 0; p < (ic ? ic : 1); ++p) {
-                const int64_t po_ = (ic ? (int64_t)(p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0) : 0) * Wp + POA_COL0;
+                const int64_t po_ = (ic ? (int64_t)pred_row(p) : 0) * Wp + POA_COL0;
                 int hp[CPL], fp[CPL], op[CPL];
                 if (mine) {
                     load_cells<CPL>(M.H + po_ + j0, hp); load_cells<CPL>(M.F + po_ + j0, fp); load_cells<CPL>(M.O + po_ + j0, op);
