@@ -26,7 +26,6 @@
 namespace gbx {
 namespace {
 
-constexpr int NEGI = -(1 << 30);
 constexpr int NBUCKET = 32;
 
 template <int CTRL, int ROWMASK = 0xf>
@@ -35,22 +34,33 @@ __device__ inline int dppi(int old, int x)
     return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xf, false);
 }
 
-struct OpMax { static constexpr int id = NEGI; __device__ static int f(int a, int b) { return max(a, b); } };
-struct OpMin { static constexpr int id = -NEGI; __device__ static int f(int a, int b) { return min(a, b); } };
-struct OpAdd { static constexpr int id = 0; __device__ static int f(int a, int b) { return a + b; } };
+// inclusive scans over the 64 lanes of the wave.  The row_shr steps use mov_dpp with bound_ctrl:1
+// (lanes without a source read 0), which the compiler folds into the consumer (v_max_u32_dpp /
+// v_add_u32_dpp): callers bias their values so that 0 is the identity.
+template <int CTRL>
+__device__ inline unsigned dppz(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true); }
 
-// inclusive scan over the 64 lanes of the wave
-template <class Op>
-__device__ inline int wave_scan(int x)
+__device__ inline unsigned wave_scan_umax(unsigned x)          // identity 0
 {
-    x = Op::f(x, dppi<0x111>(Op::id, x));
-    x = Op::f(x, dppi<0x112>(Op::id, x));
-    x = Op::f(x, dppi<0x114>(Op::id, x));
-    x = Op::f(x, dppi<0x118>(Op::id, x));
-    x = Op::f(x, dppi<0x142, 0xa>(Op::id, x));
-    x = Op::f(x, dppi<0x143, 0xc>(Op::id, x));
+    x = max(x, dppz<0x111>(x));
+    x = max(x, dppz<0x112>(x));
+    x = max(x, dppz<0x114>(x));
+    x = max(x, dppz<0x118>(x));
+    x = max(x, (unsigned)dppi<0x142, 0xa>(0, (int)x));
+    x = max(x, (unsigned)dppi<0x143, 0xc>(0, (int)x));
     return x;
 }
+__device__ inline int wave_scan_add(int x)                     // identity 0
+{
+    x += (int)dppz<0x111>((unsigned)x);
+    x += (int)dppz<0x112>((unsigned)x);
+    x += (int)dppz<0x114>((unsigned)x);
+    x += (int)dppz<0x118>((unsigned)x);
+    x += dppi<0x142, 0xa>(0, x);
+    x += dppi<0x143, 0xc>(0, x);
+    return x;
+}
+constexpr unsigned UBIAS = 1u << 30;                           // scores and skip counters are far inside +-2^30
 
 struct ChainWork {
     int32_t *counts;    // [NBUCKET] calls per size bucket
@@ -78,12 +88,26 @@ __global__ void __launch_bounds__(256) chain_order_kernel(int64_t n_calls, const
     W.order[base + atomicAdd(&W.cursors[b], 1)] = (int)c;
 }
 
+constexpr int RING = 256;                 // most recent anchors kept in LDS (covers the usual look-back)
+
+__device__ inline uint64_t readlane64(uint64_t v, int k)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, k);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), k);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *__restrict__ off,
                                                    const uint64_t *__restrict__ ax, const uint64_t *__restrict__ ay,
                                                    const gbx_chain_call *__restrict__ hdr,
                                                    int32_t *score, int32_t *parent, int32_t *target, int32_t *peak,
                                                    ChainWork W)
 {
+    // ring of the last RING anchors (slot = index & (RING-1)): anchor words and the DP state of the reference's
+    // scores / parents / targets / peak_scores vectors.  The same values also go to global memory (the outputs),
+    // which serves the rare look-backs deeper than the ring.
+    __shared__ uint64_t rx[RING], ry[RING];
+    __shared__ int rf[RING], rp[RING], rt[RING], rk[RING];
     __shared__ int mark[64];
     const int lane = threadIdx.x;
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
@@ -99,99 +123,130 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         const gbx_chain_call h = hdr[call];
         const int max_dist_x = h.max_dist_x, max_dist_y = h.max_dist_y, bw = h.bw, n_segs = h.n_segs;
         const double avg_qspan = (double)h.avg_qspan;
+        const uint64_t mdx = (uint64_t)(int64_t)max_dist_x;
 
         for (int i = lane; i < n; i += 64) t[i] = 0;          // vectors are zero-filled, host_kernel.cpp:44-47
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
         int st = 0;
+        int sb = 0;                                           // block of 64 x-values cached for the st scan
+        uint64_t xs = n ? x[min(lane, n - 1)] : 0;
         unsigned long long visited = 0;
-        for (int i = 0; i < n; ++i) {
-            const uint64_t ri = x[i], yi = y[i];
-            const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
-            const int sidi = (int)(yi >> 48 & 0xff);
-            // advance st (:56): first st with ri <= x[st] + max_dist_x
-            while (st < i) {
-                const int idx = st + lane;
-                const bool far = idx < i && ri > x[idx] + (uint64_t)(int64_t)max_dist_x;
-                const unsigned long long m = __ballot(far);
-                const int adv = m == ~0ull ? 64 : __builtin_ctzll(~m);
-                st += adv;
-                if (adv < 64) break;
-            }
-            if (i - st > max_iter) st = i - max_iter;         // :57
+        for (int ib = 0; ib < n; ib += 64) {
+            // this block's anchors, one per lane
+            const uint64_t xa = x[min(ib + lane, n - 1)], ya = y[min(ib + lane, n - 1)];
+            const int kmax = min(64, n - ib);
+            for (int k = 0; k < kmax; ++k) {
+                const int i = ib + k;
+                const uint64_t ri = readlane64(xa, k), yi = readlane64(ya, k);
+                const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
+                const int sidi = (int)(yi >> 48 & 0xff);
+                // advance st (:56): first st with ri <= x[st] + max_dist_x, scanning the cached block
+                for (;;) {
+                    if (st >= i) break;
+                    if (st >= sb + 64 || st < sb) { sb = st; xs = x[min(sb + lane, n - 1)]; }
+                    const int idx = sb + lane;
+                    const bool far = idx >= st && idx < i && ri > xs + mdx;
+                    const bool stop = idx >= st && !far;                  // first lane at/after st that is not far
+                    const unsigned long long m = __ballot(stop);
+                    if (m) { st = sb + __builtin_ctzll(m); break; }
+                    st = sb + 64;                                         // the whole rest of the block is far
+                }
+                if (st > i) st = i;
+                if (i - st > max_iter) st = i - max_iter;                 // :57
 
-            int max_f = q_span, max_j = -1, n_skip = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (int jhi = i - 1; jhi >= st; jhi -= 64) {
-                const int j = jhi - lane;
-                const bool valid = j >= st;
-                const int jj = valid ? j : st;
-                const uint64_t xj = x[jj], yj = y[jj];
-                const int fj = f[jj], pj = p[jj], tj = t[jj];
-                // ---- phase 1: candidate score / `continue` mask (:59-80)
-                const int64_t dr = (int64_t)(ri - xj);
-                const int dq = qi - (int)yj;
-                const int sidj = (int)(yj >> 48 & 0xff);
-                const bool same = sidi == sidj;
-                bool skip = !valid || (same && dr == 0) || dq <= 0;
-                skip = skip || (same && dq > max_dist_y) || dq > max_dist_x;
-                const int dd = (int)(dr > dq ? dr - dq : dq - dr);
-                skip = skip || (same && dd > bw);
-                skip = skip || (n_segs > 1 && same && dr > max_dist_y);
-                const int min_d = dq < dr ? dq : (int)dr;
-                int sc = min_d > q_span ? q_span : min_d;
-                const int log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
-                const int c_lin = (int)((double)dd * .01 * avg_qspan);
-                int gap_cost = 0;
-                if (!same) {
-                    if (dr == 0) ++sc;
-                    else gap_cost = c_lin < log_dd ? c_lin : log_dd;
-                } else {
-                    gap_cost = c_lin + (log_dd >> 1);
+                int max_f = q_span, max_j = -1, n_skip = 0;
+                bool fenced = false;
+                for (int jhi = i - 1; jhi >= st; jhi -= 64) {
+                    const int j = jhi - lane;
+                    const bool valid = j >= st;
+                    const int jj = valid ? j : st;
+                    uint64_t xj, yj;
+                    int fj, pj, tj;
+                    if (i - (jhi - 63) <= RING) {                         // the whole chunk is inside the ring
+                        const int rs = jj & (RING - 1);
+                        xj = rx[rs]; yj = ry[rs]; fj = rf[rs]; pj = rp[rs]; tj = rt[rs];
+                    } else {
+                        if (!fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); fenced = true; }
+                        xj = x[jj]; yj = y[jj]; fj = f[jj]; pj = p[jj]; tj = t[jj];
+                    }
+                    // ---- phase 1: candidate score / `continue` mask (:59-80)
+                    const int64_t dr = (int64_t)(ri - xj);
+                    const int dq = qi - (int)yj;
+                    const int sidj = (int)(yj >> 48 & 0xff);
+                    const bool same = sidi == sidj;
+                    bool skip = !valid || (same && dr == 0) || dq <= 0;
+                    skip = skip || (same && dq > max_dist_y) || dq > max_dist_x;
+                    const int dd = (int)(dr > dq ? dr - dq : dq - dr);
+                    skip = skip || (same && dd > bw);
+                    skip = skip || (n_segs > 1 && same && dr > max_dist_y);
+                    const int min_d = dq < dr ? dq : (int)dr;
+                    int sc = min_d > q_span ? q_span : min_d;
+                    const int log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
+                    const int c_lin = (int)((double)dd * .01 * avg_qspan);
+                    int gap_cost = 0;
+                    if (!same) {
+                        if (dr == 0) ++sc;
+                        else gap_cost = c_lin < log_dd ? c_lin : log_dd;
+                    } else {
+                        gap_cost = c_lin + (log_dd >> 1);
+                    }
+                    // (int)((double)gap_cost * gap_scale + .499) with gap_scale = 1.0f is gap_cost itself unless it is negative
+                    sc -= gap_cost >= 0 ? gap_cost : (int)((double)gap_cost * 1.0 + .499);
+                    sc += fj;
+                    // ---- phase 2: was this j already marked as a parent during this i? (:84)
+                    mark[lane] = 0;
+                    const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
+                    if (!skip && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
+                    const bool hit = (tj == i) || mark[lane] != 0;
+                    // ---- phase 3: ordered max_f / n_skip / break (:81-88)
+                    const unsigned cand = skip ? 0u : (unsigned)sc + UBIAS;      // biased: 0 = "no candidate"
+                    const unsigned pm = wave_scan_umax(cand);                     // inclusive prefix max of candidates
+                    unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);             // exclusive (wave_shr:1)
+                    pmx = lane == 0 ? 0u : pmx;
+                    const bool improving = !skip && cand > max((unsigned)max_f + UBIAS, pmx);
+                    const bool bump = !skip && !improving && hit;
+                    const int d = improving ? -1 : (bump ? 1 : 0);
+                    const int S = n_skip + wave_scan_add(d);
+                    // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
+                    const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
+                    const int mn = -(int)(mx - UBIAS);
+                    const int nl = S - min(0, mn);
+                    const unsigned long long brk = __ballot(bump && nl > max_skip);
+                    const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
+                    const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
+                    visited += __builtin_popcountll(__ballot(valid) & (bl >= 63 ? ~0ull : ((2ull << bl) - 1)));
+                    const unsigned long long imp = __ballot(improving) & before;
+                    if (imp) {
+                        const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
+                        max_j = jhi - li;
+                        max_f = __builtin_amdgcn_readlane(sc, li);
+                    }
+                    // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89)
+                    if (!skip && pj >= 0 && lane < bl) {
+                        t[pj] = i;
+                        if (i - pj <= RING) rt[pj & (RING - 1)] = i;
+                    }
+                    if (bl < 64) break;
+                    n_skip = __builtin_amdgcn_readlane(nl, 63);
+                    fenced = false;                               // later deep chunks must see these target stores
                 }
-                sc -= (int)((double)gap_cost * 1.0 + .499);
-                sc += fj;
-                // ---- phase 2: was this j already marked as a parent during this i? (:84)
-                mark[lane] = 0;
-                const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
-                if (!skip && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
-                const bool hit = (tj == i) || mark[lane] != 0;
-                // ---- phase 3: ordered max_f / n_skip / break (:81-88)
-                const int cand = skip ? NEGI : sc;
-                int pm = wave_scan<OpMax>(cand);               // inclusive prefix max of candidates
-                int pmx = dppi<0x138>(NEGI, pm);               // exclusive (wave_shr:1)
-                pmx = lane == 0 ? NEGI : pmx;
-                const bool improving = !skip && sc > max(max_f, pmx);
-                const bool bump = !skip && !improving && hit;
-                const int d = improving ? -1 : (bump ? 1 : 0);
-                const int S = n_skip + wave_scan<OpAdd>(d);
-                const int mn = wave_scan<OpMin>(S);
-                const int nl = S - min(0, mn);                 // n_skip after this lane (walk reflected at 0)
-                const unsigned long long brk = __ballot(bump && nl > max_skip);
-                const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
-                const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
-                visited += __builtin_popcountll(__ballot(valid) & (bl >= 63 ? ~0ull : ((2ull << bl) - 1)));
-                const unsigned long long imp = __ballot(improving) & before;
-                if (imp) {
-                    const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
-                    max_j = jhi - li;
-                    max_f = __builtin_amdgcn_readlane(sc, li);
+                // :91-92, to the outputs and to the ring
+                int pkj = 0;
+                if (max_j >= 0) {
+                    if (i - max_j <= RING) pkj = rk[max_j & (RING - 1)];
+                    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); pkj = pk[max_j]; }
                 }
-                // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89)
-                if (!skip && pj >= 0 && lane < bl) t[pj] = i;
-                if (bl < 64) break;
-                n_skip = __builtin_amdgcn_readlane(nl, 63);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
+                if (lane == 0) {
+                    f[i] = max_f; p[i] = max_j; pk[i] = pki;
+                    const int rs = i & (RING - 1);
+                    rx[rs] = ri; ry[rs] = yi; rf[rs] = max_f; rp[rs] = max_j; rt[rs] = 0; rk[rs] = pki;
+                }
             }
-            if (lane == 0) {                                  // :91-92
-                f[i] = max_f;
-                p[i] = max_j;
-                const int pkj = max_j >= 0 ? pk[max_j] : 0;
-                pk[i] = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         }
         if (lane == 0) atomicAdd(W.evaluated, visited);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
 }
 
