@@ -268,6 +268,10 @@ def main():
         k_ms = ms_sum / max(launches, 1)
         alg_bytes, k_units = work.roofline_bytes(name)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes (default sizes only)
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if not args.size and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"].get(name)
         cfg = {"workload": work.workload,
                "parallelism": "units sharded over %d rank(s), no data-path collective" % world}
         cfg.update(work.extra)
@@ -277,7 +281,7 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
             "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
