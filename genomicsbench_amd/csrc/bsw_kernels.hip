@@ -22,6 +22,7 @@
 // tests): cells right of the live window are either never written (first-row
 // initial values, E=0) or hold zeros; cells left of it are never read again.
 #include "gbx_internal.h"
+#include <cstdlib>
 
 namespace gbx {
 namespace {
@@ -29,7 +30,7 @@ namespace {
 constexpr int NEG = -(1 << 29);
 constexpr int BIGJ = 1 << 20;
 
-// qlen classes -> kernel shapes: classes 0..10 = (LPP 16, CPL 1,2,3,4,5,6,7,8,10,12,16), 11 = (64,16), 12 = LDS kernel
+// qlen classes: 0..7 = qlen <= 16,32,..,128; 8..10 = <= 160,192,256; 11 = <= 1024; 12 = LDS kernel (shapes: class_shapes())
 constexpr int NCLS = 13;
 constexpr int NTB = 32;                     // target-length buckets per class (width 16), longest first
 constexpr int NBIN = NCLS * NTB;            // 416 bins: pairs are binned by (class, descending target length)
@@ -48,11 +49,11 @@ struct BswPairs {
     gbx_bsw_result *out;
 };
 
-// workspace layout (ints): counts[512] | cursors[512] | base[512] (exclusive prefix of counts) | misc[512] | order[n]
-//   misc[0] = bad-pair count
+// workspace layout (ints): counts[512] | cursors[512] | base[512] (exclusive prefix of counts) | misc[512] | order[n] | wband[n]
+//   misc[0] = bad-pair count; order[] = pair indices binned by (class, target length), wband[] = their clamped band width
 constexpr int WS_HDR = 2048;
 struct BswWork {
-    int32_t *counts, *cursors, *base, *bad, *order;
+    int32_t *counts, *cursors, *base, *bad, *order, *wband;
 };
 
 __host__ __device__ inline int cls_of(int qlen, int bound)
@@ -70,15 +71,17 @@ __host__ __device__ inline int bin_of(int cls, int tlen)
 
 __device__ inline int imax3(int a, int b, int c) { return max(max(a, b), c); }
 
-template <int CTRL, int ROWMASK = 0xf>
+template <int CTRL, int ROWMASK = 0xf, int BANKMASK = 0xf>
 __device__ inline int dpp(int old, int x)
 {
-    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xf, false);
+    return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, BANKMASK, false);
 }
 
 // ---- group primitives -----------------------------------------------------
+// A group is LPP consecutive lanes (4, 8, 16 or 64) that own one pair.
 // mov_dpp with an undefined `old` and bound_ctrl:1 (out-of-row lanes read 0) lets the compiler fold the
-// move into the consumer (v_max_i32_dpp): one VALU op per scan / reduce step.
+// move into the consumer (v_max_i32_dpp): one VALU op per scan / reduce step.  max is idempotent, so a
+// lane that reads itself (quad_perm patterns below) is harmless.
 template <int CTRL, int ROWMASK = 0xf>
 __device__ inline int dppz(int x)
 {
@@ -89,6 +92,15 @@ __device__ inline int dppz(int x)
 template <int LPP>
 __device__ inline int group_scan_max(int x)
 {
+    if (LPP <= 8) {
+        x = max(x, dppz<0x90>(x));                        // quad_perm [0,0,1,2]
+        x = max(x, dppz<0x40>(x));                        // quad_perm [0,0,0,1]: prefix inside each quad
+        if (LPP == 8) {
+            const int tot = dppz<0xff>(x);                // quad total in every lane of the quad
+            x = max(x, dpp<0x114, 0xf, 0xa>(0, tot));     // row_shr:4 into the odd quads only
+        }
+        return x;
+    }
     x = max(x, dppz<0x111>(x));
     x = max(x, dppz<0x112>(x));
     x = max(x, dppz<0x114>(x));
@@ -103,6 +115,7 @@ template <int LPP>
 __device__ inline int group_shift_up(int x, int fill, int gl)
 {
     if (LPP == 16) return dpp<0x111>(fill, x);            // row_shr:1, old = fill
+    if (LPP < 16) { const int y = dpp<0x111>(fill, x); return gl == 0 ? fill : y; }
     int y = dpp<0x138>(fill, x);                          // wave_shr:1
     return gl == 0 ? fill : y;
 }
@@ -111,6 +124,12 @@ __device__ inline int group_shift_up(int x, int fill, int gl)
 template <int LPP>
 __device__ inline int group_allmax(int x)
 {
+    if (LPP <= 8) {
+        x = max(x, dppz<0xb1>(x));                        // quad_perm [1,0,3,2]
+        x = max(x, dppz<0x4e>(x));                        // quad_perm [2,3,0,1]
+        if (LPP == 8) x = max(x, dppz<0x141>(x));         // row_half_mirror
+        return x;
+    }
     if (LPP == 16) {
         x = max(x, dppz<0x121>(x));                       // row_ror:1,2,4,8 (every lane has a source)
         x = max(x, dppz<0x122>(x));
@@ -123,12 +142,18 @@ __device__ inline int group_allmax(int x)
     x = max(x, dpp<0x114>(x, x));
     x = max(x, dpp<0x118>(x, x));
     x = max(x, dpp<0x142, 0xa>(x, x));
-    if (LPP == 32) {
-        int a = __builtin_amdgcn_readlane(x, 31), b = __builtin_amdgcn_readlane(x, 63);
-        return (threadIdx.x & 32) ? b : a;
-    }
     x = max(x, dpp<0x143, 0xc>(x, x));
     return __builtin_amdgcn_readlane(x, 63);
+}
+
+// band clamp of scalarBandedSWA (:159-168) in integers: (int)((double)n / e + 1.) clipped below at 1
+__device__ inline int band_width(const BswDev &prm, int qlen)
+{
+    const int n_ins = qlen * prm.max_mat + prm.end_bonus - prm.o_ins;
+    const int n_del = qlen * prm.max_mat + prm.end_bonus - prm.o_del;
+    const int l_ins = n_ins >= 0 ? n_ins / prm.e_ins + 1 : 1;
+    const int l_del = n_del >= 0 ? n_del / prm.e_del + 1 : 1;
+    return min(prm.w, min(l_ins, l_del));
 }
 
 // ---- classify / bin pairs by (query-length class, descending target length) ----------------
@@ -178,7 +203,10 @@ __global__ void __launch_bounds__(CLS_THREADS) bsw_classify_kernel(BswDev prm, B
     for (int b = tid; b < NBIN; b += CLS_THREADS)
         lbase[b] = lcount[b] ? W.base[b] + atomicAdd(&W.cursors[b], lcount[b]) : 0;
     __syncthreads();
-    if (bin >= 0) W.order[lbase[bin] + slot] = (int)k;
+    if (bin >= 0) {
+        W.order[lbase[bin] + slot] = (int)k;
+        W.wband[lbase[bin] + slot] = band_width(prm, P.len2[k]);
+    }
 }
 
 // exclusive prefix of the bin counts (one block)
@@ -199,15 +227,21 @@ __global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
 }
 
 // ---- register-resident row kernel ------------------------------------------
-template <int LPP, int CPL>
+// SYM: o_ins+e_ins == o_del+e_del, the gap-open term of E and F is shared.
+template <int LPP, int CPL, bool SYM>
 __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
 {
     constexpr int KB = 10;                       // bits for the column index in the row key
     constexpr int GROUPS_PER_BLOCK = 256 / LPP;
+    constexpr int NQ = (CPL + 7) / 8;            // query codes, 4 bits each (only read for ambiguous target bases)
     static_assert(LPP * CPL <= (1 << KB), "column index must fit the key");
     static_assert(CPL <= 16, "in-lane column index uses 4 bits");
 
+    __shared__ uint32_t s_colword[8];
     const int tid = threadIdx.x;
+    if (tid < 8) s_colword[tid] = prm.colword[min(tid, 4)];
+    __syncthreads();
+
     const int gl = tid & (LPP - 1);
     const int j0 = gl * CPL;
     const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
@@ -216,25 +250,30 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
     const int first = W.base[cls * NTB];
     const int cnt = W.base[(cls + 1) * NTB] - first;
     const int32_t *order = W.order + first;
+    const int32_t *wband = W.wband + first;
 
     const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
     const int lane_tilt = gl * (CPL * e_ins);
 
-    int Hs[CPL], Ev[CPL], P4[CPL];
-    uint32_t Pw[CPL];
+    int Hs[CPL + 1], Ev[CPL];
+    uint32_t Pw[CPL], Qp[NQ];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { Hs[c] = 0; Ev[c] = 0; P4[c] = 0; Pw[c] = 0; }
+    for (int c = 0; c < CPL; ++c) { Hs[c] = 0; Ev[c] = 0; Pw[c] = 0; }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) Qp[c] = 0;
 
-    // group-uniform state (replicated in every lane of the group)
-    int qlen = 1, tlen = 1, h0 = 0, w = 0, beg = 0, end = 0, i = 0, pair = 0;
+    // group-uniform state (replicated in every lane of the group); g_i / g_score are only
+    // meaningful in lane lq, the lane that owns column qlen-1, which also writes the result
+    int qlen = 1, tlen = 1, w = 0, beg = 0, end = 0, i = 0, pair = 0, lq = 0;
     int best = 0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
+    int leftv = 0;                               // h0 - (o_del + e_del*(i+1)), :183-186
     const uint8_t *tptr = P.ref;
     int tcur = 0, tnext = 0;
     bool active = false, done = false;
 
     for (;;) {
         if (done) {                                                   // retire
-            if (gl == 0) {
+            if (gl == lq) {
                 gbx_bsw_result r;
                 r.score = best; r.tle = best_i + 1; r.gtle = g_i + 1; r.qle = best_j + 1;
                 r.gscore = g_score; r.max_off = off;
@@ -245,32 +284,26 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         }
         if (!active && next < cnt) {                                  // fetch + first row (:155-168)
             pair = order[next];
+            w = wband[next];
             next += ngroups;
-            qlen = P.len2[pair]; tlen = P.len1[pair]; h0 = P.h0[pair];
+            qlen = P.len2[pair]; tlen = P.len1[pair];
+            const int h0 = P.h0[pair];
             const uint8_t *q = P.qer + P.idq[pair];
             tptr = P.ref + P.idr[pair];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) Qp[c] = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = j0 + c;
                 int qc = j < qlen ? q[j] : 0;
                 qc = min(qc, 4);
-                uint32_t pw = prm.colword[0]; int p4 = prm.col4[0];
-                pw = qc == 1 ? prm.colword[1] : pw; p4 = qc == 1 ? prm.col4[1] : p4;
-                pw = qc == 2 ? prm.colword[2] : pw; p4 = qc == 2 ? prm.col4[2] : p4;
-                pw = qc == 3 ? prm.colword[3] : pw; p4 = qc == 3 ? prm.col4[3] : p4;
-                pw = qc == 4 ? prm.colword[4] : pw; p4 = qc == 4 ? prm.col4[4] : p4;
-                Pw[c] = pw; P4[c] = p4;
+                Pw[c] = s_colword[qc];
+                Qp[c >> 3] |= (uint32_t)qc << ((c & 7) * 4);
                 Hs[c] = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
                 Ev[c] = 0;
             }
-            {   // band clamp, :159-168
-                int lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_ins) / (double)e_ins + 1.);
-                lim = max(lim, 1);
-                w = min(prm.w, lim);
-                lim = (int)((double)(qlen * prm.max_mat + prm.end_bonus - prm.o_del) / (double)e_del + 1.);
-                lim = max(lim, 1);
-                w = min(w, lim);
-            }
+            lq = (qlen - 1) / CPL;
+            leftv = h0 - prm.o_del - e_del;
             best = h0; best_i = -1; best_j = -1; g_i = -1; g_score = -1; off = 0;
             beg = 0; end = qlen; i = 0;
             tcur = tptr[0];
@@ -282,7 +315,8 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         // ------------------------------------------------------------ one row
         const int b = max(beg, i - w);                                 // :179-181
         const int e = min(min(end, i + w + 1), qlen);
-        const int left0 = b == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;   // :183-186
+        const int left0 = b == 0 ? max(leftv, 0) : 0;                  // :183-186
+        leftv -= e_del;
         const int lo = b - j0, hi = e - j0;
         const int t = min(tcur, 4);
         tcur = tnext;
@@ -290,52 +324,61 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         const int t8 = t << 3;
         const bool t4 = t == 4;
 
-        int M[CPL], Ein[CPL], Fl[CPL], Hc[CPL], sv[CPL];
+        int G[CPL], sv[CPL];
         if (__any(t4)) {                                                // an ambiguous target base somewhere in the wave
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) sv[c] = t4 ? P4[c] : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+            for (int c = 0; c < CPL; ++c) {
+                const int qc = (int)((Qp[c >> 3] >> ((c & 7) * 4)) & 7u);
+                int p4 = prm.col4[0];
+                p4 = qc == 1 ? prm.col4[1] : p4; p4 = qc == 2 ? prm.col4[2] : p4;
+                p4 = qc == 3 ? prm.col4[3] : p4; p4 = qc == 4 ? prm.col4[4] : p4;
+                sv[c] = t4 ? p4 : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) sv[c] = __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
         }
+        // previous-row terms.  G = max(M, E, in-lane part of F); the cross-lane F is folded in below.
         int lf = NEG;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const bool p = (c >= lo) & (c < hi);
-            const int s = sv[c];
             const int hsv = Hs[c];
-            const int m = (p & (hsv != 0)) ? hsv + s : 0;              // :196
+            const int m = (p & (hsv != 0)) ? hsv + sv[c] : 0;          // :196
             const int ein = p ? Ev[c] : 0;
-            M[c] = m; Ein[c] = ein; Fl[c] = lf;
-            lf = imax3(lf - e_ins, m - oe_ins, 0);                     // F(i,j+1), :207-210
-            Ev[c] = imax3(ein - e_del, m - oe_del, 0);                 // E(i+1,j), :202-206
+            G[c] = imax3(m, ein, lf);                                  // :197-198 without the carried F
+            const int mo = m - oe_ins;
+            lf = imax3(lf - e_ins, mo, 0);                             // F(i,j+1), :207-210
+            Ev[c] = imax3(ein - e_del, SYM ? mo : m - oe_del, 0);      // E(i+1,j), :202-206
         }
         // cross-lane part of the F scan: carry-out of lane l, tilted by l*CPL*e_ins
-        int carry = group_scan_max<LPP>(lf + lane_tilt) - lane_tilt;
+        const int carry = group_scan_max<LPP>(lf + lane_tilt) - lane_tilt;
         int X = group_shift_up<LPP>(carry, NEG, gl);                   // F entering this lane's column 0
 
+        // h, the row key (last arg-max) and the shifted store eh[j+1].h <- H(i,j) for j < e
         int kl = 0, hl = 0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int f = max(Fl[c], X);
+            int h = max(G[c], X);
             X -= e_ins;
-            int h = imax3(M[c], Ein[c], f);                            // :197-198
             const bool pr = c < hi;
+            Hs[c + 1] = pr ? h : Hs[c + 1];
             hl = pr ? h : hl;                                          // h of the last live column in this lane
             h = pr ? h : 0;
-            Hc[c] = h;
+            G[c] = h;
             kl = max(kl, (h << 4) | c);
         }
-        // shifted store: eh[j].h <- H(i,j-1); column 0 takes the first-column value
-        const int hin = group_shift_up<LPP>(Hc[CPL - 1], left0, gl);
+        // column 0 takes the previous lane's last h; the pair's column 0 takes the first-column value
+        const int hin = group_shift_up<LPP>(G[CPL - 1], left0, gl);
+        Hs[0] = hi >= 0 ? hin : Hs[0];
         unsigned zm = 0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int hs = c == 0 ? hin : Hc[c - 1];
+            const int hs = c == 0 ? hin : G[c - 1];
             const unsigned nz = min((unsigned)(hs | Ev[c]), 1u);
             zm |= nz << c;
-            Hs[c] = (c <= hi) ? hs : Hs[c];
         }
+        Hs[CPL] = 0;                                                   // column (gl+1)*CPL lives in the next lane
 
         // group reductions
         const int key = group_allmax<LPP>(((kl >> 4) << KB) | (j0 + (kl & 15)));
@@ -344,28 +387,24 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         const int zl_l = zm ? j0 + (31 - __builtin_clz(zm)) : -1;
         const int zfirst = BIGJ - group_allmax<LPP>(BIGJ - zf_l);
         const int zlast = group_allmax<LPP>(zl_l);
-        const int le = (e - 1) / CPL;                                  // lane holding column e-1 (e>=1 when b<e)
-        const int hsel = group_allmax<LPP>(gl == le ? hl : 0);
 
-        // row epilogue, :213-233
+        // row epilogue, :213-233, branch-free
         const bool live = b < e;
         const int jfin = live ? e : b;
-        const int hend = live ? hsel : left0;
-        if (jfin == qlen) {                                            // :214-217
-            g_i = g_score > hend ? g_i : i;
-            g_score = max(g_score, hend);
-        }
-        bool brk = m == 0;                                             // :218
-        if (!brk) {
-            if (m > best) {                                            // :219-221
-                best = m; best_i = i; best_j = mj;
-                off = max(off, abs(mj - i));
-            } else if (prm.zdrop > 0) {                                // :222-228
-                const int di = i - best_i, dj = mj - best_j;
-                const int pen = di > dj ? (di - dj) * e_del : (dj - di) * e_ins;
-                brk = best - m - pen > prm.zdrop;
-            }
-        }
+        const int hend = live ? hl : left0;                            // = H(i,e-1) in lane lq when e == qlen
+        const bool gq = jfin == qlen;                                  // :214-217
+        g_i = (gq & (hend >= g_score)) ? i : g_i;
+        g_score = gq ? max(g_score, hend) : g_score;
+        const bool upd = (m > best) & (m != 0);                        // :218-221
+        const int dd = (i - best_i) - (mj - best_j);                   // :222-228
+        const int pen = max(__mul24(dd, e_del), __mul24(-dd, e_ins));
+        const bool zbrk = (prm.zdrop > 0) & !upd & (best - m - pen > prm.zdrop);
+        const bool brk = (m == 0) | zbrk;
+        const int dmi = mj - i;
+        off = upd ? imax3(off, dmi, -dmi) : off;
+        best_i = upd ? i : best_i;
+        best_j = upd ? mj : best_j;
+        best = upd ? m : best;
         beg = min(zfirst, e);                                          // :230-233
         end = min(zlast + 2, qlen);
         ++i;
@@ -493,6 +532,54 @@ __global__ void __launch_bounds__(64) bsw_lds_kernel(BswDev prm, BswPairs P, Bsw
     }
 }
 
+// ---- kernel shapes ----------------------------------------------------------
+// class c (query length) -> (lanes per pair, columns per lane).  Short queries use narrow groups:
+// the per-row fixed cost (scan, reductions, epilogue) is paid once per wavefront row, so 16 pairs per
+// wavefront amortise it 4x better than 4 pairs; the width is bounded by the registers CPL columns need.
+struct RowShape { int lpp, cpl; };
+typedef void (*RowsFn)(BswDev, BswPairs, BswWork, int);
+struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
+#define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
+RowKernel row_kernels[] = {
+    GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(4, 16),
+    GBX_ROW_KERNEL(8, 2),  GBX_ROW_KERNEL(8, 4),  GBX_ROW_KERNEL(8, 6),  GBX_ROW_KERNEL(8, 8),
+    GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12), GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 16),
+    GBX_ROW_KERNEL(16, 1), GBX_ROW_KERNEL(16, 2), GBX_ROW_KERNEL(16, 3), GBX_ROW_KERNEL(16, 4),
+    GBX_ROW_KERNEL(16, 5), GBX_ROW_KERNEL(16, 6), GBX_ROW_KERNEL(16, 7), GBX_ROW_KERNEL(16, 8),
+    GBX_ROW_KERNEL(16, 10), GBX_ROW_KERNEL(16, 12), GBX_ROW_KERNEL(16, 16), GBX_ROW_KERNEL(64, 16),
+};
+#undef GBX_ROW_KERNEL
+// widest query a class holds: classes 0..7 = 16,32,..,128; 8..11 = 160,192,256,1024
+constexpr int class_qmax[NCLS - 1] = {16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 1024};
+
+RowKernel *find_row_kernel(int lpp, int cpl)
+{
+    for (RowKernel &k : row_kernels)
+        if (k.lpp == lpp && k.cpl == cpl) return &k;
+    return nullptr;
+}
+
+// GBX_BSW_SHAPES="4x4,4x8,..." (12 entries) overrides the table; a tuning aid, entries that do not
+// cover their class or have no kernel are ignored.
+const RowShape *class_shapes()
+{
+    static RowShape shapes[NCLS - 1] = {{4, 4}, {4, 8}, {4, 12}, {4, 16}, {8, 10}, {8, 12}, {8, 14}, {8, 16},
+                                        {16, 10}, {16, 12}, {16, 16}, {64, 16}};
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        const char *e = getenv("GBX_BSW_SHAPES");
+        for (int c = 0; e && *e && c < NCLS - 1; ++c) {
+            int l = 0, k = 0, used = 0;
+            if (sscanf(e, "%dx%d%n", &l, &k, &used) != 2) break;
+            if (find_row_kernel(l, k) && l * k >= class_qmax[c]) shapes[c] = {l, k};
+            e += used;
+            if (*e == ',') ++e;
+        }
+    }
+    return shapes;
+}
+
 int make_dev_params(const gbx_bsw_params *p, BswDev *d)
 {
     if (p->e_del < 1 || p->e_ins < 1 || p->o_del < 0 || p->o_ins < 0 || p->e_del > 4096 || p->e_ins > 4096 ||
@@ -519,7 +606,7 @@ int make_dev_params(const gbx_bsw_params *p, BswDev *d)
 
 size_t bsw_workspace_bytes(int64_t n)
 {
-    return (size_t)(WS_HDR + (n > 0 ? n : 0)) * sizeof(int32_t);
+    return (size_t)(WS_HDR + 2 * (n > 0 ? n : 0)) * sizeof(int32_t);
 }
 
 int bsw_launch(const gbx_bsw_params *p, int64_t n,
@@ -536,7 +623,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     if (rc) return rc;
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
     int32_t *wi = (int32_t *)d_work;
-    BswWork W = {wi, wi + 512, wi + 1024, wi + 1536, wi + WS_HDR};
+    BswWork W = {wi, wi + 512, wi + 1024, wi + 1536, wi + WS_HDR, wi + WS_HDR + n};
     GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s));
     const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
@@ -557,23 +644,22 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     };
     // the grid is the number of blocks that are resident at once (occupancy query), so that the static
     // round-robin over the longest-first list starts every group on the longest pairs together
-#define GBX_ROWS(CPL_, BPC_, CLS_)                                                                                         \
-    {                                                                                                                      \
-        static int bpc = 0;                                                                                                \
-        if (!bpc) {                                                                                                        \
-            int q = 0;                                                                                                     \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, bsw_rows_kernel<16, CPL_>, 256, 0) != hipSuccess || q < 1) { \
-                (void)hipGetLastError(); q = BPC_;                                                                         \
-            }                                                                                                              \
-            bpc = q > 8 ? 8 : q;                                                                                           \
-        }                                                                                                                  \
-        Stage st("bsw_rows_16x" #CPL_, s);                                                                                 \
-        hipLaunchKernelGGL((bsw_rows_kernel<16, CPL_>), dim3(grid_for(16, bpc)), dim3(256), 0, s, dev, P, W, CLS_);        \
+    const bool sym = dev.oe_ins == dev.oe_del;
+    const RowShape *shapes = class_shapes();
+    for (int c = 0; c < NCLS - 1; ++c) {
+        RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
+        if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
+        if (!k->bpc[sym]) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k->fn[sym], 256, 0) != hipSuccess || q < 1) {
+                (void)hipGetLastError();
+                q = 2;
+            }
+            k->bpc[sym] = q > 8 ? 8 : q;
+        }
+        Stage st(k->name, s);
+        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, s, dev, P, W, c);
     }
-    GBX_ROWS(1, 8, 0) GBX_ROWS(2, 8, 1) GBX_ROWS(3, 8, 2) GBX_ROWS(4, 8, 3) GBX_ROWS(5, 6, 4) GBX_ROWS(6, 6, 5)
-    GBX_ROWS(7, 6, 6) GBX_ROWS(8, 6, 7) GBX_ROWS(10, 4, 8) GBX_ROWS(12, 4, 9) GBX_ROWS(16, 3, 10)
-#undef GBX_ROWS
-    { Stage st("bsw_rows_64x16", s); hipLaunchKernelGGL((bsw_rows_kernel<64, 16>), dim3(grid_for(4, 3)), dim3(256), 0, s, dev, P, W, 11); }
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         static bool attr_set = false;
