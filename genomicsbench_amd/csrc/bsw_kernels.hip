@@ -40,6 +40,8 @@ struct BswDev {
     int o_del, e_del, o_ins, e_ins, oe_del, oe_ins, zdrop, end_bonus, w, max_mat;
     uint32_t colword[5];   // colword[q] = bytes mat[0][q], mat[1][q], mat[2][q], mat[3][q]
     int32_t col4[5];       // col4[q]    = mat[4][q]
+    uint32_t row0[5];      // row0[t]    = bytes mat[t][0], mat[t][1], mat[t][2], mat[t][3]
+    uint32_t row1[5];      // row1[t]    = byte  mat[t][4]
 };
 
 struct BswPairs {
@@ -228,18 +230,23 @@ __global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
 
 // ---- register-resident row kernel ------------------------------------------
 // SYM: o_ins+e_ins == o_del+e_del, the gap-open term of E and F is shared.
+// the register budget is pinned per CPL (second launch-bound = wavefronts per SIMD) so that the wide
+// shapes keep 4 wavefronts per SIMD resident
+constexpr int rows_min_waves(int cpl) { return cpl >= 12 ? 4 : cpl >= 9 ? 5 : cpl >= 7 ? 6 : cpl >= 5 ? 7 : 1; }
+
 template <int LPP, int CPL, bool SYM>
-__global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
+__global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
 {
     constexpr int KB = 10;                       // bits for the column index in the row key
     constexpr int GROUPS_PER_BLOCK = 256 / LPP;
-    constexpr int NQ = (CPL + 7) / 8;            // query codes, 4 bits each (only read for ambiguous target bases)
+    constexpr int NQ = (CPL + 3) / 4;            // query codes, one byte per column: selectors of v_perm_b32
     static_assert(LPP * CPL <= (1 << KB), "column index must fit the key");
     static_assert(CPL <= 16, "in-lane column index uses 4 bits");
 
-    __shared__ uint32_t s_colword[8];
+    // scoring-matrix row of the current target base: 5 signed bytes {row0 = q 0..3, row1 = q 4}
+    __shared__ uint2 s_row[8];
     const int tid = threadIdx.x;
-    if (tid < 8) s_colword[tid] = prm.colword[min(tid, 4)];
+    if (tid < 8) s_row[tid] = make_uint2(prm.row0[min(tid, 4)], prm.row1[min(tid, 4)]);
     __syncthreads();
 
     const int gl = tid & (LPP - 1);
@@ -256,9 +263,9 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
     const int lane_tilt = gl * (CPL * e_ins);
 
     int Hs[CPL + 1], Ev[CPL];
-    uint32_t Pw[CPL], Qp[NQ];
+    uint32_t Qp[NQ];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { Hs[c] = 0; Ev[c] = 0; Pw[c] = 0; }
+    for (int c = 0; c < CPL; ++c) { Hs[c] = 0; Ev[c] = 0; }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) Qp[c] = 0;
 
@@ -268,7 +275,8 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
     int best = 0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
     int leftv = 0;                               // h0 - (o_del + e_del*(i+1)), :183-186
     const uint8_t *tptr = P.ref;
-    int tcur = 0, tnext = 0;
+    uint2 rcur = s_row[0];                       // matrix row of target base i
+    int tnext = 0;                               // target base i+1
     bool active = false, done = false;
 
     for (;;) {
@@ -297,8 +305,7 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
                 const int j = j0 + c;
                 int qc = j < qlen ? q[j] : 0;
                 qc = min(qc, 4);
-                Pw[c] = s_colword[qc];
-                Qp[c >> 3] |= (uint32_t)qc << ((c & 7) * 4);
+                Qp[c >> 2] |= (uint32_t)qc << ((c & 3) * 8);
                 Hs[c] = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
                 Ev[c] = 0;
             }
@@ -306,7 +313,7 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
             leftv = h0 - prm.o_del - e_del;
             best = h0; best_i = -1; best_j = -1; g_i = -1; g_score = -1; off = 0;
             beg = 0; end = qlen; i = 0;
-            tcur = tptr[0];
+            rcur = s_row[min((int)tptr[0], 4)];
             tnext = tptr[min(1, tlen - 1)];
             active = true;
         }
@@ -318,33 +325,22 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
         const int left0 = b == 0 ? max(leftv, 0) : 0;                  // :183-186
         leftv -= e_del;
         const int lo = b - j0, hi = e - j0;
-        const int t = min(tcur, 4);
-        tcur = tnext;
+        // scores of this row: one byte permute per 4 columns picks mat[t][q] by the query code
+        uint32_t sw[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) sw[k] = __builtin_amdgcn_perm(rcur.y, rcur.x, Qp[k]);
+        rcur = s_row[min(tnext, 4)];
         tnext = tptr[min(i + 2, tlen - 1)];
-        const int t8 = t << 3;
-        const bool t4 = t == 4;
 
-        int G[CPL], sv[CPL];
-        if (__any(t4)) {                                                // an ambiguous target base somewhere in the wave
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int qc = (int)((Qp[c >> 3] >> ((c & 7) * 4)) & 7u);
-                int p4 = prm.col4[0];
-                p4 = qc == 1 ? prm.col4[1] : p4; p4 = qc == 2 ? prm.col4[2] : p4;
-                p4 = qc == 3 ? prm.col4[3] : p4; p4 = qc == 4 ? prm.col4[4] : p4;
-                sv[c] = t4 ? p4 : __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) sv[c] = __builtin_amdgcn_sbfe((int)Pw[c], t8, 8);
-        }
+        int G[CPL];
         // previous-row terms.  G = max(M, E, in-lane part of F); the cross-lane F is folded in below.
         int lf = NEG;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const bool p = (c >= lo) & (c < hi);
             const int hsv = Hs[c];
-            const int m = (p & (hsv != 0)) ? hsv + sv[c] : 0;          // :196
+            const int sc = (int)(int8_t)(sw[c >> 2] >> ((c & 3) * 8));
+            const int m = (p & (hsv != 0)) ? hsv + sc : 0;             // :196
             const int ein = p ? Ev[c] : 0;
             G[c] = imax3(m, ein, lf);                                  // :197-198 without the carried F
             const int mo = m - oe_ins;
@@ -375,7 +371,8 @@ __global__ void __launch_bounds__(256) bsw_rows_kernel(BswDev prm, BswPairs P, B
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int hs = c == 0 ? hin : G[c - 1];
-            const unsigned nz = min((unsigned)(hs | Ev[c]), 1u);
+            unsigned nz;                                               // min(x,1); asm keeps it one op (no cmp+select)
+            asm("v_min_u32_e32 %0, 1, %1" : "=v"(nz) : "v"(hs | Ev[c]));
             zm |= nz << c;
         }
         Hs[CPL] = 0;                                                   // column (gl+1)*CPL lives in the next lane
@@ -598,6 +595,12 @@ int make_dev_params(const gbx_bsw_params *p, BswDev *d)
         for (int t = 0; t < 4; ++t) wv |= (uint32_t)(uint8_t)p->mat[t * 5 + q] << (8 * t);
         d->colword[q] = wv;
         d->col4[q] = p->mat[4 * 5 + q];
+    }
+    for (int t = 0; t < 5; ++t) {
+        uint32_t wv = 0;
+        for (int q = 0; q < 4; ++q) wv |= (uint32_t)(uint8_t)p->mat[t * 5 + q] << (8 * q);
+        d->row0[t] = wv;
+        d->row1[t] = (uint32_t)(uint8_t)p->mat[t * 5 + 4];
     }
     return GBX_OK;
 }
