@@ -24,11 +24,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
-# query-length range handled by each bsw row kernel (csrc/bsw_kernels.hip: cls_of)
-BSW_CLASS = {"bsw_rows_16x%d" % c: (lo, hi) for c, lo, hi in
-             [(1, 1, 16), (2, 17, 32), (3, 33, 48), (4, 49, 64), (5, 65, 80), (6, 81, 96), (7, 97, 112),
-              (8, 113, 128), (10, 129, 160), (12, 161, 192), (16, 193, 256)]}
-BSW_CLASS.update({"bsw_rows_64x16": (257, 1024), "bsw_lds": (1025, 1 << 30)})
+# query-length range handled by each bsw row kernel (csrc/bsw_kernels.hip: cls_of / class_shapes; the default
+# shape of a class has lanes x columns == the longest query of the class)
+_BSW_QMAX = [16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 1024]
+_BSW_SHAPE = ["4x4", "4x8", "4x12", "4x16", "8x10", "8x12", "8x14", "8x16", "16x10", "16x12", "16x16", "64x16"]
+BSW_CLASS = {"bsw_rows_" + sh: ((_BSW_QMAX[k - 1] + 1) if k else 1, _BSW_QMAX[k]) for k, sh in enumerate(_BSW_SHAPE)}
+BSW_CLASS["bsw_lds"] = (1025, 1 << 30)
 PHMM_CLASS = {"phmm_f32_rpl1": (1, 64), "phmm_f32_rpl2": (65, 128), "phmm_f32_rpl3": (129, 192),
               "phmm_f32_rpl4": (193, 256), "phmm_f32_rpl6": (257, 384), "phmm_f32_rpl8": (385, 1 << 30)}
 
