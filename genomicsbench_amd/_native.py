@@ -104,10 +104,10 @@ def _declare(L):
         L.gbx_poa_cells.argtypes = [vp, vp, C.POINTER(C.c_int64), vp]
         L.gbx_poa_consensus_device.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp, sz, vp]
     if hasattr(L, "gbx_phmm_forward_host"):
-        L.gbx_phmm_workspace_bytes.argtypes = [i64, C.c_int32]
+        L.gbx_phmm_workspace_bytes.argtypes = [i64, i64, C.c_int32]
         L.gbx_phmm_workspace_bytes.restype = sz
         L.gbx_phmm_forward_host.argtypes = [i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]
-        L.gbx_phmm_forward_device.argtypes = [i64] + [vp] * 12 + [C.c_int32, vp, vp, sz, vp]
+        L.gbx_phmm_forward_device.argtypes = [i64, vp, vp, i64] + [vp] * 10 + [C.c_int32, vp, vp, sz, vp]
     if hasattr(L, "gbx_chain_host"):
         L.gbx_chain_workspace_bytes.argtypes = [i64, i64]
         L.gbx_chain_workspace_bytes.restype = sz

@@ -375,16 +375,19 @@ int gbx_phmm_init(void)
     return phmm_init_tables();
 }
 
-size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int32_t max_hap_len) { return phmm_workspace_bytes(n_pairs, max_hap_len); }
+size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int32_t max_hap_len)
+{
+    return phmm_workspace_bytes(n_pairs, n_reads, max_hap_len);
+}
 
 int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const int32_t *d_pair_hap,
-                            const int64_t *d_read_off, const int32_t *d_read_len,
+                            int64_t n_reads, const int64_t *d_read_off, const int32_t *d_read_len,
                             const uint8_t *d_rs, const uint8_t *d_q, const uint8_t *d_i, const uint8_t *d_d,
                             const uint8_t *d_c,
                             const int64_t *d_hap_off, const int32_t *d_hap_len, const uint8_t *d_hap,
                             int32_t max_hap_len, double *d_out, void *d_work, size_t work_bytes, void *stream)
 {
-    if (n_pairs < 0 || max_hap_len < 0 || max_hap_len > GBX_PHMM_MAX_HAPLEN) {
+    if (n_pairs < 0 || n_reads < 0 || max_hap_len < 0 || max_hap_len > GBX_PHMM_MAX_HAPLEN) {
         set_error("gbx_phmm_forward_device: bad argument");
         return GBX_ERR_ARG;
     }
@@ -396,7 +399,7 @@ int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const i
     }
     int rc = require_device();
     if (rc) return rc;
-    return phmm_launch(n_pairs, d_pair_read, d_pair_hap, d_read_off, d_read_len, d_rs, d_q, d_i, d_d, d_c,
+    return phmm_launch(n_pairs, d_pair_read, d_pair_hap, n_reads, d_read_off, d_read_len, d_rs, d_q, d_i, d_d, d_c,
                        d_hap_off, d_hap_len, d_hap, max_hap_len, d_out, d_work, work_bytes, (hipStream_t)stream);
 }
 
@@ -441,7 +444,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     int rc = require_device();
     if (rc) return rc;
     DevBuf dpr, dph, dro, drl, drs, dq, di, dd, dc, dho, dhl, dh, dout, dw;
-    const size_t wb = phmm_workspace_bytes(n_pairs, max_h);
+    const size_t wb = phmm_workspace_bytes(n_pairs, n_reads, max_h);
     if ((rc = dpr.alloc(n_pairs * 4)) || (rc = dph.alloc(n_pairs * 4)) || (rc = dro.alloc(n_reads * 8)) ||
         (rc = drl.alloc(n_reads * 4)) || (rc = drs.alloc(read_bytes)) || (rc = dq.alloc(read_bytes)) ||
         (rc = di.alloc(read_bytes)) || (rc = dd.alloc(read_bytes)) || (rc = dc.alloc(read_bytes)) ||
@@ -459,7 +462,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         (rc = up(dd, d, read_bytes)) || (rc = up(dc, c, read_bytes)) || (rc = up(dho, hap_off, n_haps * 8)) ||
         (rc = up(dhl, hap_len, n_haps * 4)) || (rc = up(dh, hap, hap_bytes)))
         return rc;
-    rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), dro.as<int64_t>(), drl.as<int32_t>(),
+    rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), n_reads, dro.as<int64_t>(), drl.as<int32_t>(),
                      drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
                      dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb, s);
     if (rc) return rc;

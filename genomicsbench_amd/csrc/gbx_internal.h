@@ -46,11 +46,11 @@ int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s);
 int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s);
 
 // ---- phmm (phmm_kernels.hip)
-size_t phmm_workspace_bytes(int64_t n_pairs, int max_hap_len);
+size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len);
 int phmm_init_tables();
 const float *phmm_host_mm_table_f(int *n);
 int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
-                const int64_t *read_off, const int32_t *read_len,
+                int64_t n_reads, const int64_t *read_off, const int32_t *read_len,
                 const uint8_t *rs, const uint8_t *q, const uint8_t *qi, const uint8_t *qd, const uint8_t *qc,
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
                 double *out, void *d_work, size_t work_bytes, hipStream_t s);

@@ -20,6 +20,15 @@
 // accumulates sum_c M[R][c] + X[R][c].  Reads longer than 64*RPL rows run as
 // several row tiles, the tile's bottom DP row handed to the next tile through
 // a small global scratch row (ping-pong).
+//
+// Reads of up to 248 rows — the case GATK produces — take the *stream* path
+// (phmm_stream_kernel): pairs are grouped by read, the haplotypes of a read are
+// laid end to end in one byte stream (a 0 byte in front of each = DP column 0),
+// and half a wavefront (31 lanes x RPL rows) keeps the read's rows resident
+// while the whole stream flows through: lane l is one column behind lane l-1,
+// so the systolic pipeline fills once per read instead of once per pair, and
+// two reads share a wavefront.  The older one-pair-per-wavefront kernel below
+// serves longer reads and the fp64 redo pass.
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -78,7 +87,38 @@ struct PhmmWork {
     int32_t *dlist;      // [n_pairs] pairs to redo in fp64
     char *scratch;       // TILED_BLOCKS * scratch_stride bytes of tile boundary rows
     int64_t scratch_stride;
+    // stream path (reads of <= STREAM_MAX_ROWS rows), all indexed by read id unless noted
+    int64_t n_reads;
+    int32_t *rcount;     // pairs of the read
+    int32_t *rslen;      // stream symbols of the read: sum (H+1)
+    int32_t *rcur;       // scatter cursor
+    int32_t *rfirst;     // first position of the read's pairs in porder[]
+    int64_t *rsbase;     // byte offset of the read's stream
+    int32_t *porder;     // [n_pairs] pairs grouped by read
+    int64_t *soff;       // [n_pairs] stream offset of the pair's boundary byte (grouped order)
+    float *yin;          // [n_pairs] INITIAL_CONSTANT / haplen (grouped order)
+    float *tmp;          // [n_pairs] fp32 sums (grouped order)
+    int32_t *ucount;     // [UBINS] units (reads) per (row class, stream-length bucket)
+    int32_t *ubase;      // [UBINS+1]
+    int32_t *ulist;      // [n_pairs] units = first grouped pair of a (read, segment), class-major, long streams first
+    uint8_t *stream;
 };
+
+constexpr int STREAM_LANES = 31;                              // row lanes per half-wavefront (lane 31 / 63 stays all-zero)
+constexpr int STREAM_MAX_ROWS = STREAM_LANES * 8;
+constexpr int SEG_MAX_PAIRS = 16;                             // a read's pairs are cut into units of at most this many
+constexpr int UBUCKETS = 32;
+constexpr int UBINS = 8 * UBUCKETS;
+__host__ __device__ inline int unit_bin(int R, int slen)
+{
+    const int cls = (R - 1) / STREAM_LANES;                   // rows per lane - 1
+    const int b = slen >> 9;
+    return cls * UBUCKETS + (UBUCKETS - 1 - (b < UBUCKETS - 1 ? b : UBUCKETS - 1));
+}
+// unit = (read, segment): pairs [seg*q, min(c, seg*q+q)) of the read's c grouped pairs
+__host__ __device__ inline int seg_count(int c) { return (c + SEG_MAX_PAIRS - 1) / SEG_MAX_PAIRS; }
+__host__ __device__ inline int seg_pairs(int c) { const int ns = seg_count(c); return (c + ns - 1) / ns; }
+__host__ __device__ inline int64_t stream_bytes_of(int slen) { return ((int64_t)slen + 1 + 15 + 16) & ~(int64_t)15; }
 
 __device__ inline float shr1(float fill, float x)
 {
@@ -119,6 +159,10 @@ __global__ void __launch_bounds__(256) phmm_classify_kernel(PhmmArgs A, int64_t 
             // cannot produce an empty string).  Empty read: the result row is DP row 0 (M=X=0),
             // log10(0) = -inf; empty haplotype: INITIAL_CONSTANT/0 -> treat the same way.
             if (pass == 0) A.out[k] = -HUGE_VAL;
+        } else if (R <= STREAM_MAX_ROWS) {
+            const int rd = A.pair_read[k];
+            if (pass == 0) { atomicAdd(&W.rcount[rd], 1); atomicAdd(&W.rslen[rd], H + 1); }
+            else W.porder[W.rfirst[rd] + atomicAdd(&W.rcur[rd], 1)] = (int)k;
         } else {
             cls = class_of_rows(R);
             slot = atomicAdd(&lcount[cls], 1);
@@ -298,6 +342,239 @@ __global__ void __launch_bounds__(64) phmm_f64_kernel(PhmmArgs A, PhmmWork W)
     }
 }
 
+// ---- stream path ------------------------------------------------------------
+// One block: exclusive scans over the reads (pair positions, stream byte offsets) and the unit list
+// (reads that own pairs), binned by (row class, stream length) with the longest streams first.
+constexpr int SCAN_THREADS = 1024;
+__global__ void __launch_bounds__(SCAN_THREADS) phmm_read_scan_kernel(PhmmArgs A, PhmmWork W)
+{
+    __shared__ long long part[SCAN_THREADS];
+    __shared__ int partc[SCAN_THREADS];
+    __shared__ int bins[UBINS + 1];
+    __shared__ int bcur[UBINS];
+    const int tid = threadIdx.x;
+    const int64_t n = W.n_reads;
+    const int64_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int64_t lo = min(n, tid * per), hi = min(n, lo + per);
+    for (int b = tid; b <= UBINS; b += SCAN_THREADS) bins[b] = 0;
+    for (int b = tid; b < UBINS; b += SCAN_THREADS) bcur[b] = 0;
+    __syncthreads();
+    long long bytes = 0; int pairs = 0;
+    for (int64_t r = lo; r < hi; ++r) {
+        const int c = W.rcount[r];
+        if (c) {
+            pairs += c; bytes += stream_bytes_of(W.rslen[r]);
+            const int ns = seg_count(c);
+            atomicAdd(&bins[unit_bin(A.read_len[r], W.rslen[r] / ns)], ns);
+        }
+    }
+    part[tid] = bytes; partc[tid] = pairs;
+    __syncthreads();
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+        const long long a = tid >= d ? part[tid - d] : 0;
+        const int ac = tid >= d ? partc[tid - d] : 0;
+        __syncthreads();
+        part[tid] += a; partc[tid] += ac;
+        __syncthreads();
+    }
+    long long boff = part[tid] - bytes; int poff = partc[tid] - pairs;
+    if (tid == 0) {                                            // exclusive scan of the bins (256 entries)
+        int acc = 0;
+        for (int b = 0; b < UBINS; ++b) { const int c = bins[b]; bins[b] = acc; acc += c; }
+        bins[UBINS] = acc;
+    }
+    __syncthreads();
+    for (int b = tid; b <= UBINS; b += SCAN_THREADS) W.ubase[b] = bins[b];
+    if (tid == SCAN_THREADS - 1) W.next[0] = partc[tid];       // pairs on the stream path
+    for (int64_t r = lo; r < hi; ++r) {
+        const int c = W.rcount[r];
+        W.rfirst[r] = poff; W.rsbase[r] = boff;
+        if (c) {
+            const int ns = seg_count(c), q = seg_pairs(c);
+            const int bin = unit_bin(A.read_len[r], W.rslen[r] / ns);
+            const int at = bins[bin] + atomicAdd(&bcur[bin], ns);
+            for (int g = 0; g < ns; ++g) W.ulist[at + g] = poff + g * q;     // first grouped pair of the unit
+            poff += c; boff += stream_bytes_of(W.rslen[r]);
+        }
+    }
+}
+
+// One thread per read: stream offsets and Y[0][*] = INITIAL_CONSTANT / haplen of its pairs, the closing
+// boundary byte and the padding (boundary bytes as well).
+__global__ void __launch_bounds__(256) phmm_unit_walk_kernel(PhmmArgs A, PhmmWork W)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= W.n_reads) return;
+    const int c = W.rcount[r];
+    if (!c) return;
+    const int first = W.rfirst[r];
+    int64_t off = W.rsbase[r];
+    const float init = ldexpf(1.f, 120);
+    for (int j = first; j < first + c; ++j) {
+        const int H = A.hap_len[A.pair_hap[W.porder[j]]];
+        W.soff[j] = off;
+        W.yin[j] = init / (float)H;
+        off += H + 1;
+    }
+    const int64_t end = W.rsbase[r] + stream_bytes_of(W.rslen[r]);
+    for (; off < end; ++off) W.stream[off] = 0;
+}
+
+// One wavefront per grouped pair: boundary byte + haplotype bytes into the read's stream.
+__global__ void __launch_bounds__(256) phmm_stream_copy_kernel(PhmmArgs A, PhmmWork W)
+{
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= W.next[0]) return;
+    const int hp = A.pair_hap[W.porder[j]];
+    const int H = A.hap_len[hp];
+    const uint8_t *src = A.hap + A.hap_off[hp];
+    uint8_t *dst = W.stream + W.soff[j];
+    if (lane == 0) dst[0] = 0;
+    for (int t = lane; t < H; t += 64) dst[1 + t] = src[t];
+}
+
+// Two units per wavefront (lanes 0-30 / 32-62 hold the rows, lanes 31 / 63 stay zero so that nothing leaks
+// from one half into the other through wave_shr), RPL rows per lane, lane l one column behind lane l-1.
+// State of a slot = its (M, X, Y) of the previous column; two copies used alternately (even steps read
+// P and write N, odd steps the reverse), so that "previous column" (left), "previous column of the row
+// above" (diagonal, same copy) and "this column of the row above" (up, the copy being written) are all
+// addressable without register moves.  Across lanes the row above is the previous lane's last slot: its
+// previous-step value is this lane's `up`, its value two steps ago the diagonal (both wave_shr:1).
+// A 0 byte is DP column 0 of the next haplotype: every slot that meets it resets to zero, the lane that
+// owns the last read row emits the finished sum.  Unused slots below the last row (same lane) copy M+X
+// downwards (pMX = pXX = 1), so the sum is always read from slot RPL-1 of that lane.
+template <int RPL>
+__global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W, int cls)
+{
+    const int lane = threadIdx.x, hl = lane & 31, half = lane >> 5;
+    const int ufirst = W.ubase[cls * UBUCKETS];
+    const int ucnt = W.ubase[(cls + 1) * UBUCKETS] - ufirst;
+    const int32_t *ulist = W.ulist + ufirst;
+    const Tab<float> tab(A.tab);
+    const float zero = 0.f, one = 1.f;
+    const bool top = hl == 0;
+
+    for (int slot = blockIdx.x; 2 * slot < ucnt; slot += gridDim.x) {
+        const int ui = 2 * slot + half;
+        const bool have = ui < ucnt;
+        // the unit: `cnt` grouped pairs from `first` on, all of read `rd`
+        const int first = have ? ulist[ui] : 0;
+        const int rd = have ? A.pair_read[W.porder[first]] : 0;
+        const int R = have ? A.read_len[rd] : 0;
+        int cnt = 0;
+        int64_t s_beg = 0, s_end = 0;                           // stream bytes [s_beg, s_end]: s_end = closing boundary
+        if (have) {
+            const int c = W.rcount[rd], r0 = W.rfirst[rd];
+            cnt = min(seg_pairs(c), c - (first - r0));
+            s_beg = W.soff[first];
+            s_end = first + cnt < r0 + c ? W.soff[first + cnt] : W.rsbase[rd] + W.rslen[rd];
+        }
+        const int slen = (int)(s_end - s_beg) + 1;              // symbols including the closing boundary
+        // 4-byte aligned window over the stream: symbol p of the unit is byte p + skew of the words from wp on
+        const int skew = (int)(s_beg & 3);
+        const uint32_t *wp = (const uint32_t *)(W.stream + (s_beg - skew));
+        const int64_t ro = A.read_off[rd];
+        const int llast = R > 0 ? (R - 1) / RPL : 0;
+        const int my_steps = have ? slen + llast : 0;
+        const int steps = max(__builtin_amdgcn_readlane(my_steps, 0), __builtin_amdgcn_readlane(my_steps, 32));
+        const bool is_last = have && hl == llast;
+
+        float pMM[RPL], pGap[RPL], pMX[RPL], pXX[RPL], pMY[RPL], pYY[RPL], pm[RPL], px[RPL];
+        int rch[RPL];
+        float S0[3][RPL], S1[3][RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; ++k) {
+            const int r = hl * RPL + k;
+            const float cp = is_last ? one : zero;               // copy slot: x = up.M + up.X; matches nothing
+            pMM[k] = zero; pGap[k] = zero; pMX[k] = cp; pXX[k] = cp; pMY[k] = zero; pYY[k] = zero;
+            pm[k] = zero; px[k] = zero; rch[k] = 0x100;
+            if (r < R && hl < STREAM_LANES) {
+                const int _i = A.qi[ro + r] & 127, _d = A.qd[ro + r] & 127, _c = A.qc[ro + r] & 127;
+                const int _q = A.q[ro + r] & 127;
+                const int mn = min(_i, _d), mx = max(_i, _d);
+                pMM[k] = tab.mm(((mx * (mx + 1)) >> 1) + mn);
+                pGap[k] = one - tab.ph2pr(_c);
+                pMX[k] = tab.ph2pr(_i); pXX[k] = tab.ph2pr(_c);
+                pMY[k] = tab.ph2pr(_d); pYY[k] = tab.ph2pr(_c);
+                const float e = tab.ph2pr(_q);
+                rch[k] = A.rs[ro + r];
+                pm[k] = one - e;
+                px[k] = rch[k] == 'N' ? one - e : e / 3.f;
+            }
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { S0[v][k] = zero; S1[v][k] = zero; }
+        }
+        int kk = 0;                                            // boundaries this lane has met
+        float ycur = zero, ynext = W.yin[first];
+        float acc = zero;                                      // sum over the columns of the current haplotype (lane llast)
+        int h = 1;                                             // symbol of this lane's column (1: nothing yet, matches nothing)
+        // symbol words: w0 holds the symbols of this group of 4 steps (after the skew shift), w1/w2 the next words
+        uint32_t wa = wp[0], wb = wp[1], wc = wp[2];
+
+        auto step = [&](int sym_in, const float (&P)[3][RPL], float (&N)[3][RPL]) {
+            // the row above slot 0: previous lane's last slot (this column = its previous step, P; the column
+            // before = two steps ago, N before it is overwritten); DP row 0 for the top lane
+            const float uM = shr1(zero, P[0][RPL - 1]), uX = shr1(zero, P[1][RPL - 1]);
+            const float dM = shr1(zero, N[0][RPL - 1]), dX = shr1(zero, N[1][RPL - 1]);
+            float dY = shr1(zero, N[2][RPL - 1]);
+            h = shr1(0, h);
+            if (top) { dY = ycur; h = sym_in; }
+            const bool isb = h == 0;
+            const bool hN = h == 'N';
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) {
+                const float gM = k ? P[0][k - 1] : dM, gX = k ? P[1][k - 1] : dX, gY = k ? P[2][k - 1] : dY;
+                const float aM = k ? N[0][k - 1] : uM, aX = k ? N[1][k - 1] : uX;
+                const float distm = (h == rch[k] || hN) ? pm[k] : px[k];
+                const float m = distm * fmaf(gX + gY, pGap[k], gM * pMM[k]);
+                const float x = fmaf(aM, pMX[k], aX * pXX[k]);
+                const float y = fmaf(P[0][k], pMY[k], P[2][k] * pYY[k]);
+                N[0][k] = m; N[1][k] = x; N[2][k] = y;
+            }
+            if (__any(isb)) {                                   // some lane is at DP column 0 of a haplotype
+                if (isb && is_last && kk >= 1 && kk <= cnt) W.tmp[first + kk - 1] = acc;
+                acc = isb ? zero : acc;
+                ycur = isb ? ynext : ycur;
+                kk += isb ? 1 : 0;
+                if (isb) ynext = W.yin[first + max(0, min(kk, cnt - 1))];
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) {
+                    N[0][k] = isb ? zero : N[0][k]; N[1][k] = isb ? zero : N[1][k]; N[2][k] = isb ? zero : N[2][k];
+                }
+            }
+            acc += N[0][RPL - 1] + N[1][RPL - 1];               // only lane llast's sum is ever read
+        };
+        for (int s = 0; s < steps; s += 4) {
+            // the 4 symbols entering the top lane at steps s..s+3 (0 = boundary beyond the unit's end)
+            const uint32_t w4 = skew ? (uint32_t)(((uint64_t)wb << 32 | wa) >> (8 * skew)) : wa;
+            wa = wb; wb = wc;
+            wc = wp[(s >> 2) + 3];
+            const int s0 = s < slen ? (int)(w4 & 0xff) : 0, s1 = s + 1 < slen ? (int)(w4 >> 8 & 0xff) : 0;
+            const int s2 = s + 2 < slen ? (int)(w4 >> 16 & 0xff) : 0, s3 = s + 3 < slen ? (int)(w4 >> 24) : 0;
+            step(s0, S0, S1);
+            __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: interleaving them only costs registers
+            step(s1, S1, S0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s2, S0, S1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(s3, S1, S0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// fp32 sums of the stream path -> log10 likelihoods, or the fp64 redo list
+__global__ void __launch_bounds__(256) phmm_stream_finish_kernel(PhmmArgs A, PhmmWork W)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= W.next[0]) return;
+    const float r = W.tmp[j];
+    const int pair = W.porder[j];
+    if (r < 1e-28f) W.dlist[atomicAdd(W.dcount, 1)] = pair;                     // MIN_ACCEPTED
+    else A.out[pair] = (double)(log10f(r) - log10f(ldexpf(1.f, 120)));
+}
+
 // ---- host-side tables: GKL Context<NUMBER>::initializeStaticMembers ----
 struct HostTables {
     std::vector<float> ph_f, mm_f;
@@ -381,11 +658,44 @@ size_t scratch_stride_bytes(int max_hap_len)
 
 }  // namespace
 
-size_t phmm_workspace_bytes(int64_t n_pairs, int max_hap_len)
+namespace {
+// workspace carve-up, shared by the size query and the launch
+struct WorkLayout {
+    size_t order, dlist, scratch, rcount, rslen, rcur, rfirst, rsbase, porder, soff, yin, tmp, ucount, ubase, ulist, stream, total;
+};
+WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len)
 {
     if (n_pairs < 0) n_pairs = 0;
+    if (n_reads < 0) n_reads = 0;
     if (max_hap_len < 1) max_hap_len = 1;
-    return 64 * sizeof(int32_t) + (size_t)n_pairs * 2 * sizeof(int32_t) + 64 + (size_t)TILED_BLOCKS * scratch_stride_bytes(max_hap_len);
+    WorkLayout L;
+    size_t off = 64 * sizeof(int32_t);
+    auto take = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 63) & ~(size_t)63; return at; };
+    L.order = take((size_t)n_pairs * 4);
+    L.dlist = take((size_t)n_pairs * 4);
+    L.scratch = take((size_t)TILED_BLOCKS * scratch_stride_bytes(max_hap_len));
+    L.rcount = take((size_t)n_reads * 4);          // rcount | rslen | rcur are zeroed together
+    L.rslen = take((size_t)n_reads * 4);
+    L.rcur = take((size_t)n_reads * 4);
+    L.rfirst = take((size_t)n_reads * 4);
+    L.rsbase = take((size_t)n_reads * 8);
+    L.porder = take((size_t)n_pairs * 4);
+    L.soff = take((size_t)n_pairs * 8);
+    L.yin = take((size_t)(n_pairs + 1) * 4);
+    L.tmp = take((size_t)(n_pairs + 1) * 4);
+    L.ucount = take((size_t)UBINS * 4);
+    L.ubase = take((size_t)(UBINS + 1) * 4);
+    L.ulist = take((size_t)n_pairs * 4);
+    // every pair contributes haplen+1 symbols, every read with pairs < 48 bytes of closing boundary + padding
+    L.stream = take((size_t)n_pairs * ((size_t)max_hap_len + 1) + (size_t)(n_pairs < n_reads ? n_pairs : n_reads) * 48 + 64);
+    L.total = off;
+    return L;
+}
+}  // namespace
+
+size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len)
+{
+    return work_layout(n_pairs, n_reads, max_hap_len).total;
 }
 
 int phmm_init_tables() { DevTables t; return upload_tables(&t); }
@@ -393,40 +703,73 @@ int phmm_init_tables() { DevTables t; return upload_tables(&t); }
 const float *phmm_host_mm_table_f(int *n) { if (n) *n = MM_USED; return host_tables().mm_f.data(); }
 
 int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
-                const int64_t *read_off, const int32_t *read_len,
+                int64_t n_reads, const int64_t *read_off, const int32_t *read_len,
                 const uint8_t *rs, const uint8_t *q, const uint8_t *qi, const uint8_t *qd, const uint8_t *qc,
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
                 double *out, void *d_work, size_t work_bytes, hipStream_t s)
 {
     if (n_pairs == 0) return GBX_OK;
-    if (n_pairs > 0x7fffffffLL - 1024) { set_error("phmm: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
-    if (work_bytes < phmm_workspace_bytes(n_pairs, max_hap_len)) { set_error("phmm: workspace too small"); return GBX_ERR_ARG; }
+    if (n_pairs > 0x7fffffffLL - 1024 || n_reads > 0x7fffffffLL - 1024) {
+        set_error("phmm: more than 2^31 pairs or reads in one call");
+        return GBX_ERR_UNSUPPORTED;
+    }
+    const WorkLayout L = work_layout(n_pairs, n_reads, max_hap_len);
+    if (work_bytes < L.total) { set_error("phmm: workspace too small"); return GBX_ERR_ARG; }
     DevTables tabs;
     int rc = upload_tables(&tabs);
     if (rc) return rc;
     PhmmArgs A = {pair_read, pair_hap, read_off, read_len, rs, q, qi, qd, qc, hap_off, hap_len, hap, out, tabs};
+    char *wb = (char *)d_work;
     int32_t *wi = (int32_t *)d_work;
     PhmmWork W;
     W.counts = wi; W.cursors = wi + 8; W.next = wi + 16; W.dcount = wi + 24;
-    W.order = wi + 64; W.dlist = wi + 64 + n_pairs;
-    size_t off = (64 + (size_t)n_pairs * 2) * sizeof(int32_t);
-    off = (off + 63) & ~(size_t)63;
-    W.scratch = (char *)d_work + off;
+    W.order = (int32_t *)(wb + L.order); W.dlist = (int32_t *)(wb + L.dlist);
+    W.scratch = wb + L.scratch;
     W.scratch_stride = (int64_t)scratch_stride_bytes(max_hap_len);
+    W.n_reads = n_reads;
+    W.rcount = (int32_t *)(wb + L.rcount); W.rslen = (int32_t *)(wb + L.rslen); W.rcur = (int32_t *)(wb + L.rcur);
+    W.rfirst = (int32_t *)(wb + L.rfirst); W.rsbase = (int64_t *)(wb + L.rsbase);
+    W.porder = (int32_t *)(wb + L.porder); W.soff = (int64_t *)(wb + L.soff);
+    W.yin = (float *)(wb + L.yin); W.tmp = (float *)(wb + L.tmp);
+    W.ucount = (int32_t *)(wb + L.ucount); W.ubase = (int32_t *)(wb + L.ubase); W.ulist = (int32_t *)(wb + L.ulist);
+    W.stream = (uint8_t *)(wb + L.stream);
     GBX_HIP(hipMemsetAsync(d_work, 0, 64 * sizeof(int32_t), s));
+    GBX_HIP(hipMemsetAsync(wb + L.rcount, 0, L.rfirst - L.rcount, s));
+    GBX_HIP(hipMemsetAsync(wb + L.yin, 0, 64, s));             // yin[0] is read by idle half-wavefronts
     const int cb = (int)((n_pairs + 255) / 256);
+    const int rb = (int)((n_reads + 255) / 256);
     {
-        Stage st("phmm_classify", s);
+        // group the pairs by read, lay the haplotype streams out
+        Stage st("phmm_group", s);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 0);
+        hipLaunchKernelGGL(phmm_read_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, A, W);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 1);
+        if (rb) hipLaunchKernelGGL(phmm_unit_walk_kernel, dim3(rb), dim3(256), 0, s, A, W);
+        hipLaunchKernelGGL(phmm_stream_copy_kernel, dim3((int)((n_pairs + 3) / 4)), dim3(256), 0, s, A, W);
     }
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
     auto grid = [&](int per_cu) { int64_t cap = (int64_t)cus * per_cu; return (int)(n_pairs < cap ? n_pairs : cap); };
-    { Stage st("phmm_f32_rpl1", s); hipLaunchKernelGGL(phmm_f32_kernel<1>, dim3(grid(32)), dim3(64), 0, s, A, W, 0); }
-    { Stage st("phmm_f32_rpl2", s); hipLaunchKernelGGL(phmm_f32_kernel<2>, dim3(grid(32)), dim3(64), 0, s, A, W, 1); }
-    { Stage st("phmm_f32_rpl3", s); hipLaunchKernelGGL(phmm_f32_kernel<3>, dim3(grid(24)), dim3(64), 0, s, A, W, 2); }
+    // the number of grouped pairs is only known on the device (work.next[0]): the copy / finish kernels are
+    // launched over n_pairs slots and stop there themselves
+#define GBX_STREAM(RPL_)                                                                                                \
+    {                                                                                                                   \
+        static int per_cu = 0;                                                                                          \
+        if (!per_cu) {                                                                                                  \
+            int qb = 0;                                                                                                 \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qb, phmm_stream_kernel<RPL_>, 64, 0) != hipSuccess || qb < 1) { \
+                (void)hipGetLastError(); qb = 8;                                                                        \
+            }                                                                                                           \
+            per_cu = qb > 32 ? 32 : qb;                                                                                 \
+        }                                                                                                               \
+        Stage st("phmm_stream_rpl" #RPL_, s);                                                                           \
+        hipLaunchKernelGGL(phmm_stream_kernel<RPL_>, dim3(grid(per_cu)), dim3(64), 0, s, A, W, RPL_ - 1);               \
+    }
+    GBX_STREAM(1) GBX_STREAM(2) GBX_STREAM(3) GBX_STREAM(4) GBX_STREAM(5) GBX_STREAM(6) GBX_STREAM(7) GBX_STREAM(8)
+#undef GBX_STREAM
+    { Stage st("phmm_stream_finish", s); hipLaunchKernelGGL(phmm_stream_finish_kernel, dim3(cb), dim3(256), 0, s, A, W); }
+    // reads longer than STREAM_MAX_ROWS rows: one pair per wavefront, row tiles
     { Stage st("phmm_f32_rpl4", s); hipLaunchKernelGGL(phmm_f32_kernel<4>, dim3(grid(20)), dim3(64), 0, s, A, W, 3); }
     { Stage st("phmm_f32_rpl6", s); hipLaunchKernelGGL(phmm_f32_kernel<6>, dim3(grid(12)), dim3(64), 0, s, A, W, 4); }
     { Stage st("phmm_f32_rpl8", s); hipLaunchKernelGGL(phmm_f32_kernel<8>, dim3(std::min(grid(8), TILED_BLOCKS)), dim3(64), 0, s, A, W, 5); }

@@ -83,12 +83,12 @@ class DevicePhmmBatchSet:
         self.hap_off, self.hap_len, self.hap = t(bs.hap_off), t(bs.hap_len), t(bs.hap)
         self.out = torch.empty(max(self.n_pairs, 1), dtype=torch.float64, device=device)
         self.max_hap_len = int(bs.hap_len.max()) if len(bs.hap_len) else 1
-        self.work_bytes = N.lib().gbx_phmm_workspace_bytes(self.n_pairs, self.max_hap_len)
+        self.work_bytes = N.lib().gbx_phmm_workspace_bytes(self.n_pairs, self.n_reads, self.max_hap_len)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
 
     def run(self, stream=None):
         N.check(N.lib().gbx_phmm_forward_device(
-            self.n_pairs, self.pair_read.data_ptr(), self.pair_hap.data_ptr(), self.read_off.data_ptr(),
+            self.n_pairs, self.pair_read.data_ptr(), self.pair_hap.data_ptr(), self.n_reads, self.read_off.data_ptr(),
             self.read_len.data_ptr(), self.rs.data_ptr(), self.q.data_ptr(), self.qi.data_ptr(), self.qd.data_ptr(),
             self.qc.data_ptr(), self.hap_off.data_ptr(), self.hap_len.data_ptr(), self.hap.data_ptr(),
             self.max_hap_len, self.out.data_ptr(), self.work.data_ptr(), self.work_bytes, stream))

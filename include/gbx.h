@@ -190,9 +190,11 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
                           int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
                           const uint8_t *hap, double *out);
 
-size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int32_t max_hap_len);
+/* The device entry groups the pairs by read (workspace arrays indexed by read id, hence n_reads) and
+ * materialises one haplotype byte stream per read: workspace ~ n_pairs * (max_hap_len + 1) bytes. */
+size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int32_t max_hap_len);
 int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const int32_t *d_pair_hap,
-                            const int64_t *d_read_off, const int32_t *d_read_len,
+                            int64_t n_reads, const int64_t *d_read_off, const int32_t *d_read_len,
                             const uint8_t *d_rs, const uint8_t *d_q, const uint8_t *d_i, const uint8_t *d_d,
                             const uint8_t *d_c,
                             const int64_t *d_hap_off, const int32_t *d_hap_len, const uint8_t *d_hap,
