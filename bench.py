@@ -30,8 +30,10 @@ _BSW_QMAX = [16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 1024]
 _BSW_SHAPE = ["4x4", "4x8", "4x12", "4x16", "8x10", "8x12", "8x14", "8x16", "16x10", "16x12", "16x16", "64x16"]
 BSW_CLASS = {"bsw_rows_" + sh: ((_BSW_QMAX[k - 1] + 1) if k else 1, _BSW_QMAX[k]) for k, sh in enumerate(_BSW_SHAPE)}
 BSW_CLASS["bsw_lds"] = (1025, 1 << 30)
-PHMM_CLASS = {"phmm_f32_rpl1": (1, 64), "phmm_f32_rpl2": (65, 128), "phmm_f32_rpl3": (129, 192),
-              "phmm_f32_rpl4": (193, 256), "phmm_f32_rpl6": (257, 384), "phmm_f32_rpl8": (385, 1 << 30)}
+# read-length range handled by each phmm kernel (csrc/phmm_kernels.hip: 31 row lanes x K rows per lane on the stream
+# path, one pair per wavefront beyond 248 rows)
+PHMM_CLASS = {"phmm_stream_rpl%d" % k: (31 * (k - 1) + 1, 31 * k) for k in range(1, 9)}
+PHMM_CLASS.update({"phmm_f32_rpl4": (249, 256), "phmm_f32_rpl6": (257, 384), "phmm_f32_rpl8": (385, 1 << 30)})
 
 
 # ------------------------------------------------------------------------------------------ workloads

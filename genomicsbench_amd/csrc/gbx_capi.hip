@@ -4,6 +4,7 @@
 // returns GBX_ERR_NO_DEVICE.
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "gbx_internal.h"
 
@@ -55,6 +56,39 @@ Stage::Stage(const char *name, hipStream_t s) : slot_(-1), s_(s)
 Stage::~Stage()
 {
     if (slot_ >= 0) (void)hipEventRecord(g_prof[slot_].b, s_);
+}
+
+int SideStreams::fork(hipStream_t main)
+{
+    GBX_HIP(hipEventRecord(ev_fork, main));
+    for (int k = 0; k < N; ++k) GBX_HIP(hipStreamWaitEvent(side[k], ev_fork, 0));
+    return GBX_OK;
+}
+int SideStreams::join(hipStream_t main)
+{
+    for (int k = 0; k < N; ++k) {
+        GBX_HIP(hipEventRecord(ev_join[k], side[k]));
+        GBX_HIP(hipStreamWaitEvent(main, ev_join[k], 0));
+    }
+    return GBX_OK;
+}
+int side_streams(SideStreams **out)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<int, SideStreams *>> made;
+    int dev = 0;
+    GBX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &m : made) if (m.first == dev) { *out = m.second; return GBX_OK; }
+    SideStreams *ss = new SideStreams();
+    GBX_HIP(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming));
+    for (int k = 0; k < SideStreams::N; ++k) {
+        GBX_HIP(hipStreamCreateWithFlags(&ss->side[k], hipStreamNonBlocking));
+        GBX_HIP(hipEventCreateWithFlags(&ss->ev_join[k], hipEventDisableTiming));
+    }
+    made.emplace_back(dev, ss);
+    *out = ss;
+    return GBX_OK;
 }
 
 // RAII device buffer for the *_host entry points

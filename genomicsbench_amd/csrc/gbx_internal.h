@@ -27,6 +27,19 @@ struct Stage {
     hipStream_t s_;
 };
 
+// Side streams for independent kernels of one call (the per-class kernels have long single-wave tails that
+// overlap well).  fork(): the side streams wait for everything queued on `main`; join(): `main` waits for
+// them.  One set per device, created on first use; calls on the same device share it (stream order keeps
+// them correct, they just serialise).
+struct SideStreams {
+    static constexpr int N = 3;
+    hipStream_t side[N];
+    hipEvent_t ev_fork, ev_join[N];
+    int fork(hipStream_t main);
+    int join(hipStream_t main);
+};
+int side_streams(SideStreams **out);
+
 // ---- bsw (bsw_kernels.hip)
 size_t bsw_workspace_bytes(int64_t n);
 int bsw_launch(const gbx_bsw_params *p, int64_t n,

@@ -78,6 +78,7 @@ struct PhmmArgs {
     DevTables tab;
 };
 
+struct ReadPart;
 struct PhmmWork {
     int32_t *counts;     // [8]  pairs per row class
     int32_t *cursors;    // [8]
@@ -98,7 +99,9 @@ struct PhmmWork {
     int64_t *soff;       // [n_pairs] stream offset of the pair's boundary byte (grouped order)
     float *yin;          // [n_pairs] INITIAL_CONSTANT / haplen (grouped order)
     float *tmp;          // [n_pairs] fp32 sums (grouped order)
-    int32_t *ucount;     // [UBINS] units (reads) per (row class, stream-length bucket)
+    struct ReadPart *part;   // [ceil(n_reads/1024)] block sums, then block offsets, of the read scan
+    int32_t *ucount;     // [UBINS] units per (row class, stream-length bucket); ucur = ucount + UBINS: scatter cursors
+    int32_t *ucur;
     int32_t *ubase;      // [UBINS+1]
     int32_t *ulist;      // [n_pairs] units = first grouped pair of a (read, segment), class-major, long streams first
     uint8_t *stream;
@@ -106,7 +109,7 @@ struct PhmmWork {
 
 constexpr int STREAM_LANES = 31;                              // row lanes per half-wavefront (lane 31 / 63 stays all-zero)
 constexpr int STREAM_MAX_ROWS = STREAM_LANES * 8;
-constexpr int SEG_MAX_PAIRS = 16;                             // a read's pairs are cut into units of at most this many
+constexpr int SEG_MAX_PAIRS = 8;                              // a read's pairs are cut into units of at most this many
 constexpr int UBUCKETS = 32;
 constexpr int UBINS = 8 * UBUCKETS;
 __host__ __device__ inline int unit_bin(int R, int slen)
@@ -343,59 +346,104 @@ __global__ void __launch_bounds__(64) phmm_f64_kernel(PhmmArgs A, PhmmWork W)
 }
 
 // ---- stream path ------------------------------------------------------------
-// One block: exclusive scans over the reads (pair positions, stream byte offsets) and the unit list
-// (reads that own pairs), binned by (row class, stream length) with the longest streams first.
+// Exclusive scans over the reads (pair positions, stream byte offsets) and the unit list, binned by (row
+// class, stream length) with the longest streams first: block sums -> one-block scan -> placement.
 constexpr int SCAN_THREADS = 1024;
-__global__ void __launch_bounds__(SCAN_THREADS) phmm_read_scan_kernel(PhmmArgs A, PhmmWork W)
+struct ReadPart { long long bytes; int pairs; int pad; };
+
+__device__ inline void read_contrib(const PhmmWork &W, int64_t r, int &c, long long &bytes)
 {
-    __shared__ long long part[SCAN_THREADS];
-    __shared__ int partc[SCAN_THREADS];
-    __shared__ int bins[UBINS + 1];
-    __shared__ int bcur[UBINS];
+    c = r < W.n_reads ? W.rcount[r] : 0;
+    bytes = c ? stream_bytes_of(W.rslen[r]) : 0;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) phmm_read_sum_kernel(PhmmArgs A, PhmmWork W)
+{
+    __shared__ long long sb[SCAN_THREADS / 64];
+    __shared__ int sc[SCAN_THREADS / 64];
+    __shared__ int bins[UBINS];
     const int tid = threadIdx.x;
-    const int64_t n = W.n_reads;
-    const int64_t per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int64_t lo = min(n, tid * per), hi = min(n, lo + per);
-    for (int b = tid; b <= UBINS; b += SCAN_THREADS) bins[b] = 0;
-    for (int b = tid; b < UBINS; b += SCAN_THREADS) bcur[b] = 0;
+    for (int b = tid; b < UBINS; b += SCAN_THREADS) bins[b] = 0;
     __syncthreads();
-    long long bytes = 0; int pairs = 0;
-    for (int64_t r = lo; r < hi; ++r) {
-        const int c = W.rcount[r];
-        if (c) {
-            pairs += c; bytes += stream_bytes_of(W.rslen[r]);
-            const int ns = seg_count(c);
-            atomicAdd(&bins[unit_bin(A.read_len[r], W.rslen[r] / ns)], ns);
+    const int64_t r = (int64_t)blockIdx.x * SCAN_THREADS + tid;
+    int c; long long bytes;
+    read_contrib(W, r, c, bytes);
+    if (c) { const int ns = seg_count(c); atomicAdd(&bins[unit_bin(A.read_len[r], W.rslen[r] / ns)], ns); }
+    long long wb = bytes; int wc = c;
+    for (int d = 32; d; d >>= 1) { wb += __shfl_down(wb, d); wc += __shfl_down(wc, d); }
+    if ((tid & 63) == 0) { sb[tid >> 6] = wb; sc[tid >> 6] = wc; }
+    __syncthreads();
+    if (tid == 0) {
+        long long tb = 0; int tc = 0;
+        for (int k = 0; k < SCAN_THREADS / 64; ++k) { tb += sb[k]; tc += sc[k]; }
+        W.part[blockIdx.x].bytes = tb; W.part[blockIdx.x].pairs = tc;
+    }
+    for (int b = tid; b < UBINS; b += SCAN_THREADS)
+        if (bins[b]) atomicAdd(&W.ucount[b], bins[b]);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) phmm_read_scan_kernel(PhmmWork W, int nblk)
+{
+    __shared__ long long sb[SCAN_THREADS];
+    __shared__ int sc[SCAN_THREADS];
+    const int tid = threadIdx.x;
+    long long base_b = 0; int base_c = 0;
+    for (int k0 = 0; k0 < nblk; k0 += SCAN_THREADS) {
+        const int k = k0 + tid;
+        const long long vb = k < nblk ? W.part[k].bytes : 0;
+        const int vc = k < nblk ? W.part[k].pairs : 0;
+        sb[tid] = vb; sc[tid] = vc;
+        __syncthreads();
+        for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+            const long long ab = tid >= d ? sb[tid - d] : 0;
+            const int ac = tid >= d ? sc[tid - d] : 0;
+            __syncthreads();
+            sb[tid] += ab; sc[tid] += ac;
+            __syncthreads();
         }
-    }
-    part[tid] = bytes; partc[tid] = pairs;
-    __syncthreads();
-    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
-        const long long a = tid >= d ? part[tid - d] : 0;
-        const int ac = tid >= d ? partc[tid - d] : 0;
-        __syncthreads();
-        part[tid] += a; partc[tid] += ac;
+        if (k < nblk) { W.part[k].bytes = base_b + sb[tid] - vb; W.part[k].pairs = base_c + sc[tid] - vc; }
+        base_b += sb[SCAN_THREADS - 1]; base_c += sc[SCAN_THREADS - 1];
         __syncthreads();
     }
-    long long boff = part[tid] - bytes; int poff = partc[tid] - pairs;
-    if (tid == 0) {                                            // exclusive scan of the bins (256 entries)
+    if (tid == 0) {
+        W.next[0] = base_c;                                    // pairs on the stream path
         int acc = 0;
-        for (int b = 0; b < UBINS; ++b) { const int c = bins[b]; bins[b] = acc; acc += c; }
-        bins[UBINS] = acc;
+        for (int b = 0; b < UBINS; ++b) { W.ubase[b] = acc; acc += W.ucount[b]; }
+        W.ubase[UBINS] = acc;
     }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) phmm_read_place_kernel(PhmmArgs A, PhmmWork W)
+{
+    __shared__ long long sb[SCAN_THREADS / 64];
+    __shared__ int sc[SCAN_THREADS / 64];
+    __shared__ int lbin[UBINS], lbase[UBINS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int b = tid; b < UBINS; b += SCAN_THREADS) lbin[b] = 0;
+    const int64_t r = (int64_t)blockIdx.x * SCAN_THREADS + tid;
+    int c; long long bytes;
+    read_contrib(W, r, c, bytes);
+    long long ib = bytes; int ic = c;                          // inclusive scan inside the wavefront
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long ub = __shfl_up(ib, d); const int uc = __shfl_up(ic, d);
+        if (lane >= d) { ib += ub; ic += uc; }
+    }
+    if (lane == 63) { sb[wv] = ib; sc[wv] = ic; }
     __syncthreads();
-    for (int b = tid; b <= UBINS; b += SCAN_THREADS) W.ubase[b] = bins[b];
-    if (tid == SCAN_THREADS - 1) W.next[0] = partc[tid];       // pairs on the stream path
-    for (int64_t r = lo; r < hi; ++r) {
-        const int c = W.rcount[r];
-        W.rfirst[r] = poff; W.rsbase[r] = boff;
-        if (c) {
-            const int ns = seg_count(c), q = seg_pairs(c);
-            const int bin = unit_bin(A.read_len[r], W.rslen[r] / ns);
-            const int at = bins[bin] + atomicAdd(&bcur[bin], ns);
-            for (int g = 0; g < ns; ++g) W.ulist[at + g] = poff + g * q;     // first grouped pair of the unit
-            poff += c; boff += stream_bytes_of(W.rslen[r]);
-        }
+    long long off_b = W.part[blockIdx.x].bytes; int off_c = W.part[blockIdx.x].pairs;
+    for (int k = 0; k < wv; ++k) { off_b += sb[k]; off_c += sc[k]; }
+    const int poff = off_c + ic - c;
+    if (r < W.n_reads) { W.rfirst[r] = poff; W.rsbase[r] = off_b + ib - bytes; }
+    // units: block-aggregated allocation inside the (class, length) bins
+    const int ns = c ? seg_count(c) : 0;
+    const int bin = c ? unit_bin(A.read_len[r], W.rslen[r] / ns) : 0;
+    const int local = c ? atomicAdd(&lbin[bin], ns) : 0;
+    __syncthreads();
+    for (int b = tid; b < UBINS; b += SCAN_THREADS) lbase[b] = lbin[b] ? W.ubase[b] + atomicAdd(&W.ucur[b], lbin[b]) : 0;
+    __syncthreads();
+    if (c) {
+        const int q = seg_pairs(c), at = lbase[bin] + local;
+        for (int g = 0; g < ns; ++g) W.ulist[at + g] = poff + g * q;         // first grouped pair of the unit
     }
 }
 
@@ -661,7 +709,7 @@ size_t scratch_stride_bytes(int max_hap_len)
 namespace {
 // workspace carve-up, shared by the size query and the launch
 struct WorkLayout {
-    size_t order, dlist, scratch, rcount, rslen, rcur, rfirst, rsbase, porder, soff, yin, tmp, ucount, ubase, ulist, stream, total;
+    size_t order, dlist, scratch, rcount, rslen, rcur, ucount, rfirst, rsbase, porder, soff, yin, tmp, part, ubase, ulist, stream, total;
 };
 WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len)
 {
@@ -677,13 +725,14 @@ WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len)
     L.rcount = take((size_t)n_reads * 4);          // rcount | rslen | rcur are zeroed together
     L.rslen = take((size_t)n_reads * 4);
     L.rcur = take((size_t)n_reads * 4);
+    L.ucount = take((size_t)2 * UBINS * 4);        // + scatter cursors; zeroed with the three arrays above
     L.rfirst = take((size_t)n_reads * 4);
     L.rsbase = take((size_t)n_reads * 8);
     L.porder = take((size_t)n_pairs * 4);
     L.soff = take((size_t)n_pairs * 8);
     L.yin = take((size_t)(n_pairs + 1) * 4);
     L.tmp = take((size_t)(n_pairs + 1) * 4);
-    L.ucount = take((size_t)UBINS * 4);
+    L.part = take((size_t)(n_reads / 1024 + 2) * 16);
     L.ubase = take((size_t)(UBINS + 1) * 4);
     L.ulist = take((size_t)n_pairs * 4);
     // every pair contributes haplen+1 symbols, every read with pairs < 48 bytes of closing boundary + padding
@@ -731,7 +780,8 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     W.rfirst = (int32_t *)(wb + L.rfirst); W.rsbase = (int64_t *)(wb + L.rsbase);
     W.porder = (int32_t *)(wb + L.porder); W.soff = (int64_t *)(wb + L.soff);
     W.yin = (float *)(wb + L.yin); W.tmp = (float *)(wb + L.tmp);
-    W.ucount = (int32_t *)(wb + L.ucount); W.ubase = (int32_t *)(wb + L.ubase); W.ulist = (int32_t *)(wb + L.ulist);
+    W.part = (ReadPart *)(wb + L.part);
+    W.ucount = (int32_t *)(wb + L.ucount); W.ucur = W.ucount + UBINS; W.ubase = (int32_t *)(wb + L.ubase); W.ulist = (int32_t *)(wb + L.ulist);
     W.stream = (uint8_t *)(wb + L.stream);
     GBX_HIP(hipMemsetAsync(d_work, 0, 64 * sizeof(int32_t), s));
     GBX_HIP(hipMemsetAsync(wb + L.rcount, 0, L.rfirst - L.rcount, s));
@@ -742,7 +792,10 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
         // group the pairs by read, lay the haplotype streams out
         Stage st("phmm_group", s);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 0);
-        hipLaunchKernelGGL(phmm_read_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, A, W);
+        const int nblk = (int)((n_reads + SCAN_THREADS - 1) / SCAN_THREADS);
+        if (nblk) hipLaunchKernelGGL(phmm_read_sum_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, A, W);
+        hipLaunchKernelGGL(phmm_read_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, W, nblk);
+        if (nblk) hipLaunchKernelGGL(phmm_read_place_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, A, W);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 1);
         if (rb) hipLaunchKernelGGL(phmm_unit_walk_kernel, dim3(rb), dim3(256), 0, s, A, W);
         hipLaunchKernelGGL(phmm_stream_copy_kernel, dim3((int)((n_pairs + 3) / 4)), dim3(256), 0, s, A, W);
@@ -753,7 +806,10 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     auto grid = [&](int per_cu) { int64_t cap = (int64_t)cus * per_cu; return (int)(n_pairs < cap ? n_pairs : cap); };
     // the number of grouped pairs is only known on the device (work.next[0]): the copy / finish kernels are
     // launched over n_pairs slots and stop there themselves
-#define GBX_STREAM(RPL_)                                                                                                \
+    // the row classes are independent and each ends in a tail of single long units: they run side by side
+    SideStreams *ss = nullptr;
+    if ((rc = side_streams(&ss)) || (rc = ss->fork(s))) return rc;
+#define GBX_STREAM(RPL_, STREAM_)                                                                                       \
     {                                                                                                                   \
         static int per_cu = 0;                                                                                          \
         if (!per_cu) {                                                                                                  \
@@ -763,11 +819,13 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
             }                                                                                                           \
             per_cu = qb > 32 ? 32 : qb;                                                                                 \
         }                                                                                                               \
-        Stage st("phmm_stream_rpl" #RPL_, s);                                                                           \
-        hipLaunchKernelGGL(phmm_stream_kernel<RPL_>, dim3(grid(per_cu)), dim3(64), 0, s, A, W, RPL_ - 1);               \
+        Stage st("phmm_stream_rpl" #RPL_, STREAM_);                                                                     \
+        hipLaunchKernelGGL(phmm_stream_kernel<RPL_>, dim3(grid(per_cu)), dim3(64), 0, STREAM_, A, W, RPL_ - 1);         \
     }
-    GBX_STREAM(1) GBX_STREAM(2) GBX_STREAM(3) GBX_STREAM(4) GBX_STREAM(5) GBX_STREAM(6) GBX_STREAM(7) GBX_STREAM(8)
+    GBX_STREAM(5, s) GBX_STREAM(4, ss->side[0]) GBX_STREAM(6, ss->side[1]) GBX_STREAM(3, ss->side[2])
+    GBX_STREAM(2, ss->side[0]) GBX_STREAM(7, ss->side[1]) GBX_STREAM(1, ss->side[2]) GBX_STREAM(8, ss->side[1])
 #undef GBX_STREAM
+    if ((rc = ss->join(s))) return rc;
     { Stage st("phmm_stream_finish", s); hipLaunchKernelGGL(phmm_stream_finish_kernel, dim3(cb), dim3(256), 0, s, A, W); }
     // reads longer than STREAM_MAX_ROWS rows: one pair per wavefront, row tiles
     { Stage st("phmm_f32_rpl4", s); hipLaunchKernelGGL(phmm_f32_kernel<4>, dim3(grid(20)), dim3(64), 0, s, A, W, 3); }

@@ -61,6 +61,34 @@ def test_row_classes_and_tiles():
     assert_close(forward_host(bs), O.phmm_oracle(bs, 8))
 
 
+def test_stream_units_segments_and_lane_classes():
+    """The stream path: read lengths on both sides of every 31-rows-per-lane class edge (and past its 248-row
+    limit), more haplotypes per read than one unit holds (several segments per read), an odd number of
+    units (idle half wavefront), very short haplotypes between long ones, and pairs in scrambled order."""
+    rng = np.random.default_rng(11)
+    base = rand_seq(rng, 700)
+    haps = []
+    for k in range(37):
+        H = int(rng.integers(1, 12)) if k % 5 == 0 else int(rng.integers(40, 460))
+        o = int(rng.integers(0, 200))
+        haps.append("".join(c if rng.random() > 0.02 else "ACGTN"[int(rng.integers(5))] for c in base[o:o + H]))
+    reads = []
+    for R in (1, 30, 31, 32, 61, 62, 63, 93, 94, 124, 125, 151, 155, 156, 186, 187, 217, 218, 247, 248, 249, 256, 300):
+        o = int(rng.integers(0, 300))
+        reads.append("".join(c if rng.random() > 0.03 else "ACGT"[int(rng.integers(4))] for c in base[o:o + R]))
+    bs = make_set(reads, haps, seed=12)
+    want = O.phmm_oracle(bs, 8)
+    assert_close(forward_host(bs), want)
+    # the same pairs in a scrambled order, a third of them dropped
+    perm = rng.permutation(bs.n_pairs)[: 2 * bs.n_pairs // 3]
+    sub = PhmmBatchSet.__new__(PhmmBatchSet)
+    sub.__dict__.update(bs.__dict__)
+    sub.pair_read, sub.pair_hap = bs.pair_read[perm].copy(), bs.pair_hap[perm].copy()
+    sub.n_pairs = len(perm)
+    sub.batch_pair_off = np.array([0, len(perm)], dtype=np.int64)
+    assert_close(forward_host(sub), want[perm])
+
+
 def test_fp64_fallback_pairs():
     rng = np.random.default_rng(3)
     haps = [rand_seq(rng, 120), rand_seq(rng, 300)]
