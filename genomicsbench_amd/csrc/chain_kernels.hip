@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         const uint64_t mdx = (uint64_t)(int64_t)max_dist_x;
 
         for (int i = lane; i < n; i += 64) t[i] = 0;          // vectors are zero-filled, host_kernel.cpp:44-47
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
         int st = 0;
         int sb = 0;                                           // block of 64 x-values cached for the st scan
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         const int rs = jj & (RING - 1);
                         xj = rx[rs]; yj = ry[rs]; fj = rf[rs]; pj = rp[rs]; tj = rt[rs];
                     } else {
-                        if (!fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); fenced = true; }
+                        if (!fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); fenced = true; }
                         xj = x[jj]; yj = y[jj]; fj = f[jj]; pj = p[jj]; tj = t[jj];
                     }
                     // ---- phase 1: candidate score / `continue` mask (:59-80)
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 int pkj = 0;
                 if (max_j >= 0) {
                     if (i - max_j <= RING) pkj = rk[max_j & (RING - 1)];
-                    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); pkj = pk[max_j]; }
+                    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); pkj = pk[max_j]; }
                 }
                 const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
                 if (lane == 0) {
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
             }
         }
         if (lane == 0) atomicAdd(W.evaluated, visited);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 }
 

@@ -544,7 +544,7 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     else (void)hipGetLastError();
-    int64_t slots = (int64_t)cus * 10;      /* LDS (15 KB per wave) admits 10 waves per CU */
+    int64_t slots = (int64_t)cus * poa_waves_per_cu(plan->node_cap);   /* one window per resident wavefront */
     if (n_windows < slots) slots = n_windows > 0 ? n_windows : 1;
     plan->n_slots = (int32_t)slots;
     return GBX_OK;

@@ -70,6 +70,7 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
 
 // ---- poa (poa_kernels.hip)
 size_t poa_slot_bytes(int ncap, int deg, int lmax);
+int poa_waves_per_cu(int ncap);
 int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,

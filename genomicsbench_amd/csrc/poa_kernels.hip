@@ -155,8 +155,8 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
         PoaGraph &gm = const_cast<PoaGraph &>(g);
         for (int r = lane; r < n; r += 64) poa_rowdesc_one(gm, r);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const bool single = len <= BLK;
     int sq[CPL];
@@ -281,9 +281,224 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
                 hlast = __builtin_amdgcn_readlane(hv, (len - 1 - base) / CPL);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (sink && best < hlast) { best = hlast; max_i = i; max_j = len; }       // NW: best sink at the last column
+    }
+}
+
+// ---- the same DP with the row loop software-pipelined (sequences of at most 512 columns) ------------
+// A row costs three dependent memory round trips in poa_dp (column 0 of the predecessors, their rows, and
+// the wait for its own stores before the next row may read them), far more than its arithmetic.  Here the
+// inputs of row r+1 (rows of its first two predecessors, packed int16, plus their column 0) are requested
+// while row r is still being computed and *before* row r is stored, so they are not queued behind those
+// stores; a predecessor that is row r itself is handed over in registers.  Vector memory operations of one
+// wavefront are performed in order, so a row stored in an earlier iteration is visible to these loads
+// without a fence.
+struct PoaPredIn { v8s h, f, o; int h0, o0, f0; };
+
+__device__ inline void poa_unpack(const v8s &t, int *out)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = t[e];
+}
+__device__ inline v8s poa_pack(const int *in)
+{
+    v8s t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (short)in[e];
+    return t;
+}
+
+__device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
+                                 int &max_i, int &max_j)
+{
+    constexpr int CPL = 8;
+    const int lane = threadIdx.x & 63;
+    const PoaScore S = A.S;
+    const int Wp = M.Wp;
+    const int n = g.n_nodes;
+    const Mat2 *Tc = A.Tc[0];
+    const Mat2 P16 = mp_pow(Tc[0], (lane & 15) + 1);
+    const Mat2 P32 = mp_pow(Tc[0], (lane & 31) + 1);
+    const Mat2 PC = mp_pow(Tc[0], lane);
+
+    for (int j = lane; j <= len; j += 64) {                    // row 0 (`initialize`)
+        const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
+        M.E[j + POA_COL0] = (poa_cell_t)e0; M.Q[j + POA_COL0] = (poa_cell_t)q0;
+        M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
+        M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
+    }
+    int32_t *d_pred = g.score, *d_info = g.pred;
+    const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;
+    {
+        PoaGraph &gm = const_cast<PoaGraph &>(g);
+        for (int r = lane; r < n; r += 64) poa_rowdesc_one(gm, r);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int j0 = lane * CPL + 1;                             // the lane's first column
+    const bool mine = j0 <= len;
+    int sq[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = j <= len ? seq[j - 1] : -1; }
+
+    auto fetch = [&](int prow, PoaPredIn &x) {
+        const int64_t b = (int64_t)prow * Wp + POA_COL0;
+        if (mine) { x.h = *(const v8s *)(M.H + b + j0); x.f = *(const v8s *)(M.F + b + j0); x.o = *(const v8s *)(M.O + b + j0); }
+        x.h0 = M.H[b]; x.o0 = M.O[b]; x.f0 = M.F[b];
+    };
+    auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
+        const int rr = min(r, n - 1);
+        p0 = d_pred[rr]; p1 = d_pred1[rr]; p2 = d_pred2[rr]; info = d_info[rr];
+    };
+
+    int best = POA_NEG_INF;
+    max_i = -1; max_j = -1;
+    if (n == 0) return;
+    // descriptors: row r (a*), row r+1 (b*), row r+2 is requested inside the loop
+    int ap0, ap1, ap2, ainfo, bp0, bp1, bp2, binfo;
+    desc(0, ap0, ap1, ap2, ainfo);
+    desc(1, bp0, bp1, bp2, binfo);
+    PoaPredIn in0, in1, last;
+    in0.h = in0.f = in0.o = in1.h = in1.f = in1.o = last.h = last.f = last.o = (v8s)0;
+    in0.h0 = in0.o0 = in0.f0 = in1.h0 = in1.o0 = in1.f0 = last.h0 = last.o0 = last.f0 = 0;
+    bool reg0 = false, reg1 = false;                           // predecessor k of the row at hand is the previous row
+    {
+        const int ic = (ainfo >> 8) & 0xff;
+        fetch(ic ? ap0 : 0, in0);
+        if (ic > 1) fetch(ap1, in1);
+    }
+    for (int r = 0; r < n; ++r) {
+        const int i = r + 1;
+        const int p2 = ap2, info = ainfo;
+        const int letter = info & 0xff, ic = (info >> 8) & 0xff;
+        const bool sink = (info >> 16) & 1;
+        const int64_t ro = (int64_t)i * Wp + POA_COL0;
+        int cp0, cp1, cp2, cinfo;                              // row r+2
+        desc(r + 2, cp0, cp1, cp2, cinfo);
+
+        // ---- inputs of this row out of the prefetch registers (or the previous row's registers)
+        int Fa[CPL], Oa[CPL], Ha[CPL];
+        int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
+        {
+            const PoaPredIn &x = reg0 ? last : in0;
+            int hp[CPL], fp[CPL], op[CPL];
+            poa_unpack(x.h, hp); poa_unpack(x.f, fp); poa_unpack(x.o, op);
+            if (ic > 0) { po = max(po, x.o0); pf = max(pf, x.f0); }
+            int hl = __builtin_amdgcn_update_dpp(x.h0, hp[CPL - 1], 0x138, 0xf, 0xf, false);
+            if (lane == 0) hl = x.h0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int sc = sq[c] == letter ? S.m : S.n;
+                Fa[c] = max(hp[c] + S.g, fp[c] + S.e);
+                Oa[c] = max(hp[c] + S.q, op[c] + S.c);
+                Ha[c] = hl + sc;
+                hl = hp[c];
+            }
+        }
+        if (ic > 1) {
+            const PoaPredIn &x = reg1 ? last : in1;
+            int hp[CPL], fp[CPL], op[CPL];
+            poa_unpack(x.h, hp); poa_unpack(x.f, fp); poa_unpack(x.o, op);
+            po = max(po, x.o0); pf = max(pf, x.f0);
+            int hl = __builtin_amdgcn_update_dpp(x.h0, hp[CPL - 1], 0x138, 0xf, 0xf, false);
+            if (lane == 0) hl = x.h0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int sc = sq[c] == letter ? S.m : S.n;
+                Fa[c] = max(Fa[c], max(hp[c] + S.g, fp[c] + S.e));
+                Oa[c] = max(Oa[c], max(hp[c] + S.q, op[c] + S.c));
+                Ha[c] = max(Ha[c], hl + sc);
+                hl = hp[c];
+            }
+        }
+        // ---- request the inputs of row r+1 now: before this row's stores, behind those of the rows before
+        const int nic = (binfo >> 8) & 0xff;
+        const bool nreg0 = r + 1 < n && nic >= 1 && bp0 == i, nreg1 = r + 1 < n && nic >= 2 && bp1 == i;
+        if (r + 1 < n) {
+            if (!nreg0) fetch(nic ? bp0 : 0, in0);
+            if (nic > 1 && !nreg1) fetch(bp1, in1);
+        }
+        // ---- predecessors beyond the second: read in place (rare)
+        if (ic > 2) {
+            const int node = g.r2n[r];
+            for (int k = 2; k < ic; ++k) {
+                const int prow = k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1;
+                const int64_t b = (int64_t)prow * Wp + POA_COL0;
+                int hp[CPL], fp[CPL], op[CPL];
+                if (mine) { load_cells<CPL>(M.H + b + j0, hp); load_cells<CPL>(M.F + b + j0, fp); load_cells<CPL>(M.O + b + j0, op); }
+                else {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) { hp[c] = 0; fp[c] = 0; op[c] = 0; }
+                }
+                const int hfirst = M.H[b];
+                po = max(po, (int)M.O[b]); pf = max(pf, (int)M.F[b]);
+                int hl = __builtin_amdgcn_update_dpp(hfirst, hp[CPL - 1], 0x138, 0xf, 0xf, false);
+                if (lane == 0) hl = hfirst;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int sc = sq[c] == letter ? S.m : S.n;
+                    Fa[c] = max(Fa[c], max(hp[c] + S.g, fp[c] + S.e));
+                    Oa[c] = max(Oa[c], max(hp[c] + S.q, op[c] + S.c));
+                    Ha[c] = max(Ha[c], hl + sc);
+                    hl = hp[c];
+                }
+            }
+        }
+        const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
+        if (lane == 0) {
+            M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
+            M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
+        }
+        const int cE = H0 + S.g, cQ = H0 + S.q;                // (E,Q) entering column 1
+        int Aa[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Aa[c] = mine ? max(Ha[c], max(Fa[c], Oa[c])) : SNEG;
+        int bE = SNEG, bQ = SNEG;                              // pass 1: lane-local recurrence from the identity
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int h = max(Aa[c], max(bE, bQ));
+            const int ne = max(h + S.g, bE + S.e), nq = max(h + S.q, bQ + S.c);
+            bE = ne; bQ = nq;
+        }
+        int xE = bE, xQ = bQ, tE, tQ;                          // inclusive scan over the lanes
+        mp_apply(Tc[0], dpp_i<0x111>(SNEG, xE), dpp_i<0x111>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        mp_apply(Tc[1], dpp_i<0x112>(SNEG, xE), dpp_i<0x112>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        mp_apply(Tc[2], dpp_i<0x114>(SNEG, xE), dpp_i<0x114>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        mp_apply(Tc[3], dpp_i<0x118>(SNEG, xE), dpp_i<0x118>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        mp_apply(P16, dpp_i<0x142, 0xa>(SNEG, xE), dpp_i<0x142, 0xa>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        mp_apply(P32, dpp_i<0x143, 0xc>(SNEG, xE), dpp_i<0x143, 0xc>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
+        int vE = dpp_i<0x138>(SNEG, xE), vQ = dpp_i<0x138>(SNEG, xQ);
+        if (lane == 0) { vE = SNEG; vQ = SNEG; }
+        mp_apply(PC, cE, cQ, tE, tQ);                          // Tc^lane (x) the (E,Q) entering column 1
+        vE = max(vE, tE); vQ = max(vQ, tQ);
+        int Hn[CPL], En[CPL], Qn[CPL];                         // pass 2: exact E, Q, H
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int h = max(Aa[c], max(vE, vQ));
+            Hn[c] = h; En[c] = vE; Qn[c] = vQ;
+            const int ne = max(h + S.g, vE + S.e), nq = max(h + S.q, vQ + S.c);
+            vE = ne; vQ = nq;
+        }
+        last.h = poa_pack(Hn); last.f = poa_pack(Fa); last.o = poa_pack(Oa);
+        last.h0 = H0; last.o0 = O0; last.f0 = F0;
+        if (mine) {
+            *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
+            store_cells<CPL>(M.E + ro + j0, En); store_cells<CPL>(M.Q + ro + j0, Qn);
+        }
+        if (sink) {                                            // H(i, len)
+            const int cl = (len - 1) % CPL;
+            int hv = Hn[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) hv = c == cl ? Hn[c] : hv;
+            const int hlast = __builtin_amdgcn_readlane(hv, (len - 1) / CPL);
+            if (best < hlast) { best = hlast; max_i = i; max_j = len; }
+        }
+        reg0 = nreg0; reg1 = nreg1;
+        ap2 = bp2; ainfo = binfo;
+        bp0 = cp0; bp1 = cp1; bp2 = cp2; binfo = cinfo;
     }
 }
 
@@ -312,8 +527,8 @@ __device__ int poa_add_chain_wave(PoaGraph &g, const uint8_t *seq, int begin, in
         if (k < L - 1) { PG_OUT_DST(g, id, 0) = id + 1; PG_OUT_SLOT(g, id, 0) = 0; }
     }
     g.n_nodes = n0 + L;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return n0;
 }
 
@@ -343,8 +558,8 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short 
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < n; i += 64) st8[i] = 4;                    // mark 0, check 1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int sp = 0, nr = 0;
     for (int i = 0; i < n; ++i) {
         if ((st8[i] & 3) != 0) continue;
@@ -387,11 +602,11 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short 
             if (valid) --sp;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 #ifdef GBX_POA_PHASE_STATS
@@ -479,7 +694,7 @@ __device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len,
     TOPO_TIMED(g)
 }
 
-__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
+__global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
     PoaGraph g;
@@ -527,7 +742,8 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 PH_T0
-                poa_dp<8>(g, M, A, seq, len, mi, mj);      // sequences longer than 512 run as several column blocks
+                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+                else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
@@ -537,8 +753,8 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 if (g.err == 0) poa_add_alignment_wave(g, seq, len, lds_st8, lds_ord, lds_stk);
                 PH_ACC(t_add)
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         int clen = 0;
         {
@@ -557,6 +773,20 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 }
 
 }  // namespace
+
+// wavefronts (= windows in flight) one CU keeps resident for this node capacity: registers and the LDS of
+// the topological sort decide
+int poa_waves_per_cu(int ncap)
+{
+    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    const bool lds_marks = lds_need <= 20 * 1024 && ncap < 32768;
+    int q = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
+        (void)hipGetLastError();
+        q = 8;
+    }
+    return q;
+}
 
 // workspace = slots * slot_bytes
 size_t poa_slot_bytes(int ncap, int deg, int lmax) { return (size_t)make_layout(ncap, deg, lmax).total; }
