@@ -553,13 +553,41 @@ __device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
 // order is written to r2n / n2r by all lanes at the end.  Same order as poa_topo_sort (poa_graph.h).
 constexpr int POA_LDS_STACK16 = 1024;
 
-__device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short *ord, short *stk)
+// LDS arrays of the topological sort, persistent per wavefront for the life of a window
+struct PoaTopoLds {
+    unsigned char *st8;      // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
+    short *ord;              // [ncp] order under construction
+    short *old;              // [ncp] rank of the node in the previous sort (-1: node added since)
+    short *stk;              // [POA_LDS_STACK16] DFS stack
+    int n_sorted;            // nodes ranked by the previous sort
+};
+
+__device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
+    unsigned char *st8 = T.st8; short *ord = T.ord, *stk = T.stk, *old = T.old;
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
-    for (int i = lane; i < n; i += 64) st8[i] = 4;                    // mark 0, check 1
+    const int n_old = T.n_sorted;
+    for (int i = lane; i < n; i += 64) { st8[i] = 4; if (i >= n_old) old[i] = -1; }   // mark 0, check 1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // The walk follows the previous topological order closely (one sequence changes the graph little), so
+    // the per-node records (in-degree, aligned count, first four in-edge sources, aligned nodes) of 64 nodes
+    // that were consecutive in the previous order sit in registers, one per lane, and reach the
+    // wave-uniform DFS through v_readlane; the block is re-read when the walk has moved on (second miss
+    // in the same 64-rank region).  Nodes added since the previous sort are read in place.
+    int rb = -64, miss_rb = -64;
+    int c_cnt = 0;
+    PoaInt4 c_e, c_a, c_b;
+    c_e.v[0] = c_e.v[1] = c_e.v[2] = c_e.v[3] = 0; c_a = c_e; c_b = c_e;
+    auto load_block = [&](int base) {
+        rb = base;
+        const int id = g.r2n[min(base + lane, n_old - 1)];
+        c_cnt = (int)g.in_cnt[id] | (int)g.aln_cnt[id] << 8;
+        c_e = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
+        c_a = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
+        c_b = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+    };
     int sp = 0, nr = 0;
     for (int i = 0; i < n; ++i) {
         if ((st8[i] & 3) != 0) continue;
@@ -567,10 +595,25 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short 
         while (sp) {
             const int id = stk[sp - 1];
             const int stv = st8[id];
-            const int ic = g.in_cnt[id], ac = g.aln_cnt[id];
-            const PoaInt4 e4 = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
-            const PoaInt4 a4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
-            const PoaInt4 b4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+            int ic, ac;
+            PoaInt4 e4, a4, b4;
+            const int o = old[id];
+            if (o >= 0 && (unsigned)(o - rb) >= 64u) {          // ranked before, outside the block
+                const int mb = o & ~63;
+                if (mb == miss_rb) load_block(mb); else miss_rb = mb;
+            }
+            const int l = o - rb;
+            if (o >= 0 && (unsigned)l < 64u) {
+                const int cc = rl(c_cnt, l);
+                ic = cc & 0xff; ac = cc >> 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e4.v[k] = rl(c_e.v[k], l); a4.v[k] = rl(c_a.v[k], l); b4.v[k] = rl(c_b.v[k], l); }
+            } else {
+                ic = g.in_cnt[id]; ac = g.aln_cnt[id];
+                e4 = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
+                a4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
+                b4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+            }
             const bool chk = (stv & 4) != 0;
             bool valid = true;
             if ((stv & 3) != 2) {
@@ -604,7 +647,8 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, unsigned char *st8, short 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; }
+    for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; old[id] = (short)r; }
+    T.n_sorted = n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
@@ -616,8 +660,8 @@ __device__ unsigned long long g_topo_cycles, g_topo_iters;
 #define TOPO_TIMED(g) POA_TOPO(g);
 #endif
 // topological sort through LDS when the kernel was launched with the LDS layout, else the global-memory one
-#define POA_TOPO(g) { if (lds_st8) poa_topo_sort_lds(g, lds_st8, lds_ord, lds_stk); else poa_topo_sort(g); }
-__device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, unsigned char *lds_st8, short *lds_ord, short *lds_stk)
+#define POA_TOPO(g) { if (T.st8) poa_topo_sort_lds(g, T); else poa_topo_sort(g); }
+__device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, PoaTopoLds &T)
 {
     if (len == 0) return;
     const int lane = threadIdx.x & 63;
@@ -713,9 +757,12 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int ncp = (A.ncap + 15) & ~15;
     // serial DFS state on chip (LDS): state byte per node, order under construction, stack
-    unsigned char *lds_st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
-    short *lds_ord = (short *)(lds_raw + ncp);
-    short *lds_stk = (short *)(lds_raw + ncp + 2 * ncp);
+    PoaTopoLds T;
+    T.st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
+    T.ord = (short *)(lds_raw + ncp);
+    T.old = (short *)(lds_raw + 3 * ncp);
+    T.stk = (short *)(lds_raw + 5 * ncp);
+    T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
 
@@ -730,6 +777,7 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 #endif
     for (int64_t w = blockIdx.x; w < A.n_windows; w += gridDim.x) {
         poa_graph_reset(g);
+        T.n_sorted = 0;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
         for (int64_t s = s0; s < s1; ++s) {
             const uint8_t *seq = A.arena + A.seq_off[s];
@@ -750,7 +798,7 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
             }
             {
                 PH_T0
-                if (g.err == 0) poa_add_alignment_wave(g, seq, len, lds_st8, lds_ord, lds_stk);
+                if (g.err == 0) poa_add_alignment_wave(g, seq, len, T);
                 PH_ACC(t_add)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -778,7 +826,7 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 // the topological sort decide
 int poa_waves_per_cu(int ncap)
 {
-    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
     const bool lds_marks = lds_need <= 20 * 1024 && ncap < 32768;
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
@@ -834,7 +882,7 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         }
     }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
-    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
     A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
     {
         Stage st("poa_window", s);
