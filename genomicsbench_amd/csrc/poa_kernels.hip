@@ -551,100 +551,129 @@ __device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
 // "check aligned nodes" in bit 2), the DFS stack and the order being built (16-bit node ids).  The loop
 // issues no global stores (on gfx9 a load behind a store waits for the store's acknowledgement); the
 // order is written to r2n / n2r by all lanes at the end.  Same order as poa_topo_sort (poa_graph.h).
-constexpr int POA_LDS_STACK16 = 1024;
+constexpr int POA_LDS_STACK16 = 768;
 
+#ifdef GBX_POA_PHASE_STATS
+__device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo_blocks, g_topo_dfs_cycles;
+#endif
 // LDS arrays of the topological sort, persistent per wavefront for the life of a window
+constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
 struct PoaTopoLds {
     unsigned char *st8;      // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
     short *ord;              // [ncp] order under construction
     short *old;              // [ncp] rank of the node in the previous sort (-1: node added since)
     short *stk;              // [POA_LDS_STACK16] DFS stack
+    short *rec;              // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
     int n_sorted;            // nodes ranked by the previous sort
 };
 
+// Graph::topological_sort, same order as poa_topo_sort (poa_graph.h).  The walk itself is serial, but one
+// visit is done by the lanes together: lane k < 4 owns in-edge source k, lane 4+k aligned node k; they read
+// the marks of their nodes at once, a ballot says who must be pushed (in list order = lane order), the
+// pushes / the emission of the node with its aligned nodes are single LDS instructions.  A visit is four
+// dependent LDS round trips instead of one per list entry.  The walk follows the previous topological
+// order closely (one sequence changes the graph little), so the records of 64 nodes that were consecutive
+// in that order are cached in LDS and re-read when the walk has moved on (second miss in the same
+// 64-rank region); nodes added since the previous sort are read in place.
 __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
-    unsigned char *st8 = T.st8; short *ord = T.ord, *stk = T.stk, *old = T.old;
+    unsigned char *st8 = T.st8; short *ord = T.ord, *stk = T.stk, *old = T.old, *rec = T.rec;
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
     const int n_old = T.n_sorted;
     for (int i = lane; i < n; i += 64) { st8[i] = 4; if (i >= n_old) old[i] = -1; }   // mark 0, check 1
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // The walk follows the previous topological order closely (one sequence changes the graph little), so
-    // the per-node records (in-degree, aligned count, first four in-edge sources, aligned nodes) of 64 nodes
-    // that were consecutive in the previous order sit in registers, one per lane, and reach the
-    // wave-uniform DFS through v_readlane; the block is re-read when the walk has moved on (second miss
-    // in the same 64-rank region).  Nodes added since the previous sort are read in place.
     int rb = -64, miss_rb = -64;
-    int c_cnt = 0;
-    PoaInt4 c_e, c_a, c_b;
-    c_e.v[0] = c_e.v[1] = c_e.v[2] = c_e.v[3] = 0; c_a = c_e; c_b = c_e;
     auto load_block = [&](int base) {
         rb = base;
         const int id = g.r2n[min(base + lane, n_old - 1)];
-        c_cnt = (int)g.in_cnt[id] | (int)g.aln_cnt[id] << 8;
-        c_e = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
-        c_a = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
-        c_b = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+        const int cc = (int)g.in_cnt[id] | (int)g.aln_cnt[id] << 8;
+        const PoaInt4 e = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
+        const PoaInt4 a = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
+        const PoaInt4 b = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+        short *r = rec + lane * POA_REC_SHORTS;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r[k] = (short)e.v[k]; r[4 + k] = (short)a.v[k]; r[8 + k] = (short)b.v[k]; }
+        r[12] = (short)cc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    const unsigned long long below = (1ull << lane) - 1;
     int sp = 0, nr = 0;
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long tv0_ = __builtin_readcyclecounter(), nvis_ = 0, nblk_ = 0;
+#endif
     for (int i = 0; i < n; ++i) {
         if ((st8[i] & 3) != 0) continue;
         stk[sp++] = (short)i;
         while (sp) {
+#ifdef GBX_POA_PHASE_STATS
+            ++nvis_;
+#endif
             const int id = stk[sp - 1];
             const int stv = st8[id];
-            int ic, ac;
-            PoaInt4 e4, a4, b4;
+            if ((stv & 3) == 2) { --sp; continue; }
             const int o = old[id];
             if (o >= 0 && (unsigned)(o - rb) >= 64u) {          // ranked before, outside the block
                 const int mb = o & ~63;
-                if (mb == miss_rb) load_block(mb); else miss_rb = mb;
+                if (mb == miss_rb) {
+                    load_block(mb);
+#ifdef GBX_POA_PHASE_STATS
+                    ++nblk_;
+#endif
+                } else miss_rb = mb;
             }
+            // this lane's list entry and the counts
+            int cand, cc;
             const int l = o - rb;
             if (o >= 0 && (unsigned)l < 64u) {
-                const int cc = rl(c_cnt, l);
-                ic = cc & 0xff; ac = cc >> 8;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { e4.v[k] = rl(c_e.v[k], l); a4.v[k] = rl(c_a.v[k], l); b4.v[k] = rl(c_b.v[k], l); }
+                cand = rec[l * POA_REC_SHORTS + min(lane, 11)];
+                cc = (unsigned short)rec[l * POA_REC_SHORTS + 12];
             } else {
-                ic = g.in_cnt[id]; ac = g.aln_cnt[id];
-                e4 = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
-                a4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
-                b4 = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
+                cand = lane < 4 ? g.in_src[(int64_t)id * 4 + lane] : g.aln[(int64_t)id * POA_ALN_STRIDE + min(lane, 11) - 4];
+                cc = (int)g.in_cnt[id] | (int)g.aln_cnt[id] << 8;
             }
+            const int ic = cc & 0xff, ac = cc >> 8;
             const bool chk = (stv & 4) != 0;
+            const bool is_in = lane < min(ic, 4), is_al = chk && lane >= 4 && lane < 4 + ac;
+            const int sa = (is_in || is_al) ? st8[cand] : 2;
+            const bool need = (sa & 3) != 2;
             bool valid = true;
-            if ((stv & 3) != 2) {
-                for (int k = 0; k < ic; ++k) {
-                    const int b = k < 4 ? pick4(e4, k) : PG_IN_SRC(g, id, k);
-                    if ((st8[b] & 3) != 2) {
-                        if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
-                        stk[sp++] = (short)b; valid = false;
-                    }
-                }
-                if (chk) {
-                    for (int k = 0; k < ac; ++k) {
-                        const int a = k < 4 ? pick4(a4, k) : pick4(b4, k - 4);
-                        const int sa = st8[a];
-                        if ((sa & 3) != 2) {
-                            if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
-                            stk[sp++] = (short)a; st8[a] = (unsigned char)(sa & 3); valid = false;
-                        }
-                    }
-                }
-                if (valid) {
-                    st8[id] = (unsigned char)((stv & 4) | 2);
-                    if (chk) {
-                        ord[nr++] = (short)id;
-                        for (int k = 0; k < ac; ++k) ord[nr++] = (short)(k < 4 ? pick4(a4, k) : pick4(b4, k - 4));
-                    }
-                } else st8[id] = (unsigned char)((stv & 4) | 1);
+            // pushes in list order: hot in-edge sources, cold ones (rare, serial), aligned nodes
+            const unsigned long long pin = __ballot(is_in && need);
+            if (pin) {
+                if (sp + __builtin_popcountll(pin) > POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                if (is_in && need) stk[sp + __builtin_popcountll(pin & below)] = (short)cand;
+                sp += __builtin_popcountll(pin); valid = false;
             }
-            if (valid) --sp;
+            for (int k = 4; k < ic; ++k) {
+                const int b = PG_IN_SRC(g, id, k);
+                if ((st8[b] & 3) != 2) {
+                    if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                    stk[sp++] = (short)b; valid = false;
+                }
+            }
+            const unsigned long long pal = __ballot(is_al && need);
+            if (pal) {
+                if (sp + __builtin_popcountll(pal) > POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                if (is_al && need) { stk[sp + __builtin_popcountll(pal & below)] = (short)cand; st8[cand] = (unsigned char)(sa & 3); }
+                sp += __builtin_popcountll(pal); valid = false;
+            }
+            if (valid) {
+                if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 2);
+                if (chk) {
+                    if (lane == 0) ord[nr] = (short)id;
+                    if (lane >= 4 && lane < 4 + ac) ord[nr + 1 + lane - 4] = (short)cand;
+                    nr += 1 + ac;
+                }
+                --sp;
+            } else if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 1);
         }
     }
+#ifdef GBX_POA_PHASE_STATS
+    if (lane == 0) { atomicAdd(&g_topo_dfs_cycles, __builtin_readcyclecounter() - tv0_); atomicAdd(&g_topo_visits, nvis_); atomicAdd(&g_topo_blocks, nblk_); }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; old[id] = (short)r; }
@@ -654,7 +683,6 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 }
 
 #ifdef GBX_POA_PHASE_STATS
-__device__ unsigned long long g_topo_cycles, g_topo_iters;
 #define TOPO_TIMED(g) { unsigned long long t0_ = __builtin_readcyclecounter(); POA_TOPO(g); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_topo_cycles, __builtin_readcyclecounter() - t0_); atomicAdd(&g_topo_iters, (unsigned long long)g.n_nodes); } }
 #else
 #define TOPO_TIMED(g) POA_TOPO(g);
@@ -762,6 +790,7 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
     T.ord = (short *)(lds_raw + ncp);
     T.old = (short *)(lds_raw + 3 * ncp);
     T.stk = (short *)(lds_raw + 5 * ncp);
+    T.rec = T.stk + POA_LDS_STACK16;
     T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
@@ -816,7 +845,9 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 #ifdef GBX_POA_PHASE_STATS
     if ((threadIdx.x & 63) == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); }
     __syncthreads();
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; }
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles;
+    }
 #endif
 }
 
@@ -826,7 +857,7 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 // the topological sort decide
 int poa_waves_per_cu(int ncap)
 {
-    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     const bool lds_marks = lds_need <= 20 * 1024 && ncap < 32768;
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
@@ -882,7 +913,7 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         }
     }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
-    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2;
+    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
     {
         Stage st("poa_window", s);

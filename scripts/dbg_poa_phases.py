@@ -11,5 +11,6 @@ d.run(p, s); torch.cuda.synchronize()
 t = time.perf_counter(); d.run(p, s); torch.cuda.synchronize(); dt = time.perf_counter() - t
 tail = d.work[d.work_bytes - 128:].cpu().numpy().view(np.uint64)
 print("windows", n, "ms", round(dt * 1e3, 1), "cells", tail[0], "cycles dp/tb/add/cons", tail[1:5], "shares", np.round(tail[1:5] / max(1, tail[1:5].sum()), 3), flush=True)
-print("topo cycles (partial, block0 snapshot)", tail[5], "node-visits", tail[6], "cyc/node", tail[5]/max(1,tail[6]), flush=True)
-print("rows fast/slow", tail[5], tail[6], "cyc/row fast", tail[9] / max(1, tail[5]), "slow", tail[8] / max(1, tail[6]), "fence cyc per slow row", tail[7] / max(1, tail[6]), flush=True)
+print("topo (cumulative over both runs; block 0 snapshot): cycles", tail[5], "nodes", tail[6], "cyc/node", tail[5] / max(1, tail[6]),
+      "visits", tail[7], "visits/node", tail[7] / max(1, tail[6]), "block loads", tail[8], "dfs-loop cycles", tail[9],
+      "dfs cyc/visit", tail[9] / max(1, tail[7]), flush=True)
