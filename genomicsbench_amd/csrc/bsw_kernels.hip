@@ -649,7 +649,13 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     // round-robin over the longest-first list starts every group on the longest pairs together
     const bool sym = dev.oe_ins == dev.oe_del;
     const RowShape *shapes = class_shapes();
+    // the classes are independent and every kernel ends in a tail of a few long pairs: they go to four
+    // streams so that a tail overlaps the next class (GBX_BSW_SERIAL=1 keeps them on the caller's stream)
+    static const bool serial = getenv("GBX_BSW_SERIAL") != nullptr;
+    SideStreams *ss = nullptr;
+    if (!serial && ((rc = side_streams(&ss)) || (rc = ss->fork(s)))) return rc;
     for (int c = 0; c < NCLS - 1; ++c) {
+        hipStream_t sc = serial || (c & 3) == 0 ? s : ss->side[(c & 3) - 1];
         RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
         if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
         if (!k->bpc[sym]) {
@@ -660,9 +666,10 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
             }
             k->bpc[sym] = q > 8 ? 8 : q;
         }
-        Stage st(k->name, s);
-        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, s, dev, P, W, c);
+        Stage st(k->name, sc);
+        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, sc, dev, P, W, c);
     }
+    if (!serial && (rc = ss->join(s))) return rc;
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         static bool attr_set = false;
