@@ -9,6 +9,13 @@
 #
 # phmm and poa are NOT buildable here: their arithmetic lives in the GKL and
 # spoa submodules, which are empty in this checkout.
+#
+# Drop-in check (not an oracle): the reference's own, unmodified DRIVERS linked against our GPU library
+# instead of the reference kernels, to prove the boundary of include/gbx.h is the one the drivers bind:
+#   oracle/_ref/bsw_refdriver_gbx    main_banded.cpp + csrc/shims/bsw_class_shim.cpp        (no bandedSWA.cpp)
+#   oracle/_ref/chain_refdriver_gbx  main.cpp host_data_io.cpp common.cpp + chain_hostkernel_shim.cpp (no host_kernel.cpp)
+#   oracle/_ref/phmm_refdriver_gbx   PairHMMUnitTest.cpp + our libgkl_pairhmm_c.so (csrc/shims/gkl_pairhmm_shim.cpp)
+# They need genomicsbench_amd/libgbx.so (make -C genomicsbench_amd/csrc first) and a GPU at run time.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 REF="${GBX_REFERENCE_DIR:-/root/reference}"
@@ -40,4 +47,20 @@ grep -v -E '^#include "(minimap|mmpriv|kalloc)\.h"' "$CH/host_kernel.cpp" |
 $CXX -shared -fPIC -O3 -std=c++11 -fopenmp -w -I"$CH" \
     "$OUT/chain_host_kernel.o" "$HERE/ref_harness/chain_ref_shim.cpp" -o "$OUT/libchain_ref.so"
 rm -f "$OUT/chain_host_kernel.o"
+
+# ---- the reference drivers on our library (skipped until libgbx.so exists)
+PKG="$HERE/../genomicsbench_amd"
+SH="$PKG/csrc/shims"
+INC="$HERE/../include"
+if [ -f "$PKG/libgbx.so" ] && [ -f "$PKG/libgkl_pairhmm_c.so" ]; then
+    RP='-Wl,-rpath,$ORIGIN/../../genomicsbench_amd'
+    $CXX -O2 -std=c++11 -fopenmp -mavx2 -w -DSORT_PAIRS -DENABLE_PREFETCH -DBWA_OTHER_ELE=0 -I"$BSW" -I"$INC" \
+        "$BSW/main_banded.cpp" "$SH/bsw_class_shim.cpp" -L"$PKG" -lgbx "$RP" -o "$OUT/bsw_refdriver_gbx"
+    $CXX -O2 -std=c++11 -fopenmp -w -DPRINT_OUTPUT=1 -I"$CH" -I"$INC" \
+        "$CH/main.cpp" "$CH/host_data_io.cpp" "$CH/common.cpp" "$SH/chain_hostkernel_shim.cpp" \
+        -L"$PKG" -lgbx "$RP" -o "$OUT/chain_refdriver_gbx"
+    PH="$REF/benchmarks/phmm"
+    $CXX -O2 -std=c++11 -fopenmp -msse4.1 -w -DPRINT_OUTPUT -I"$PH" "$PH/PairHMMUnitTest.cpp" \
+        -L"$PKG" -lgkl_pairhmm_c -lgbx "$RP" -o "$OUT/phmm_refdriver_gbx"
+fi
 echo "built: $(ls "$OUT")"

@@ -42,6 +42,17 @@ def test_drivers_exist_and_print_usage():
     assert run([os.path.join(BIN, "chain")]).returncode != 0
 
 
+def test_gkl_dropin_library_exports_the_symbols_the_reference_driver_binds():
+    """libgkl_pairhmm_c.so (csrc/shims/gkl_pairhmm_shim.cpp): the C++-mangled names PairHMMUnitTest.cpp:84-86 declares
+    and the ConvertChar table of pairhmm_common.h:27, so that the unmodified driver links."""
+    lib = os.path.join(ROOT, "genomicsbench_amd", "libgkl_pairhmm_c.so")
+    assert os.path.exists(lib), "make -C genomicsbench_amd/csrc builds it next to libgbx.so"
+    syms = run(["nm", "-D", "--defined-only", lib]).stdout
+    for s in ("_Z11initPairHMMv", "_Z22computelikelihoodsbothP8testcasePdi", "_Z23computelikelihoodsfloatP8testcasePf",
+              "_ZN11ConvertChar15conversionTableE"):
+        assert s in syms, s
+
+
 def test_file_formats_roundtrip(data):
     d, b, c, ph, po = data
     assert gio.read_poa_windows(str(d / "poa.fasta")).window(1) == po.window(1)
