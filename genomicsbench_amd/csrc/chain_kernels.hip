@@ -90,6 +90,18 @@ __global__ void __launch_bounds__(256) chain_order_kernel(int64_t n_calls, const
 
 constexpr int RING = 256;                 // most recent anchors kept in LDS (covers the usual look-back)
 
+// Loaded values that are produced on a rare path and consumed after the paths merge make the compiler put
+// `s_waitcnt vmcnt(0)` at the merge point - which, on the common path, waits for this wavefront's
+// outstanding global *stores* (gfx9 counts them in vmcnt), a microsecond per anchor.  settle() consumes the
+// value inside the rare path, so the wait stays there.
+__device__ inline int settle(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ inline uint64_t settle(uint64_t v)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ inline uint64_t readlane64(uint64_t v, int k)
 {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, k);
@@ -134,7 +146,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         unsigned long long visited = 0;
         for (int ib = 0; ib < n; ib += 64) {
             // this block's anchors, one per lane
-            const uint64_t xa = x[min(ib + lane, n - 1)], ya = y[min(ib + lane, n - 1)];
+            const uint64_t xa = settle(x[min(ib + lane, n - 1)]), ya = settle(y[min(ib + lane, n - 1)]);
             const int kmax = min(64, n - ib);
             for (int k = 0; k < kmax; ++k) {
                 const int i = ib + k;
@@ -144,7 +156,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 // advance st (:56): first st with ri <= x[st] + max_dist_x, scanning the cached block
                 for (;;) {
                     if (st >= i) break;
-                    if (st >= sb + 64 || st < sb) { sb = st; xs = x[min(sb + lane, n - 1)]; }
+                    if (st >= sb + 64 || st < sb) { sb = st; xs = settle(x[min(sb + lane, n - 1)]); }
                     const int idx = sb + lane;
                     const bool far = idx >= st && idx < i && ri > xs + mdx;
                     const bool stop = idx >= st && !far;                  // first lane at/after st that is not far
@@ -156,20 +168,11 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 if (i - st > max_iter) st = i - max_iter;                 // :57
 
                 int max_f = q_span, max_j = -1, n_skip = 0;
-                bool fenced = false;
-                for (int jhi = i - 1; jhi >= st; jhi -= 64) {
-                    const int j = jhi - lane;
-                    const bool valid = j >= st;
-                    const int jj = valid ? j : st;
-                    uint64_t xj, yj;
-                    int fj, pj, tj;
-                    if (i - (jhi - 63) <= RING) {                         // the whole chunk is inside the ring
-                        const int rs = jj & (RING - 1);
-                        xj = rx[rs]; yj = ry[rs]; fj = rf[rs]; pj = rp[rs]; tj = rt[rs];
-                    } else {
-                        if (!fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); fenced = true; }
-                        xj = x[jj]; yj = y[jj]; fj = f[jj]; pj = p[jj]; tj = t[jj];
-                    }
+                // One 64-wide chunk of the look-back, lane 0 = anchor jhi.  Returns true when the max_skip break fired.
+                // The anchor words and DP state of the chunk arrive as arguments, so that the ring path below is
+                // made of LDS reads only: a flat / global load here would have to wait (vmcnt) for the global
+                // stores of the previous anchors, which is most of a chunk's latency.
+                auto chunk = [&](int jhi, bool valid, uint64_t xj, uint64_t yj, int fj, int pj, int tj) -> bool {
                     // ---- phase 1: candidate score / `continue` mask (:59-80)
                     const int64_t dr = (int64_t)(ri - xj);
                     const int dq = qi - (int)yj;
@@ -191,8 +194,9 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                     } else {
                         gap_cost = c_lin + (log_dd >> 1);
                     }
-                    // (int)((double)gap_cost * gap_scale + .499) with gap_scale = 1.0f is gap_cost itself unless it is negative
-                    sc -= gap_cost >= 0 ? gap_cost : (int)((double)gap_cost * 1.0 + .499);
+                    // (int)((double)gap_cost * gap_scale + .499) with gap_scale = 1.0f is gap_cost itself: gap_cost >= 0
+                    // for every lane that is not skipped (dd >= 0), and skipped lanes never use sc
+                    sc -= gap_cost;
                     sc += fj;
                     // ---- phase 2: was this j already marked as a parent during this i? (:84)
                     mark[lane] = 0;
@@ -227,15 +231,31 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         t[pj] = i;
                         if (i - pj <= RING) rt[pj & (RING - 1)] = i;
                     }
-                    if (bl < 64) break;
                     n_skip = __builtin_amdgcn_readlane(nl, 63);
-                    fenced = false;                               // later deep chunks must see these target stores
+                    return bl < 64;
+                };
+                int jhi = i - 1;
+                bool broke = false;
+                // chunks that lie inside the ring: LDS only
+                for (; jhi >= st && i - (jhi - 63) <= RING; jhi -= 64) {
+                    const int j = jhi - lane;
+                    const bool valid = j >= st;
+                    const int rs = (valid ? j : st) & (RING - 1);
+                    if ((broke = chunk(jhi, valid, rx[rs], ry[rs], rf[rs], rp[rs], rt[rs]))) break;
                 }
+                // deeper chunks: the global arrays (this wavefront's own earlier stores are visible in order)
+                if (!broke)
+                    for (; jhi >= st; jhi -= 64) {
+                        const int j = jhi - lane;
+                        const bool valid = j >= st;
+                        const int jj = valid ? j : st;
+                        if (chunk(jhi, valid, settle(x[jj]), settle(y[jj]), settle(f[jj]), settle(p[jj]), settle(t[jj]))) break;
+                    }
                 // :91-92, to the outputs and to the ring
                 int pkj = 0;
                 if (max_j >= 0) {
                     if (i - max_j <= RING) pkj = rk[max_j & (RING - 1)];
-                    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); pkj = pk[max_j]; }
+                    else pkj = settle(pk[max_j]);
                 }
                 const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
                 if (lane == 0) {
