@@ -68,6 +68,13 @@ struct PoaArgs {
     Mat2 Tc[2][4];                    // [CPL 8 | CPL 16][(T^CPL)^(1,2,4,8)]: uniform factors of the row_shr scan steps
 };
 
+constexpr int POA_SPILL_CELLS = 64 * 8;
+// Row stride of the pipelined DP: 64 lanes x 8 columns always exist in memory, so every lane issues every
+// load and store of a row (a fixed number of memory instructions per iteration lets the compiler wait for
+// exactly the loads it needs instead of for everything outstanding, stores included).
+constexpr int POA_PIPE_STRIDE = 8 + 512;
+__host__ __device__ inline int poa_cap_stride(int lmax) { const int s = poa_row_stride(lmax); return s > POA_PIPE_STRIDE ? s : POA_PIPE_STRIDE; }
+
 // byte offsets of the arrays inside one workspace slot
 struct SlotLayout {
     int64_t code, in_cnt, out_cnt, aln_cnt, out_slot, out_slot_x, mark, check, decoder, coder;
@@ -93,7 +100,9 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
-    L.mat = take((int64_t)(ncap + 1) * poa_row_stride(lmax) * 5 * (int64_t)sizeof(poa_cell_t) + 64);
+    // + a 1 KB spill row (64 lanes x 16 B) right behind the matrices: the lanes that own no column of the
+    // current sequence read and write there, so that every lane issues every memory instruction
+    L.mat = take(((int64_t)(ncap + 1) * poa_cap_stride(lmax) * 5 + POA_SPILL_CELLS) * (int64_t)sizeof(poa_cell_t) + 64);
     L.total = align_up(o, 256);
     return L;
 }
@@ -311,7 +320,7 @@ __device__ inline v8s poa_pack(const int *in)
 }
 
 __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
-                                 int &max_i, int &max_j)
+                                 poa_cell_t *spill, int &max_i, int &max_j)
 {
     constexpr int CPL = 8;
     const int lane = threadIdx.x & 63;
@@ -339,19 +348,24 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     const int j0 = lane * CPL + 1;                             // the lane's first column
-    const bool mine = j0 <= len;
+    const bool mine = j0 <= len;                               // rows are POA_PIPE_STRIDE wide: columns beyond len exist, hold garbage
     int sq[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = j <= len ? seq[j - 1] : -1; }
 
     auto fetch = [&](int prow, PoaPredIn &x) {
         const int64_t b = (int64_t)prow * Wp + POA_COL0;
-        if (mine) { x.h = *(const v8s *)(M.H + b + j0); x.f = *(const v8s *)(M.F + b + j0); x.o = *(const v8s *)(M.O + b + j0); }
+        x.h = *(const v8s *)(M.H + b + j0); x.f = *(const v8s *)(M.F + b + j0); x.o = *(const v8s *)(M.O + b + j0);
         x.h0 = M.H[b]; x.o0 = M.O[b]; x.f0 = M.F[b];
     };
     auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
         const int rr = min(r, n - 1);
         p0 = d_pred[rr]; p1 = d_pred1[rr]; p2 = d_pred2[rr]; info = d_info[rr];
+    };
+    auto settle_i = [](int &v) { asm volatile("" : "+v"(v)); };
+    auto settle_in = [&](PoaPredIn &x) {
+        asm volatile("" : "+v"(x.h), "+v"(x.f), "+v"(x.o));
+        settle_i(x.h0); settle_i(x.o0); settle_i(x.f0);
     };
 
     int best = POA_NEG_INF;
@@ -362,14 +376,18 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
     desc(0, ap0, ap1, ap2, ainfo);
     desc(1, bp0, bp1, bp2, binfo);
     PoaPredIn in0, in1, last;
-    in0.h = in0.f = in0.o = in1.h = in1.f = in1.o = last.h = last.f = last.o = (v8s)0;
-    in0.h0 = in0.o0 = in0.f0 = in1.h0 = in1.o0 = in1.f0 = last.h0 = last.o0 = last.f0 = 0;
+    last.h = last.f = last.o = (v8s)0;
+    last.h0 = last.o0 = last.f0 = 0;
     bool reg0 = false, reg1 = false;                           // predecessor k of the row at hand is the previous row
     {
         const int ic = (ainfo >> 8) & 0xff;
         fetch(ic ? ap0 : 0, in0);
-        if (ic > 1) fetch(ap1, in1);
+        fetch(ic > 1 ? ap1 : 0, in1);
     }
+    // nothing is in flight when the loop is entered: the loop's own issue order is then the only one the
+    // compiler has to reason about
+    settle_i(ap0); settle_i(ap1); settle_i(ap2); settle_i(ainfo); settle_i(bp0); settle_i(bp1); settle_i(bp2); settle_i(binfo);
+    settle_in(in0); settle_in(in1);
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
         const int p2 = ap2, info = ainfo;
@@ -398,29 +416,33 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
                 hl = hp[c];
             }
         }
-        if (ic > 1) {
+        {
+            // second predecessor: evaluated for every row (its registers hold the start row when there is none),
+            // merged only when it exists - no branch around the use of the prefetched registers
             const PoaPredIn &x = reg1 ? last : in1;
+            const bool two = ic > 1;
             int hp[CPL], fp[CPL], op[CPL];
             poa_unpack(x.h, hp); poa_unpack(x.f, fp); poa_unpack(x.o, op);
-            po = max(po, x.o0); pf = max(pf, x.f0);
+            if (two) { po = max(po, x.o0); pf = max(pf, x.f0); }
             int hl = __builtin_amdgcn_update_dpp(x.h0, hp[CPL - 1], 0x138, 0xf, 0xf, false);
             if (lane == 0) hl = x.h0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int sc = sq[c] == letter ? S.m : S.n;
-                Fa[c] = max(Fa[c], max(hp[c] + S.g, fp[c] + S.e));
-                Oa[c] = max(Oa[c], max(hp[c] + S.q, op[c] + S.c));
-                Ha[c] = max(Ha[c], hl + sc);
+                const int f2 = max(hp[c] + S.g, fp[c] + S.e), o2 = max(hp[c] + S.q, op[c] + S.c), h2 = hl + sc;
+                Fa[c] = two ? max(Fa[c], f2) : Fa[c];
+                Oa[c] = two ? max(Oa[c], o2) : Oa[c];
+                Ha[c] = two ? max(Ha[c], h2) : Ha[c];
                 hl = hp[c];
             }
         }
-        // ---- request the inputs of row r+1 now: before this row's stores, behind those of the rows before
+        // ---- request the inputs of row r+1 now: before this row's stores, behind those of the rows before.
+        // Always both predecessors (the start row stands in for a missing one; a predecessor that is this very
+        // row is read as well and ignored): a fixed number of loads per iteration.
         const int nic = (binfo >> 8) & 0xff;
         const bool nreg0 = r + 1 < n && nic >= 1 && bp0 == i, nreg1 = r + 1 < n && nic >= 2 && bp1 == i;
-        if (r + 1 < n) {
-            if (!nreg0) fetch(nic ? bp0 : 0, in0);
-            if (nic > 1 && !nreg1) fetch(bp1, in1);
-        }
+        fetch(nic >= 1 && !nreg0 ? bp0 : 0, in0);
+        fetch(nic >= 2 && !nreg1 ? bp1 : 0, in1);
         // ---- predecessors beyond the second: read in place (rare)
         if (ic > 2) {
             const int node = g.r2n[r];
@@ -428,11 +450,7 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
                 const int prow = k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1;
                 const int64_t b = (int64_t)prow * Wp + POA_COL0;
                 int hp[CPL], fp[CPL], op[CPL];
-                if (mine) { load_cells<CPL>(M.H + b + j0, hp); load_cells<CPL>(M.F + b + j0, fp); load_cells<CPL>(M.O + b + j0, op); }
-                else {
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c) { hp[c] = 0; fp[c] = 0; op[c] = 0; }
-                }
+                load_cells<CPL>(M.H + b + j0, hp); load_cells<CPL>(M.F + b + j0, fp); load_cells<CPL>(M.O + b + j0, op);
                 const int hfirst = M.H[b];
                 po = max(po, (int)M.O[b]); pf = max(pf, (int)M.F[b]);
                 int hl = __builtin_amdgcn_update_dpp(hfirst, hp[CPL - 1], 0x138, 0xf, 0xf, false);
@@ -448,10 +466,9 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
             }
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
-        if (lane == 0) {
-            M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
-            M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
-        }
+        // column 0: every lane stores the same values to the same cells
+        M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
+        M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
         const int cE = H0 + S.g, cQ = H0 + S.q;                // (E,Q) entering column 1
         int Aa[CPL];
 #pragma unroll
@@ -484,10 +501,8 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         }
         last.h = poa_pack(Hn); last.f = poa_pack(Fa); last.o = poa_pack(Oa);
         last.h0 = H0; last.o0 = O0; last.f0 = F0;
-        if (mine) {
-            *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
-            store_cells<CPL>(M.E + ro + j0, En); store_cells<CPL>(M.Q + ro + j0, Qn);
-        }
+        *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
+        store_cells<CPL>(M.E + ro + j0, En); store_cells<CPL>(M.Q + ro + j0, Qn);
         if (sink) {                                            // H(i, len)
             const int cl = (len - 1) % CPL;
             int hv = Hn[0];
@@ -813,13 +828,13 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
             const int len = A.seq_len[s];
             g.n_path = 0;
             if (g.n_nodes != 0 && len != 0 && g.err == 0) {
-                const int wp = poa_row_stride(len);
+                const int wp = len <= 512 ? POA_PIPE_STRIDE : poa_row_stride(len);
                 const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
                 PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 PH_T0
-                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mat + 5 * plane, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 poa_traceback(g, M, A.S, seq, mi, mj);
