@@ -190,7 +190,7 @@ class PoaWork:
         self.extra["dp_cells_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        return int(self.units * 19), self.units             # 5 x 2 B written + 3 x 2 B x ~1.5 predecessor rows read per cell
+        return int(self.units * 13), self.units             # 3 x 2 B written (H, F, O) + 3 x 2 B x ~1.2 predecessor rows read per cell
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O

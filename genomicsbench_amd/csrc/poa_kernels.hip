@@ -334,7 +334,6 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 
     for (int j = lane; j <= len; j += 64) {                    // row 0 (`initialize`)
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
-        M.E[j + POA_COL0] = (poa_cell_t)e0; M.Q[j + POA_COL0] = (poa_cell_t)q0;
         M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
         M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
     }
@@ -468,7 +467,6 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
         // column 0: every lane stores the same values to the same cells
         M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
-        M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
         const int cE = H0 + S.g, cQ = H0 + S.q;                // (E,Q) entering column 1
         int Aa[CPL];
 #pragma unroll
@@ -491,18 +489,17 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         if (lane == 0) { vE = SNEG; vQ = SNEG; }
         mp_apply(PC, cE, cQ, tE, tQ);                          // Tc^lane (x) the (E,Q) entering column 1
         vE = max(vE, tE); vQ = max(vQ, tQ);
-        int Hn[CPL], En[CPL], Qn[CPL];                         // pass 2: exact E, Q, H
+        int Hn[CPL];                                           // pass 2: exact H (E, Q are rebuilt by the traceback on demand)
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int h = max(Aa[c], max(vE, vQ));
-            Hn[c] = h; En[c] = vE; Qn[c] = vQ;
+            Hn[c] = h;
             const int ne = max(h + S.g, vE + S.e), nq = max(h + S.q, vQ + S.c);
             vE = ne; vQ = nq;
         }
         last.h = poa_pack(Hn); last.f = poa_pack(Fa); last.o = poa_pack(Oa);
         last.h0 = H0; last.o0 = O0; last.f0 = F0;
         *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
-        store_cells<CPL>(M.E + ro + j0, En); store_cells<CPL>(M.Q + ro + j0, Qn);
         if (sink) {                                            // H(i, len)
             const int cl = (len - 1) % CPL;
             int hv = Hn[0];
@@ -515,6 +512,145 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         ap2 = bp2; ainfo = binfo;
         bp0 = cp0; bp1 = cp1; bp2 = cp2; binfo = cinfo;
     }
+}
+
+// ---- traceback for the pipelined DP: E and Q are not stored ---------------------------------------
+// The pipelined DP writes H, F, O only (3 of the 5 planes: -40 % of the stores).  The traceback needs E and Q
+// of a row only where the path moves left (an insertion), a few per cent of its steps; there the row's E, Q
+// are rebuilt from its H by two tilted prefix-max scans, E(i,j) = max_{k<j} H(i,k) + g + (j-1-k) e (same
+// for Q with q, c) - the same integers the DP had, since H is final - one row load and ~60 instructions,
+// cached per row.  Otherwise identical to poa_traceback (poa_graph.h), which serves the stored-E/Q path.
+__device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len,
+                                   int max_i, int max_j)
+{
+    g.n_path = 0;
+    if (max_i == -1 && max_j == -1) return;
+    constexpr int CPL = 8;
+    const int lane = threadIdx.x & 63;
+    const int Wp = M.Wp;
+    const int32_t *rd_pred = g.score, *rd_info = g.pred;
+    const int j0 = lane * CPL + 1;
+    (void)len;
+    int eq_row = -1;
+    int Ec[CPL], Qc[CPL];                                      // E(eq_row, j0+c), Q(eq_row, j0+c)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { Ec[c] = 0; Qc[c] = 0; }
+    auto fill_eq = [&](int i) {
+        if (i == eq_row) return;
+        eq_row = i;
+        const int64_t b = (int64_t)i * Wp + POA_COL0;
+        int h[CPL];
+        load_cells<CPL>(M.H + b + j0, h);
+        const int h0 = M.H[b];
+        int left = __builtin_amdgcn_update_dpp(h0, h[CPL - 1], 0x138, 0xf, 0xf, false);   // H(i, j0-1)
+        if (lane == 0) left = h0;
+        // lane-local pass from the identity
+        int le = SNEG, lq = SNEG, u = left;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            le = max(u + S.g, le + S.e); lq = max(u + S.q, lq + S.c);
+            Ec[c] = le; Qc[c] = lq;
+            u = h[c];
+        }
+        // inclusive scan over the lanes with decay: x[l] = max_k<=l  last[k] + (l-k) * 8 * step
+        int xe = le, xq = lq;
+        const int de = CPL * S.e, dq = CPL * S.c;
+        xe = max(xe, dpp_i<0x111>(SNEG, xe) + de);      xq = max(xq, dpp_i<0x111>(SNEG, xq) + dq);
+        xe = max(xe, dpp_i<0x112>(SNEG, xe) + 2 * de);  xq = max(xq, dpp_i<0x112>(SNEG, xq) + 2 * dq);
+        xe = max(xe, dpp_i<0x114>(SNEG, xe) + 4 * de);  xq = max(xq, dpp_i<0x114>(SNEG, xq) + 4 * dq);
+        xe = max(xe, dpp_i<0x118>(SNEG, xe) + 8 * de);  xq = max(xq, dpp_i<0x118>(SNEG, xq) + 8 * dq);
+        xe = max(xe, dpp_i<0x142, 0xa>(SNEG, xe) + ((lane & 15) + 1) * de);  xq = max(xq, dpp_i<0x142, 0xa>(SNEG, xq) + ((lane & 15) + 1) * dq);
+        xe = max(xe, dpp_i<0x143, 0xc>(SNEG, xe) + ((lane & 31) + 1) * de);  xq = max(xq, dpp_i<0x143, 0xc>(SNEG, xq) + ((lane & 31) + 1) * dq);
+        int ie = dpp_i<0x138>(SNEG, xe), iq = dpp_i<0x138>(SNEG, xq);          // E, Q of column j0-1
+        if (lane == 0) { ie = SNEG; iq = SNEG; }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { Ec[c] = max(Ec[c], ie + (c + 1) * S.e); Qc[c] = max(Qc[c], iq + (c + 1) * S.c); }
+    };
+    auto pick = [&](const int (&a)[CPL], int j) -> int {       // a = Ec or Qc of the cached row, column j >= 1
+        const int idx = (j - 1) & 7;
+        int v = a[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) v = c == idx ? a[c] : v;
+        return __builtin_amdgcn_readlane(v, (j - 1) >> 3);
+    };
+    auto E_at = [&](int i, int j) -> int { if (j == 0) return POA_NEG_INF; fill_eq(i); return pick(Ec, j); };
+    auto Q_at = [&](int i, int j) -> int { if (j == 0) return POA_NEG_INF; fill_eq(i); return pick(Qc, j); };
+
+    int i = max_i, j = max_j, prev_i = 0, prev_j = 0, np = 0;
+#define PG_AT(A, a, b) ((int)(A)[(int64_t)(a) * Wp + (b) + POA_COL0])
+    int plo = -1, phi = -1;                      // positions come out in descending order
+#define PG_PUSH(nd, ps) do { const int ps_ = (ps); if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = ps_; } \
+                             if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; } while (0)
+    while (!(i == 0 && j == 0)) {
+        const int Hij = PG_AT(M.H, i, j);
+        bool found = false, ext_left = false, ext_up = false;
+        int node = -1, ic = 0, p0 = 0;
+        if (i != 0) { p0 = rd_pred[i - 1]; const int info = rd_info[i - 1]; ic = (info >> 8) & 0xff; node = g.r2n[i - 1];
+            if (j != 0) {
+                const int mc = (info & 0xff) == seq[j - 1] ? S.m : S.n;
+                for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                    if (Hij == PG_AT(M.H, pi, j - 1) + mc) { prev_i = pi; prev_j = j - 1; found = true; }
+                }
+            }
+            if (!found) {
+                for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                    const int fv = PG_AT(M.F, pi, j), hv = PG_AT(M.H, pi, j), ov = PG_AT(M.O, pi, j);
+                    const bool c1 = Hij == fv + S.e;
+                    const bool c2 = !c1 && Hij == hv + S.g;
+                    const bool c3 = !c1 && !c2 && Hij == ov + S.c;
+                    const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
+                    ext_up = ext_up || c1 || c3;
+                    if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; }
+                }
+            }
+        }
+        if (!found && j != 0) {
+            const int ev = E_at(i, j - 1), hv = PG_AT(M.H, i, j - 1), qv = Q_at(i, j - 1);
+            const bool c1 = Hij == ev + S.e;
+            const bool c2 = !c1 && Hij == hv + S.g;
+            const bool c3 = !c1 && !c2 && Hij == qv + S.c;
+            const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
+            ext_left = c1 || c3;
+            if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; }
+        }
+        PG_PUSH(i == prev_i ? -1 : node, j == prev_j ? -1 : j - 1);
+        i = prev_i; j = prev_j;
+        if (ext_left) {
+            for (;;) {
+                PG_PUSH(-1, j - 1);
+                --j;
+                if (E_at(i, j) + S.e != E_at(i, j + 1) && Q_at(i, j) + S.c != Q_at(i, j + 1)) break;
+            }
+        } else if (ext_up) {
+            for (;;) {
+                bool stop = false;
+                prev_i = 0;
+                const int nd = g.r2n[i - 1];
+                const int icu = (rd_info[i - 1] >> 8) & 0xff;
+                const int fij = PG_AT(M.F, i, j), oij = PG_AT(M.O, i, j);
+                for (int p = 0; p < icu; ++p) {
+                    const int pi = p ? g.n2r[PG_IN_SRC(g, nd, p)] + 1 : rd_pred[i - 1];
+                    const int hv = PG_AT(M.H, pi, j);
+                    const bool s1 = fij == hv + S.g;
+                    const bool s2 = !s1 && fij == PG_AT(M.F, pi, j) + S.e;
+                    const bool s3 = !s1 && !s2 && oij == hv + S.q;
+                    const bool s4 = !s1 && !s2 && !s3 && oij == PG_AT(M.O, pi, j) + S.c;
+                    if (s1) stop = true; else if (s2) stop = false; else stop = s3;
+                    if (s1 || s2 || s3 || s4) { prev_i = pi; break; }
+                }
+                PG_PUSH(nd, -1);
+                i = prev_i;
+                if (stop || i == 0) break;
+            }
+        }
+        if (np > g.aln_path_cap) { g.err |= POA_ERR_NODES; break; }
+    }
+#undef PG_AT
+#undef PG_PUSH
+    g.n_path = np <= g.aln_path_cap ? np : 0;
+    g.path_lo = plo; g.path_hi = phi;
 }
 
 // ---- Graph::add_alignment, wavefront version --------------------------------------------------
@@ -837,7 +973,8 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
                 if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mat + 5 * plane, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
-                poa_traceback(g, M, A.S, seq, mi, mj);
+                if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+                else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
             }
             {
