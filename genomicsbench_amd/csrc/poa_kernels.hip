@@ -306,31 +306,57 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
 // without a fence.
 struct PoaPredIn { v8s h, f, o; int h0, o0, f0; };
 
-__device__ inline void poa_unpack(const v8s &t, int *out)
+// ---- packed int16 arithmetic of the pipelined DP --------------------------------------------------
+// Cells are int16 in memory; the row arithmetic stays in packed int16 (two columns, or the (E,Q) pair,
+// per register; v_pk_add_i16 with clamp, v_pk_max_i16, op_sel for swaps and broadcasts): half the
+// instructions and registers of the int32 form, and no unpack / pack.  -32768 is the identity of the
+// max-plus scan (saturating adds keep it there); real scores stay above -30000 (host plan), so the
+// results are the integers of the int32 formulation.
+typedef short v2s __attribute__((ext_vector_type(2)));
+constexpr short PK_NEG = -32768;
+__device__ inline v2s pk2(int lo, int hi) { v2s r; r.x = (short)lo; r.y = (short)hi; return r; }
+__device__ inline v2s pk_sat(int lo, int hi) { return pk2(max(lo, -32768), max(hi, -32768)); }      // clamp of -inf entries
+__device__ inline v2s pk_add(v2s a, v2s b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ inline v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ inline v2s pk_swap(v2s a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ inline v2s pk_lo(v2s a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ inline v2s pk_hi(v2s a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ inline unsigned pk_bits(v2s a) { return __builtin_bit_cast(unsigned, a); }
+__device__ inline v2s pk_from(unsigned u) { return __builtin_bit_cast(v2s, u); }
+template <int K> __device__ inline v2s pk_pair(const v8s &x) { return __builtin_shufflevector(x, x, 2 * K, 2 * K + 1); }
+__device__ inline v8s pk_join(v2s a, v2s b, v2s c, v2s d)
 {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = t[e];
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const v4s lo = __builtin_shufflevector(a, b, 0, 1, 2, 3), hi = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-__device__ inline v8s poa_pack(const int *in)
+template <int CTRL, int ROWMASK = 0xf>
+__device__ inline v2s pk_dpp(v2s old, v2s x)
 {
-    v8s t;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = (short)in[e];
-    return t;
+    return pk_from((unsigned)__builtin_amdgcn_update_dpp((int)pk_bits(old), (int)pk_bits(x), CTRL, ROWMASK, 0xf, false));
 }
+// 2x2 max-plus matrix as two packed columns: AC = (a, c), BD = (b, d);  m (x) (E,Q) = max(AC + (E,E), BD + (Q,Q))
+struct PkMat { v2s ac, bd; };
+__device__ inline PkMat pk_mat(const Mat2 &m) { PkMat r; r.ac = pk_sat(m.a, m.c); r.bd = pk_sat(m.b, m.d); return r; }
+__device__ inline v2s pk_apply(const PkMat &m, v2s eq) { return pk_max(pk_add(m.ac, pk_lo(eq)), pk_add(m.bd, pk_hi(eq))); }
 
 __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
                                  poa_cell_t *spill, int &max_i, int &max_j)
 {
+    (void)spill;
     constexpr int CPL = 8;
     const int lane = threadIdx.x & 63;
     const PoaScore S = A.S;
     const int Wp = M.Wp;
     const int n = g.n_nodes;
     const Mat2 *Tc = A.Tc[0];
-    const Mat2 P16 = mp_pow(Tc[0], (lane & 15) + 1);
-    const Mat2 P32 = mp_pow(Tc[0], (lane & 31) + 1);
-    const Mat2 PC = mp_pow(Tc[0], lane);
+    const PkMat T0 = pk_mat(Tc[0]), T1 = pk_mat(Tc[1]), T2 = pk_mat(Tc[2]), T3 = pk_mat(Tc[3]);
+    const PkMat P16 = pk_mat(mp_pow(Tc[0], (lane & 15) + 1));
+    const PkMat P32 = pk_mat(mp_pow(Tc[0], (lane & 31) + 1));
+    const PkMat PC = pk_mat(mp_pow(Tc[0], lane));
+    const v2s G2 = pk2(S.g, S.g), E2 = pk2(S.e, S.e), Q2 = pk2(S.q, S.q), C2 = pk2(S.c, S.c);
+    const v2s GQ = pk2(S.g, S.q), EC = pk2(S.e, S.c), NM = pk2(S.n - S.m, S.n - S.m), MM = pk2(S.m, S.m);
+    const v2s NEG2 = pk2(PK_NEG, PK_NEG);
 
     for (int j = lane; j <= len; j += 64) {                    // row 0 (`initialize`)
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
@@ -348,9 +374,14 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 
     const int j0 = lane * CPL + 1;                             // the lane's first column
     const bool mine = j0 <= len;                               // rows are POA_PIPE_STRIDE wide: columns beyond len exist, hold garbage
-    int sq[CPL];
+    v2s sqp[4];                                                // sequence letters of the lane's columns, two per register
+    {
+        int sq[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = j <= len ? seq[j - 1] : -1; }
+        for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = j <= len ? seq[j - 1] : 0x7fff; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sqp[k] = pk2(sq[2 * k], sq[2 * k + 1]);
+    }
 
     auto fetch = [&](int prow, PoaPredIn &x) {
         const int64_t b = (int64_t)prow * Wp + POA_COL0;
@@ -365,6 +396,23 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
     auto settle_in = [&](PoaPredIn &x) {
         asm volatile("" : "+v"(x.h), "+v"(x.f), "+v"(x.o));
         settle_i(x.h0); settle_i(x.o0); settle_i(x.f0);
+    };
+    // F, O and diagonal-H contributions of one predecessor row to the lane's columns (packed pairs)
+    auto pred_terms = [&](const PoaPredIn &x, const v2s (&sc)[4], v2s (&F)[4], v2s (&O)[4], v2s (&H)[4]) {
+        const v2s hp[4] = {pk_pair<0>(x.h), pk_pair<1>(x.h), pk_pair<2>(x.h), pk_pair<3>(x.h)};
+        const v2s fp[4] = {pk_pair<0>(x.f), pk_pair<1>(x.f), pk_pair<2>(x.f), pk_pair<3>(x.f)};
+        const v2s op[4] = {pk_pair<0>(x.o), pk_pair<1>(x.o), pk_pair<2>(x.o), pk_pair<3>(x.o)};
+        // H(pred, j0-1): high half of the previous lane's last pair, or column 0 for lane 0
+        unsigned left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk_bits(hp[3]), 0x138, 0xf, 0xf, false);
+        if (lane == 0) left = (unsigned)x.h0 << 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            F[k] = pk_max(pk_add(hp[k], G2), pk_add(fp[k], E2));
+            O[k] = pk_max(pk_add(hp[k], Q2), pk_add(op[k], C2));
+            const unsigned prev = k ? pk_bits(hp[k - 1]) : left;
+            const v2s hs = pk_from(__builtin_amdgcn_alignbit(pk_bits(hp[k]), prev, 16));      // (H[j-1]) of the pair's columns
+            H[k] = pk_add(hs, sc[k]);
+        }
     };
 
     int best = POA_NEG_INF;
@@ -396,43 +444,34 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         int cp0, cp1, cp2, cinfo;                              // row r+2
         desc(r + 2, cp0, cp1, cp2, cinfo);
 
+        // match / mismatch score of the lane's columns against this row's letter: m + (n-m) * (seq != letter)
+        v2s sc[4];
+        {
+            const v2s LL = pk2(letter, letter);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sc[k] = __builtin_elementwise_min(sqp[k] ^ LL, pk2(1, 1)) * NM + MM;
+        }
         // ---- inputs of this row out of the prefetch registers (or the previous row's registers)
-        int Fa[CPL], Oa[CPL], Ha[CPL];
+        v2s Fa[4], Oa[4], Ha[4];
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
         {
             const PoaPredIn &x = reg0 ? last : in0;
-            int hp[CPL], fp[CPL], op[CPL];
-            poa_unpack(x.h, hp); poa_unpack(x.f, fp); poa_unpack(x.o, op);
             if (ic > 0) { po = max(po, x.o0); pf = max(pf, x.f0); }
-            int hl = __builtin_amdgcn_update_dpp(x.h0, hp[CPL - 1], 0x138, 0xf, 0xf, false);
-            if (lane == 0) hl = x.h0;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int sc = sq[c] == letter ? S.m : S.n;
-                Fa[c] = max(hp[c] + S.g, fp[c] + S.e);
-                Oa[c] = max(hp[c] + S.q, op[c] + S.c);
-                Ha[c] = hl + sc;
-                hl = hp[c];
-            }
+            pred_terms(x, sc, Fa, Oa, Ha);
         }
         {
             // second predecessor: evaluated for every row (its registers hold the start row when there is none),
             // merged only when it exists - no branch around the use of the prefetched registers
             const PoaPredIn &x = reg1 ? last : in1;
             const bool two = ic > 1;
-            int hp[CPL], fp[CPL], op[CPL];
-            poa_unpack(x.h, hp); poa_unpack(x.f, fp); poa_unpack(x.o, op);
             if (two) { po = max(po, x.o0); pf = max(pf, x.f0); }
-            int hl = __builtin_amdgcn_update_dpp(x.h0, hp[CPL - 1], 0x138, 0xf, 0xf, false);
-            if (lane == 0) hl = x.h0;
+            v2s F2[4], O2[4], H2[4];
+            pred_terms(x, sc, F2, O2, H2);
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int sc = sq[c] == letter ? S.m : S.n;
-                const int f2 = max(hp[c] + S.g, fp[c] + S.e), o2 = max(hp[c] + S.q, op[c] + S.c), h2 = hl + sc;
-                Fa[c] = two ? max(Fa[c], f2) : Fa[c];
-                Oa[c] = two ? max(Oa[c], o2) : Oa[c];
-                Ha[c] = two ? max(Ha[c], h2) : Ha[c];
-                hl = hp[c];
+            for (int k = 0; k < 4; ++k) {
+                Fa[k] = two ? pk_max(Fa[k], F2[k]) : Fa[k];
+                Oa[k] = two ? pk_max(Oa[k], O2[k]) : Oa[k];
+                Ha[k] = two ? pk_max(Ha[k], H2[k]) : Ha[k];
             }
         }
         // ---- request the inputs of row r+1 now: before this row's stores, behind those of the rows before.
@@ -447,65 +486,64 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
             const int node = g.r2n[r];
             for (int k = 2; k < ic; ++k) {
                 const int prow = k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1;
-                const int64_t b = (int64_t)prow * Wp + POA_COL0;
-                int hp[CPL], fp[CPL], op[CPL];
-                load_cells<CPL>(M.H + b + j0, hp); load_cells<CPL>(M.F + b + j0, fp); load_cells<CPL>(M.O + b + j0, op);
-                const int hfirst = M.H[b];
-                po = max(po, (int)M.O[b]); pf = max(pf, (int)M.F[b]);
-                int hl = __builtin_amdgcn_update_dpp(hfirst, hp[CPL - 1], 0x138, 0xf, 0xf, false);
-                if (lane == 0) hl = hfirst;
+                PoaPredIn x;
+                fetch(prow, x);
+                po = max(po, x.o0); pf = max(pf, x.f0);
+                v2s F2[4], O2[4], H2[4];
+                pred_terms(x, sc, F2, O2, H2);
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const int sc = sq[c] == letter ? S.m : S.n;
-                    Fa[c] = max(Fa[c], max(hp[c] + S.g, fp[c] + S.e));
-                    Oa[c] = max(Oa[c], max(hp[c] + S.q, op[c] + S.c));
-                    Ha[c] = max(Ha[c], hl + sc);
-                    hl = hp[c];
-                }
+                for (int q = 0; q < 4; ++q) { Fa[q] = pk_max(Fa[q], F2[q]); Oa[q] = pk_max(Oa[q], O2[q]); Ha[q] = pk_max(Ha[q], H2[q]); }
             }
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
         // column 0: every lane stores the same values to the same cells
         M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
-        const int cE = H0 + S.g, cQ = H0 + S.q;                // (E,Q) entering column 1
-        int Aa[CPL];
+        const v2s cEQ = pk2(H0 + S.g, H0 + S.q);               // (E,Q) entering column 1
+        v2s Aa[4];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) Aa[c] = mine ? max(Ha[c], max(Fa[c], Oa[c])) : SNEG;
-        int bE = SNEG, bQ = SNEG;                              // pass 1: lane-local recurrence from the identity
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int h = max(Aa[c], max(bE, bQ));
-            const int ne = max(h + S.g, bE + S.e), nq = max(h + S.q, bQ + S.c);
-            bE = ne; bQ = nq;
-        }
-        int xE = bE, xQ = bQ, tE, tQ;                          // inclusive scan over the lanes
-        mp_apply(Tc[0], dpp_i<0x111>(SNEG, xE), dpp_i<0x111>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        mp_apply(Tc[1], dpp_i<0x112>(SNEG, xE), dpp_i<0x112>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        mp_apply(Tc[2], dpp_i<0x114>(SNEG, xE), dpp_i<0x114>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        mp_apply(Tc[3], dpp_i<0x118>(SNEG, xE), dpp_i<0x118>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        mp_apply(P16, dpp_i<0x142, 0xa>(SNEG, xE), dpp_i<0x142, 0xa>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        mp_apply(P32, dpp_i<0x143, 0xc>(SNEG, xE), dpp_i<0x143, 0xc>(SNEG, xQ), tE, tQ); xE = max(xE, tE); xQ = max(xQ, tQ);
-        int vE = dpp_i<0x138>(SNEG, xE), vQ = dpp_i<0x138>(SNEG, xQ);
-        if (lane == 0) { vE = SNEG; vQ = SNEG; }
-        mp_apply(PC, cE, cQ, tE, tQ);                          // Tc^lane (x) the (E,Q) entering column 1
-        vE = max(vE, tE); vQ = max(vQ, tQ);
-        int Hn[CPL];                                           // pass 2: exact H (E, Q are rebuilt by the traceback on demand)
+        for (int k = 0; k < 4; ++k) Aa[k] = mine ? pk_max(Ha[k], pk_max(Fa[k], Oa[k])) : NEG2;
+        // pass 1: lane-local (E,Q) recurrence from the identity; column c sits in half c&1 of pair c>>1
+        v2s bEQ = NEG2;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int h = max(Aa[c], max(vE, vQ));
-            Hn[c] = h;
-            const int ne = max(h + S.g, vE + S.e), nq = max(h + S.q, vQ + S.c);
-            vE = ne; vQ = nq;
+            const v2s a = (c & 1) ? pk_hi(Aa[c >> 1]) : pk_lo(Aa[c >> 1]);
+            const v2s h = pk_max(a, pk_max(bEQ, pk_swap(bEQ)));
+            bEQ = pk_max(pk_add(h, GQ), pk_add(bEQ, EC));
         }
-        last.h = poa_pack(Hn); last.f = poa_pack(Fa); last.o = poa_pack(Oa);
+        // inclusive scan over the lanes: x[l] = max_k<=l Tc^(l-k) (x) b[k]
+        v2s x = bEQ;
+        x = pk_max(x, pk_apply(T0, pk_dpp<0x111>(NEG2, x)));
+        x = pk_max(x, pk_apply(T1, pk_dpp<0x112>(NEG2, x)));
+        x = pk_max(x, pk_apply(T2, pk_dpp<0x114>(NEG2, x)));
+        x = pk_max(x, pk_apply(T3, pk_dpp<0x118>(NEG2, x)));
+        x = pk_max(x, pk_apply(P16, pk_dpp<0x142, 0xa>(NEG2, x)));
+        x = pk_max(x, pk_apply(P32, pk_dpp<0x143, 0xc>(NEG2, x)));
+        v2s vEQ = pk_dpp<0x138>(NEG2, x);                      // (E,Q) entering this lane from the lanes before
+        if (lane == 0) vEQ = NEG2;
+        vEQ = pk_max(vEQ, pk_apply(PC, cEQ));                  // (+) Tc^lane (x) the (E,Q) entering column 1
+        // pass 2: exact H (E, Q are rebuilt by the traceback on demand)
+        v2s hcol[CPL];                                         // both halves = H of column c
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const v2s a = (c & 1) ? pk_hi(Aa[c >> 1]) : pk_lo(Aa[c >> 1]);
+            const v2s h = pk_max(a, pk_max(vEQ, pk_swap(vEQ)));
+            hcol[c] = h;
+            vEQ = pk_max(pk_add(h, GQ), pk_add(vEQ, EC));
+        }
+        v2s Hn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Hn[k] = __builtin_shufflevector(hcol[2 * k], hcol[2 * k + 1], 0, 3);
+        last.h = pk_join(Hn[0], Hn[1], Hn[2], Hn[3]);
+        last.f = pk_join(Fa[0], Fa[1], Fa[2], Fa[3]);
+        last.o = pk_join(Oa[0], Oa[1], Oa[2], Oa[3]);
         last.h0 = H0; last.o0 = O0; last.f0 = F0;
         *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
         if (sink) {                                            // H(i, len)
             const int cl = (len - 1) % CPL;
-            int hv = Hn[0];
+            v2s hv = hcol[0];
 #pragma unroll
-            for (int c = 1; c < CPL; ++c) hv = c == cl ? Hn[c] : hv;
-            const int hlast = __builtin_amdgcn_readlane(hv, (len - 1) / CPL);
+            for (int c = 1; c < CPL; ++c) hv = c == cl ? hcol[c] : hv;
+            const int hlast = (int)(short)__builtin_amdgcn_readlane((int)pk_bits(hv), (len - 1) / CPL);
             if (best < hlast) { best = hlast; max_i = i; max_j = len; }
         }
         reg0 = nreg0; reg1 = nreg1;
