@@ -23,6 +23,7 @@
 //     consensus are inherently serial; every lane of the wave executes them
 //     with identical (wave-uniform) data, so no election or broadcast is needed.
 #include <algorithm>
+#include <cstdlib>
 #include "gbx_internal.h"
 #include "poa_graph.h"
 
@@ -749,7 +750,6 @@ __device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo
 constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
 struct PoaTopoLds {
     unsigned char *st8;      // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
-    short *ord;              // [ncp] order under construction
     short *old;              // [ncp] rank of the node in the previous sort (-1: node added since)
     short *stk;              // [POA_LDS_STACK16] DFS stack
     short *rec;              // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
@@ -766,7 +766,10 @@ struct PoaTopoLds {
 // 64-rank region); nodes added since the previous sort are read in place.
 __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
-    unsigned char *st8 = T.st8; short *ord = T.ord, *stk = T.stk, *old = T.old, *rec = T.rec;
+    unsigned char *st8 = T.st8; short *stk = T.stk, *old = T.old, *rec = T.rec;
+    int32_t *ord = g.stack;                                    // the order under construction goes to global memory (the
+                                                               // global DFS-stack area is free here): stores only, nothing in
+                                                               // the walk waits for them; r2n still holds the previous order
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
     const int n_old = T.n_sorted;
@@ -852,8 +855,8 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
             if (valid) {
                 if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 2);
                 if (chk) {
-                    if (lane == 0) ord[nr] = (short)id;
-                    if (lane >= 4 && lane < 4 + ac) ord[nr + 1 + lane - 4] = (short)cand;
+                    if (lane == 0) ord[nr] = id;
+                    if (lane >= 4 && lane < 4 + ac) ord[nr + 1 + lane - 4] = cand;
                     nr += 1 + ac;
                 }
                 --sp;
@@ -955,7 +958,7 @@ __device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len,
     TOPO_TIMED(g)
 }
 
-__global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
+__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
     PoaGraph g;
@@ -976,9 +979,8 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
     // serial DFS state on chip (LDS): state byte per node, order under construction, stack
     PoaTopoLds T;
     T.st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
-    T.ord = (short *)(lds_raw + ncp);
-    T.old = (short *)(lds_raw + 3 * ncp);
-    T.stk = (short *)(lds_raw + 5 * ncp);
+    T.old = (short *)(lds_raw + ncp);
+    T.stk = (short *)(lds_raw + 3 * ncp);
     T.rec = T.stk + POA_LDS_STACK16;
     T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
@@ -1047,12 +1049,19 @@ __global__ void __launch_bounds__(64, 2) poa_kernel(PoaArgs A, SlotLayout L)
 // the topological sort decide
 int poa_waves_per_cu(int ncap)
 {
-    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
+    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     const bool lds_marks = lds_need <= 20 * 1024 && ncap < 32768;
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
         (void)hipGetLastError();
         q = 8;
+    }
+    // measured on MI355X (6144 windows): 6 per CU 743 ms, 8: 628, 10: 607, 12: 632 - the kernel is bound by
+    // instruction issue from ~8 wavefronts per CU on, more windows in flight only cost workspace
+    if (q > 10) q = 10;
+    if (const char *e = getenv("GBX_POA_WAVES_PER_CU")) {      // tuning aid: fewer windows in flight than the hardware admits
+        const int v = atoi(e);
+        if (v >= 1 && v < q) q = v;
     }
     return q;
 }
@@ -1103,7 +1112,7 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         }
     }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
-    const size_t lds_need = (size_t)5 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
+    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
     {
         Stage st("poa_window", s);
