@@ -205,17 +205,29 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                     const bool hit = (tj == i) || mark[lane] != 0;
                     // ---- phase 3: ordered max_f / n_skip / break (:81-88)
                     const unsigned cand = skip ? 0u : (unsigned)sc + UBIAS;      // biased: 0 = "no candidate"
-                    const unsigned pm = wave_scan_umax(cand);                     // inclusive prefix max of candidates
-                    unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);             // exclusive (wave_shr:1)
-                    pmx = lane == 0 ? 0u : pmx;
-                    const bool improving = !skip && cand > max((unsigned)max_f + UBIAS, pmx);
-                    const bool bump = !skip && !improving && hit;
-                    const int d = improving ? -1 : (bump ? 1 : 0);
-                    const int S = n_skip + wave_scan_add(d);
-                    // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
-                    const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
-                    const int mn = -(int)(mx - UBIAS);
-                    const int nl = S - min(0, mn);
+                    bool improving, bump;
+                    int nl;                                                       // n_skip after this lane
+                    if (__ballot(cand > (unsigned)max_f + UBIAS) == 0) {
+                        // no lane beats max_f (the usual case beyond the first chunk): nobody improves, n_skip only
+                        // counts the marked lanes - a prefix popcount instead of three wave scans
+                        improving = false;
+                        bump = !skip && hit;
+                        const unsigned long long bm = __ballot(bump);
+                        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+                        nl = n_skip + below + (bump ? 1 : 0);
+                    } else {
+                        const unsigned pm = wave_scan_umax(cand);                 // inclusive prefix max of candidates
+                        unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);         // exclusive (wave_shr:1)
+                        pmx = lane == 0 ? 0u : pmx;
+                        improving = !skip && cand > max((unsigned)max_f + UBIAS, pmx);
+                        bump = !skip && !improving && hit;
+                        const int d = improving ? -1 : (bump ? 1 : 0);
+                        const int S = n_skip + wave_scan_add(d);
+                        // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
+                        const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
+                        const int mn = -(int)(mx - UBIAS);
+                        nl = S - min(0, mn);
+                    }
                     const unsigned long long brk = __ballot(bump && nl > max_skip);
                     const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
                     const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
