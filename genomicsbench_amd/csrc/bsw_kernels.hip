@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
 // SYM: o_ins+e_ins == o_del+e_del, the gap-open term of E and F is shared.
 // the register budget is pinned per CPL (second launch-bound = wavefronts per SIMD) so that the wide
 // shapes keep 4 wavefronts per SIMD resident
-constexpr int rows_min_waves(int cpl) { return cpl >= 12 ? 4 : cpl >= 9 ? 5 : cpl >= 7 ? 6 : cpl >= 5 ? 7 : 1; }
+constexpr int rows_min_waves(int cpl) { return cpl >= 20 ? 3 : cpl >= 12 ? 4 : cpl >= 9 ? 5 : cpl >= 7 ? 6 : cpl >= 5 ? 7 : 1; }
 
 template <int LPP, int CPL, bool SYM>
 __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswD
     constexpr int GROUPS_PER_BLOCK = 256 / LPP;
     constexpr int NQ = (CPL + 3) / 4;            // query codes, one byte per column: selectors of v_perm_b32
     static_assert(LPP * CPL <= (1 << KB), "column index must fit the key");
-    static_assert(CPL <= 16, "in-lane column index uses 4 bits");
+    static_assert(CPL <= 32, "in-lane column index uses 5 bits");
 
     // scoring-matrix row of the current target base: 5 signed bytes {row0 = q 0..3, row1 = q 4}
     __shared__ uint2 s_row[8];
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswD
             hl = pr ? h : hl;                                          // h of the last live column in this lane
             h = pr ? h : 0;
             G[c] = h;
-            kl = max(kl, (h << 4) | c);
+            kl = max(kl, (h << 5) | c);
         }
         // column 0 takes the previous lane's last h; the pair's column 0 takes the first-column value
         const int hin = group_shift_up<LPP>(G[CPL - 1], left0, gl);
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswD
         Hs[CPL] = 0;                                                   // column (gl+1)*CPL lives in the next lane
 
         // group reductions
-        const int key = group_allmax<LPP>(((kl >> 4) << KB) | (j0 + (kl & 15)));
+        const int key = group_allmax<LPP>(((kl >> 5) << KB) | (j0 + (kl & 31)));
         const int m = key >> KB, mj = key & ((1 << KB) - 1);
         const int zf_l = zm ? j0 + (__builtin_ffs((int)zm) - 1) : BIGJ;
         const int zl_l = zm ? j0 + (31 - __builtin_clz(zm)) : -1;
@@ -539,6 +539,7 @@ struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
 #define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
 RowKernel row_kernels[] = {
     GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(4, 16),
+    GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 24),
     GBX_ROW_KERNEL(8, 2),  GBX_ROW_KERNEL(8, 4),  GBX_ROW_KERNEL(8, 6),  GBX_ROW_KERNEL(8, 8),
     GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12), GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 16),
     GBX_ROW_KERNEL(16, 1), GBX_ROW_KERNEL(16, 2), GBX_ROW_KERNEL(16, 3), GBX_ROW_KERNEL(16, 4),
@@ -560,7 +561,7 @@ RowKernel *find_row_kernel(int lpp, int cpl)
 // cover their class or have no kernel are ignored.
 const RowShape *class_shapes()
 {
-    static RowShape shapes[NCLS - 1] = {{4, 4}, {4, 8}, {4, 12}, {4, 16}, {8, 10}, {8, 12}, {8, 14}, {8, 16},
+    static RowShape shapes[NCLS - 1] = {{4, 4}, {4, 8}, {4, 12}, {4, 16}, {4, 20}, {4, 24}, {8, 14}, {8, 16},
                                         {16, 10}, {16, 12}, {16, 16}, {64, 16}};
     static bool parsed = false;
     if (!parsed) {
