@@ -80,7 +80,7 @@ __device__ inline int dpp(int old, int x)
 }
 
 // ---- group primitives -----------------------------------------------------
-// A group is LPP consecutive lanes (4, 8, 16 or 64) that own one pair.
+// A group is LPP consecutive lanes (2, 4, 8, 16 or 64) that own one pair.
 // mov_dpp with an undefined `old` and bound_ctrl:1 (out-of-row lanes read 0) lets the compiler fold the
 // move into the consumer (v_max_i32_dpp): one VALU op per scan / reduce step.  max is idempotent, so a
 // lane that reads itself (quad_perm patterns below) is harmless.
@@ -94,6 +94,7 @@ __device__ inline int dppz(int x)
 template <int LPP>
 __device__ inline int group_scan_max(int x)
 {
+    if (LPP == 2) return max(x, dppz<0xa0>(x));           // quad_perm [0,0,2,2]
     if (LPP <= 8) {
         x = max(x, dppz<0x90>(x));                        // quad_perm [0,0,1,2]
         x = max(x, dppz<0x40>(x));                        // quad_perm [0,0,0,1]: prefix inside each quad
@@ -126,6 +127,7 @@ __device__ inline int group_shift_up(int x, int fill, int gl)
 template <int LPP>
 __device__ inline int group_allmax(int x)
 {
+    if (LPP == 2) return max(x, dppz<0xb1>(x));           // quad_perm [1,0,3,2]
     if (LPP <= 8) {
         x = max(x, dppz<0xb1>(x));                        // quad_perm [1,0,3,2]
         x = max(x, dppz<0x4e>(x));                        // quad_perm [2,3,0,1]
@@ -538,6 +540,7 @@ typedef void (*RowsFn)(BswDev, BswPairs, BswWork, int);
 struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
 #define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
 RowKernel row_kernels[] = {
+    GBX_ROW_KERNEL(2, 8),  GBX_ROW_KERNEL(2, 16), GBX_ROW_KERNEL(2, 24),
     GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(4, 16),
     GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 24),
     GBX_ROW_KERNEL(8, 2),  GBX_ROW_KERNEL(8, 4),  GBX_ROW_KERNEL(8, 6),  GBX_ROW_KERNEL(8, 8),
@@ -561,7 +564,7 @@ RowKernel *find_row_kernel(int lpp, int cpl)
 // cover their class or have no kernel are ignored.
 const RowShape *class_shapes()
 {
-    static RowShape shapes[NCLS - 1] = {{4, 4}, {4, 8}, {4, 12}, {4, 16}, {4, 20}, {4, 24}, {8, 14}, {8, 16},
+    static RowShape shapes[NCLS - 1] = {{2, 8}, {2, 16}, {2, 24}, {4, 16}, {4, 20}, {4, 24}, {8, 14}, {8, 16},
                                         {16, 10}, {16, 12}, {16, 16}, {64, 16}};
     static bool parsed = false;
     if (!parsed) {
