@@ -540,14 +540,15 @@ typedef void (*RowsFn)(BswDev, BswPairs, BswWork, int);
 struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
 #define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
 RowKernel row_kernels[] = {
+    // the default table (class_shapes) ...
     GBX_ROW_KERNEL(2, 8),  GBX_ROW_KERNEL(2, 16), GBX_ROW_KERNEL(2, 24),
-    GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(4, 16),
-    GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 24),
-    GBX_ROW_KERNEL(8, 2),  GBX_ROW_KERNEL(8, 4),  GBX_ROW_KERNEL(8, 6),  GBX_ROW_KERNEL(8, 8),
-    GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12), GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 16),
-    GBX_ROW_KERNEL(16, 1), GBX_ROW_KERNEL(16, 2), GBX_ROW_KERNEL(16, 3), GBX_ROW_KERNEL(16, 4),
-    GBX_ROW_KERNEL(16, 5), GBX_ROW_KERNEL(16, 6), GBX_ROW_KERNEL(16, 7), GBX_ROW_KERNEL(16, 8),
+    GBX_ROW_KERNEL(4, 16), GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 24),
+    GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 16),
     GBX_ROW_KERNEL(16, 10), GBX_ROW_KERNEL(16, 12), GBX_ROW_KERNEL(16, 16), GBX_ROW_KERNEL(64, 16),
+    // ... and the alternatives scripts/tune_bsw_shapes.sh compares them with
+    GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12),
+    GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12),
+    GBX_ROW_KERNEL(16, 4), GBX_ROW_KERNEL(16, 6), GBX_ROW_KERNEL(16, 8),
 };
 #undef GBX_ROW_KERNEL
 // widest query a class holds: classes 0..7 = 16,32,..,128; 8..11 = 160,192,256,1024

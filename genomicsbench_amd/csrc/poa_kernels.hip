@@ -69,7 +69,6 @@ struct PoaArgs {
     Mat2 Tc[2][4];                    // [CPL 8 | CPL 16][(T^CPL)^(1,2,4,8)]: uniform factors of the row_shr scan steps
 };
 
-constexpr int POA_SPILL_CELLS = 64 * 8;
 // Row stride of the pipelined DP: 64 lanes x 8 columns always exist in memory, so every lane issues every
 // load and store of a row (a fixed number of memory instructions per iteration lets the compiler wait for
 // exactly the loads it needs instead of for everything outstanding, stores included).
@@ -101,9 +100,7 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
-    // + a 1 KB spill row (64 lanes x 16 B) right behind the matrices: the lanes that own no column of the
-    // current sequence read and write there, so that every lane issues every memory instruction
-    L.mat = take(((int64_t)(ncap + 1) * poa_cap_stride(lmax) * 5 + POA_SPILL_CELLS) * (int64_t)sizeof(poa_cell_t) + 64);
+    L.mat = take((int64_t)(ncap + 1) * poa_cap_stride(lmax) * 5 * (int64_t)sizeof(poa_cell_t) + 64);
     L.total = align_up(o, 256);
     return L;
 }
@@ -342,9 +339,8 @@ __device__ inline PkMat pk_mat(const Mat2 &m) { PkMat r; r.ac = pk_sat(m.a, m.c)
 __device__ inline v2s pk_apply(const PkMat &m, v2s eq) { return pk_max(pk_add(m.ac, pk_lo(eq)), pk_add(m.bd, pk_hi(eq))); }
 
 __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
-                                 poa_cell_t *spill, int &max_i, int &max_j)
+                                 int &max_i, int &max_j)
 {
-    (void)spill;
     constexpr int CPL = 8;
     const int lane = threadIdx.x & 63;
     const PoaScore S = A.S;
@@ -1010,7 +1006,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 PH_T0
-                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mat + 5 * plane, mi, mj);
+                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
