@@ -468,18 +468,34 @@ __global__ void __launch_bounds__(256) phmm_unit_walk_kernel(PhmmArgs A, PhmmWor
     for (; off < end; ++off) W.stream[off] = 0;
 }
 
-// One wavefront per grouped pair: boundary byte + haplotype bytes into the read's stream.
+// One wavefront per grouped pair: boundary byte + haplotype bytes into the read's stream.  The body is
+// copied as aligned 4-byte words of the destination; a source word straddles two aligned source words and
+// is put together with v_alignbyte (the haplotype arena must be readable a few bytes past its end).
 __global__ void __launch_bounds__(256) phmm_stream_copy_kernel(PhmmArgs A, PhmmWork W)
 {
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (j >= W.next[0]) return;
-    const int hp = A.pair_hap[W.porder[j]];
-    const int H = A.hap_len[hp];
-    const uint8_t *src = A.hap + A.hap_off[hp];
-    uint8_t *dst = W.stream + W.soff[j];
-    if (lane == 0) dst[0] = 0;
-    for (int t = lane; t < H; t += 64) dst[1 + t] = src[t];
+    const int64_t n = W.next[0];
+    for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (int64_t)gridDim.x * 4) {
+        const int hp = A.pair_hap[W.porder[j]];
+        const int H = A.hap_len[hp];
+        const uint8_t *src = A.hap + A.hap_off[hp];
+        uint8_t *dst = W.stream + W.soff[j];
+        if (lane == 0) dst[0] = 0;
+        ++dst;                                                  // haplotype bytes follow the boundary byte
+        const int head = min(H, (int)((4 - ((uintptr_t)dst & 3)) & 3));
+        if (lane < head) dst[lane] = src[lane];
+        const int nw = (H - head) >> 2;                         // aligned destination words
+        const uint8_t *sb = src + head;
+        const int m = (int)((uintptr_t)sb & 3);
+        const uint32_t *s32 = (const uint32_t *)(sb - m);
+        uint32_t *d32 = (uint32_t *)(dst + head);
+        for (int t = lane; t < nw; t += 64) {
+            const uint32_t lo = s32[t], hi = s32[t + 1];
+            d32[t] = m ? __builtin_amdgcn_alignbyte(hi, lo, (unsigned)m) : lo;
+        }
+        const int done = head + 4 * nw;
+        if (lane < H - done) dst[done + lane] = src[done + lane];
+    }
 }
 
 // Two units per wavefront (lanes 0-30 / 32-62 hold the rows, lanes 31 / 63 stay zero so that nothing leaks
@@ -798,7 +814,13 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
         if (nblk) hipLaunchKernelGGL(phmm_read_place_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, A, W);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 1);
         if (rb) hipLaunchKernelGGL(phmm_unit_walk_kernel, dim3(rb), dim3(256), 0, s, A, W);
-        hipLaunchKernelGGL(phmm_stream_copy_kernel, dim3((int)((n_pairs + 3) / 4)), dim3(256), 0, s, A, W);
+        {
+            int dev_c = 0, cus_c = 256;
+            (void)hipGetDevice(&dev_c);
+            (void)hipDeviceGetAttribute(&cus_c, hipDeviceAttributeMultiprocessorCount, dev_c);
+            const int64_t want = (n_pairs + 3) / 4, cap_c = (int64_t)cus_c * 32;
+            hipLaunchKernelGGL(phmm_stream_copy_kernel, dim3((int)(want < cap_c ? want : cap_c)), dim3(256), 0, s, A, W);
+        }
     }
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);

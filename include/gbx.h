@@ -191,7 +191,8 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
                           const uint8_t *hap, double *out);
 
 /* The device entry groups the pairs by read (workspace arrays indexed by read id, hence n_reads) and
- * materialises one haplotype byte stream per read: workspace ~ n_pairs * (max_hap_len + 1) bytes. */
+ * materialises one haplotype byte stream per read: workspace ~ n_pairs * (max_hap_len + 1) bytes.
+ * The haplotype arena must be readable for 16 bytes past its last base (hipMalloc slack is enough). */
 size_t gbx_phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int32_t max_hap_len);
 int gbx_phmm_forward_device(int64_t n_pairs, const int32_t *d_pair_read, const int32_t *d_pair_hap,
                             int64_t n_reads, const int64_t *d_read_off, const int32_t *d_read_len,
