@@ -78,12 +78,19 @@ class BswWork:
                                            C.byref(secs))
                 best = secs.value if best is None else min(best, secs.value)
             kind, dt, what = "reference", best, "reference AVX2 getScores16 -b 512, one object per thread"
+            cols = [0, 1, 3, 5]     # score, tle, qle, max_off: the fields the AVX2 path defines like the scalar one
         else:
             t0 = time.perf_counter()
-            O.bsw_oracle(self.params, sample, cores)
+            out = O.bsw_oracle(self.params, sample, cores)
             kind, dt, what = "port", time.perf_counter() - t0, "oracle/bsw_oracle.c scalar restatement, OpenMP"
+            cols = [0, 1, 2, 3, 4, 5]
+        got = self.d.results()[:n]
+        got = np.stack([got[f] for f in ("score", "tle", "gtle", "qle", "gscore", "max_off")], axis=1) if got.dtype.names else got
+        same = bool(np.array_equal(np.asarray(got)[:, cols], np.asarray(out)[:, cols]))
         return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
-                "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" % (n, what, dt)}
+                "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" % (n, what, dt),
+                "verified": "device results of these %d pairs %s the CPU run's (%d of 6 fields compared)"
+                            % (n, "identical to" if same else "DIFFER from", len(cols))}
 
 
 class ChainWork:
@@ -119,15 +126,19 @@ class ChainWork:
         ref = O.ref_lib("chain")
         t0 = time.perf_counter()
         if ref is not None:
-            O.chain_ref(*sub, nthreads=cores)
+            want = O.chain_ref(*sub, nthreads=cores)
             kind, what = "reference", "reference host_chain_kernel (chain_dp), OpenMP dynamic"
         else:
-            O.chain_oracle(*sub, nthreads=cores)
+            want = O.chain_oracle(*sub, nthreads=cores)
             kind, what = "port", "oracle/chain_oracle.c, OpenMP dynamic"
         dt = time.perf_counter() - t0
         pairs = O.chain_oracle(*sub, nthreads=cores, return_pairs=True)[4]
+        k = int(off[n])
+        same = all(np.array_equal(g[:k], w[:k]) for g, w in zip(self.d.results(), want[:4]))
         return {"value": pairs / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
-                "sample": "first %d calls of the rank-0 shard (%d evaluated pairs), %s, %.2f s" % (n, pairs, what, dt)}
+                "sample": "first %d calls of the rank-0 shard (%d evaluated pairs), %s, %.2f s" % (n, pairs, what, dt),
+                "verified": "device score/parent/target/peak of these %d anchors %s the CPU run's"
+                            % (k, "identical to" if same else "DIFFER from")}
 
 
 class PhmmWork:
@@ -159,11 +170,17 @@ class PhmmWork:
         cores = os.cpu_count() or 1
         sub = self.bs.take_batches(0, min(self.n, max_units or 400))
         t0 = time.perf_counter()
-        O.phmm_oracle(sub, cores)
+        want = O.phmm_oracle(sub, cores)
         dt = time.perf_counter() - t0
+        got = self.d.results()[:sub.n_pairs]                 # whole batches from the front: the same pairs, same order
+        fin = np.isfinite(want)
+        err = float(np.max(np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0))) if fin.any() else 0.0
+        ok = err <= 1e-5 and np.array_equal(np.isfinite(got), fin)
         return {"value": sub.cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
                 "sample": "first %d batches (%d pairs), oracle/phmm_oracle.c scalar fp32+fp64 redo, OpenMP, %.2f s "
-                          "(GKL is an empty submodule: no reference build)" % (len(sub.n_reads), sub.n_pairs, dt)}
+                          "(GKL is an empty submodule: no reference build)" % (len(sub.n_reads), sub.n_pairs, dt),
+                "verified": "device log10 likelihoods of these pairs %s the CPU run's (max rel err %.2e, bound 1e-5)"
+                            % ("within tolerance of" if ok else "DIFFER from", err)}
 
 
 class PoaWork:
@@ -197,11 +214,14 @@ class PoaWork:
         cores = os.cpu_count() or 1
         sub = self.ws.take(0, min(self.n, max_units or 256))
         t0 = time.perf_counter()
-        _, cells = O.poa_oracle(self.params, sub, cores, return_cells=True)
+        want, cells = O.poa_oracle(self.params, sub, cores, return_cells=True)
         dt = time.perf_counter() - t0
+        same = self.d.results()[:sub.n_windows] == want
         return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
                 "sample": "first %d windows, oracle/poa_oracle.c scalar spoa restatement, OpenMP, %.2f s "
-                          "(spoa is an empty submodule: no reference build)" % (sub.n_windows, dt)}
+                          "(spoa is an empty submodule: no reference build)" % (sub.n_windows, dt),
+                "verified": "device consensus strings of these %d windows %s the CPU run's"
+                            % (sub.n_windows, "identical to" if same else "DIFFER from")}
 
 
 WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork}
