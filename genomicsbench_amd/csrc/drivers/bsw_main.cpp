@@ -1,8 +1,10 @@
 // bsw — GPU driver with the CLI of R/benchmarks/bsw/main_banded.cpp:
 //   bsw -pairs <InSeqFile> -t <threads> -b <batch_size> [-match N -mismatch N -ambig N -gapo N -gape N]
 // Input format (main_banded.cpp:131-141): 3 lines per pair: seed score, target digits 0-4, query digits 0-4.
-// -t and -b are accepted for compatibility; the GPU path takes all pairs in one call.
-// Extras: --dump FILE writes "score tle gtle qle gscore max_off" per pair.  Exit status 0 (the reference returns 1).
+// -b is accepted for compatibility; the GPU path takes all pairs in one call.  -t = threads of the parallel
+// ingest (line split, digit conversion, packing).
+// Extras: --dump FILE writes "score tle gtle qle gscore max_off" per pair; --parse-only 1 stops after the ingest and
+// prints pair count and checksums of the packed arrays (no GPU needed).  Exit status 0 (the reference returns 1).
 #include "driver_common.h"
 
 int main(int argc, char **argv)
@@ -13,6 +15,7 @@ int main(int argc, char **argv)
     }
     int a = 1, b = 4, ambig = -1, o = 6, e = 1, threads = 1, batch = 0;
     const char *pairs = nullptr, *dump = nullptr;
+    bool parse_only = false;
     for (int i = 1; i + 1 < argc; i += 2) {
         const char *k = argv[i], *v = argv[i + 1];
         if (!strcmp(k, "-match")) a = atoi(v);
@@ -24,8 +27,10 @@ int main(int argc, char **argv)
         else if (!strcmp(k, "-t")) threads = atoi(v);
         else if (!strcmp(k, "-b")) batch = atoi(v);
         else if (!strcmp(k, "--dump")) dump = v;
+        else if (!strcmp(k, "--parse-only")) parse_only = atoi(v) != 0;
     }
-    (void)threads; (void)batch;
+    (void)batch;
+    if (threads < 1) threads = 1;
     if (!pairs) { fprintf(stderr, "ERROR! pairFileName not specified.\n"); return EXIT_FAILURE; }
     std::vector<char> text;
     if (!slurp(pairs, text)) { fprintf(stderr, "Could not open file: %s\n", pairs); return EXIT_FAILURE; }
@@ -33,30 +38,34 @@ int main(int argc, char **argv)
     const double t_read0 = now_s();
     // split lines; numPairs = lines / 3 (main_banded.cpp:235)
     std::vector<const char *> line; std::vector<int> llen;
-    for (char *p = text.data(), *end = text.data() + text.size() - 1; p < end;) {
-        char *nl = (char *)memchr(p, '\n', (size_t)(end - p));
-        if (!nl) break;
-        line.push_back(p); llen.push_back((int)(nl - p));
-        p = nl + 1;
-    }
+    split_lines(text.data(), text.size() - 1, threads, line, llen);
     const int64_t n = (int64_t)line.size() / 3;
     printf("Number of input pairs: %ld\n", (long)n);
-    std::vector<int64_t> idr(n), idq(n);
-    std::vector<int32_t> len1(n), len2(n), h0(n);
+    std::vector<int64_t> idr((size_t)n), idq((size_t)n);
+    std::vector<int32_t> len1((size_t)n), len2((size_t)n), h0((size_t)n);
     int64_t rb = 0, qb = 0;
-    for (int64_t k = 0; k < n; ++k) {
-        h0[k] = atoi(line[3 * k]);
+    for (int64_t k = 0; k < n; ++k) {                           // offsets: a serial prefix over two ints per pair
         len1[k] = llen[3 * k + 1]; len2[k] = llen[3 * k + 2];
         if (len1[k] <= 0 || len2[k] <= 0) { fprintf(stderr, "pair %ld has an empty sequence\n", (long)k); return EXIT_FAILURE; }
         idr[k] = rb; idq[k] = qb;
         rb += (len1[k] + 3) & ~3; qb += (len2[k] + 3) & ~3;
     }
     std::vector<uint8_t> ref((size_t)rb + 8), qer((size_t)qb + 8);
+#pragma omp parallel for num_threads(threads) schedule(static)
     for (int64_t k = 0; k < n; ++k) {
+        h0[k] = atoi(line[3 * k]);
         for (int l = 0; l < len1[k]; ++l) ref[idr[k] + l] = (uint8_t)(line[3 * k + 1][l] - 48);
         for (int l = 0; l < len2[k]; ++l) qer[idq[k] + l] = (uint8_t)(line[3 * k + 2][l] - 48);
     }
     const double t_read = now_s() - t_read0;
+    if (parse_only) {
+        uint64_t h = fnv1a(h0.data(), (size_t)n * 4);
+        h = fnv1a(len1.data(), (size_t)n * 4, h); h = fnv1a(len2.data(), (size_t)n * 4, h);
+        for (int64_t k = 0; k < n; ++k) { h = fnv1a(&ref[idr[k]], (size_t)len1[k], h); h = fnv1a(&qer[idq[k]], (size_t)len2[k], h); }
+        printf("{\"benchmark\":\"bsw\",\"pairs\":%ld,\"ingest_threads\":%d,\"ingest_seconds\":%.4f,\"ingest_mb_per_s\":%.1f,\"checksum\":\"%016llx\"}\n",
+               (long)n, threads, t_read, text.size() / 1e6 / t_read, (unsigned long long)h);
+        return 0;
+    }
 
     gbx_bsw_params P;
     gbx_bsw_default_params(&P);

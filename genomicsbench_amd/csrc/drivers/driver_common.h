@@ -39,6 +39,55 @@ static inline bool slurp(const char *path, std::vector<char> &buf)
     return true;
 }
 
+// ---- parallel ingest: the input text is split and converted by `threads` OpenMP threads.
+// Chunk boundaries never cut a record: every thread finds the delimiters of its own byte range, the ranges
+// are stitched by a prefix sum, and the records are then parsed independently.
+#include <omp.h>
+
+// start and length of every '\n'-terminated line of [p, p+n)
+static inline void split_lines(const char *p, size_t n, int threads, std::vector<const char *> &line, std::vector<int> &llen)
+{
+    if (threads < 1) threads = 1;
+    std::vector<std::vector<size_t>> nl((size_t)threads);
+#pragma omp parallel num_threads(threads)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
+        std::vector<size_t> &v = nl[(size_t)t];
+        for (const char *q = p + lo, *e = p + hi; q < e;) {
+            const char *f = (const char *)memchr(q, '\n', (size_t)(e - q));
+            if (!f) break;
+            v.push_back((size_t)(f - p));
+            q = f + 1;
+        }
+    }
+    size_t total = 0;
+    std::vector<size_t> base((size_t)threads + 1, 0);
+    for (int t = 0; t < threads; ++t) { base[(size_t)t] = total; total += nl[(size_t)t].size(); }
+    line.resize(total); llen.resize(total);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int t = 0; t < threads; ++t) {
+        const std::vector<size_t> &v = nl[(size_t)t];
+        for (size_t k = 0; k < v.size(); ++k) {
+            const size_t g = base[(size_t)t] + k;
+            // the line starts behind the previous newline, which may belong to an earlier thread's range
+            size_t start = 0;
+            if (k > 0) start = v[k - 1] + 1;
+            else for (int u = t - 1; u >= 0; --u) if (!nl[(size_t)u].empty()) { start = nl[(size_t)u].back() + 1; break; }
+            line[g] = p + start; llen[g] = (int)(v[k] - start);
+        }
+    }
+}
+
+// 64-bit FNV-1a over a byte range: the checksum `--parse-only` prints, so that tests can compare the parsed
+// arrays with an independent reader without a GPU
+static inline uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *b = (const unsigned char *)data;
+    for (size_t k = 0; k < bytes; ++k) { h ^= b[k]; h *= 1099511628211ull; }
+    return h;
+}
+
 static inline void print_device_banner()
 {
     char name[256];

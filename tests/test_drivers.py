@@ -53,6 +53,48 @@ def test_gkl_dropin_library_exports_the_symbols_the_reference_driver_binds():
         assert s in syms, s
 
 
+def _fnv1a(chunks):
+    h = 1469598103934665603
+    for c in chunks:
+        for b in bytes(c):
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_bsw_parallel_ingest_matches_an_independent_reader(data):
+    """the driver's multithreaded ingest (line split, digit conversion, packing) yields the same
+    arrays whatever the thread count, and the same as the Python reader (checksum over h0, lengths and bases)."""
+    d, b = data[0], data[1]
+    outs = []
+    for t in ("1", "3", "8"):
+        r = run([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", t, "--parse-only", "1"])
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert all(o["pairs"] == b.n for o in outs) and len({o["checksum"] for o in outs}) == 1
+    chunks = [b.h0.astype(np.int32).tobytes(), b.len1.astype(np.int32).tobytes(), b.len2.astype(np.int32).tobytes()]
+    for k in range(b.n):
+        chunks.append(b.ref[b.idr[k]:b.idr[k] + b.len1[k]].tobytes())
+        chunks.append(b.qer[b.idq[k]:b.idq[k] + b.len2[k]].tobytes())
+    assert outs[0]["checksum"] == "%016x" % _fnv1a(chunks)
+
+
+def test_chain_parallel_ingest_matches_an_independent_reader(data):
+    d, c = data[0], data[2]
+    off, ax, ay, hdr = c
+    outs = []
+    for t in ("1", "5"):
+        r = run([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", str(d / "chain.unused"), "-t", t, "--parse-only"])
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["calls"] == len(off) - 1 and outs[0]["anchors"] == int(off[-1]) and outs[0]["checksum"] == outs[1]["checksum"]
+    chunks = [np.asarray(off, dtype=np.int64).tobytes()]
+    for k in range(len(off) - 1):
+        chunks.append(np.float32(hdr[k]["avg_qspan"]).tobytes())
+        chunks.append(np.array([hdr[k]["max_dist_x"], hdr[k]["max_dist_y"], hdr[k]["bw"], hdr[k]["n_segs"]], dtype=np.int32).tobytes())
+    chunks += [np.asarray(ax[:off[-1]], dtype=np.uint64).tobytes(), np.asarray(ay[:off[-1]], dtype=np.uint64).tobytes()]
+    assert outs[0]["checksum"] == "%016x" % _fnv1a(chunks)
+
+
 def test_file_formats_roundtrip(data):
     d, b, c, ph, po = data
     assert gio.read_poa_windows(str(d / "poa.fasta")).window(1) == po.window(1)
