@@ -95,6 +95,36 @@ def test_chain_parallel_ingest_matches_an_independent_reader(data):
     assert outs[0]["checksum"] == "%016x" % _fnv1a(chunks)
 
 
+def test_phmm_parallel_ingest_matches_an_independent_reader(data):
+    d = data[0]
+    bs = gio.read_phmm_batches(str(d / "phmm.in"))
+    outs = []
+    for t in ("1", "6"):
+        r = run([os.path.join(BIN, "phmm"), "-f", str(d / "phmm.in"), "-t", t, "--parse-only"])
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["pairs"] == bs.n_pairs and outs[0]["checksum"] == outs[1]["checksum"]
+    nb = int(bs.read_len.astype(np.int64).sum()), int(bs.hap_len.astype(np.int64).sum())
+    chunks = [bs.read_len.astype(np.int32).tobytes(), bs.hap_len.astype(np.int32).tobytes(),
+              bs.pair_read.astype(np.int32).tobytes(), bs.pair_hap.astype(np.int32).tobytes()]
+    chunks += [a[:nb[0]].tobytes() for a in (bs.rs, bs.q, bs.qi, bs.qd, bs.qc)] + [bs.hap[:nb[1]].tobytes()]
+    assert outs[0]["checksum"] == "%016x" % _fnv1a(chunks)
+
+
+def test_poa_parallel_ingest_matches_an_independent_reader(data):
+    d = data[0]
+    ws = gio.read_poa_windows(str(d / "poa.fasta"))
+    outs = []
+    for t in ("1", "4"):
+        r = run([os.path.join(BIN, "poa"), "-s", str(d / "poa.fasta"), "-t", t, "--parse-only"])
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["windows"] == ws.n_windows and outs[0]["sequences"] == ws.n_seqs and outs[0]["checksum"] == outs[1]["checksum"]
+    seqs = b"".join(ws.arena[ws.seq_off[k]:ws.seq_off[k] + ws.seq_len[k]].tobytes() for k in range(ws.n_seqs))
+    chunks = [np.asarray(ws.win_first_seq, dtype=np.int64).tobytes(), np.asarray(ws.seq_len, dtype=np.int32).tobytes(), seqs]
+    assert outs[0]["checksum"] == "%016x" % _fnv1a(chunks)
+
+
 def test_file_formats_roundtrip(data):
     d, b, c, ph, po = data
     assert gio.read_poa_windows(str(d / "poa.fasta")).window(1) == po.window(1)
