@@ -26,8 +26,9 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X
 
 # query-length range handled by each bsw row kernel (csrc/bsw_kernels.hip: cls_of / class_shapes; the default
 # shape of a class has lanes x columns == the longest query of the class)
-_BSW_QMAX = [16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 1024]
-_BSW_SHAPE = ["2x8", "2x16", "2x24", "4x16", "4x20", "4x24", "8x14", "8x16", "16x10", "16x12", "16x16", "64x16"]
+_BSW_QMAX = [8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 160, 192, 256, 1024]
+_BSW_SHAPE = ["2x4", "2x8", "2x12", "2x16", "2x20", "2x24", "4x14", "4x16", "4x18", "4x20", "4x22", "4x24", "8x13", "8x14", "8x15",
+              "8x16", "16x10", "16x12", "16x16", "64x16"]
 BSW_CLASS = {"bsw_rows_" + sh: ((_BSW_QMAX[k - 1] + 1) if k else 1, _BSW_QMAX[k]) for k, sh in enumerate(_BSW_SHAPE)}
 BSW_CLASS["bsw_lds"] = (1025, 1 << 30)
 # read-length range handled by each phmm kernel (csrc/phmm_kernels.hip: 31 row lanes x K rows per lane on the stream

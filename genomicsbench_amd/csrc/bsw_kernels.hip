@@ -30,10 +30,12 @@ namespace {
 constexpr int NEG = -(1 << 29);
 constexpr int BIGJ = 1 << 20;
 
-// qlen classes: 0..7 = qlen <= 16,32,..,128; 8..10 = <= 160,192,256; 11 = <= 1024; 12 = LDS kernel (shapes: class_shapes())
-constexpr int NCLS = 13;
+// qlen classes: 0..15 = qlen <= 8,16,..,128; 16..18 = <= 160,192,256; 19 = <= 1024; 20 = LDS kernel (shapes: class_shapes())
+constexpr int NCLS = 21;
+constexpr int CLS_LDS = NCLS - 1;
 constexpr int NTB = 32;                     // target-length buckets per class (width 16), longest first
-constexpr int NBIN = NCLS * NTB;            // 416 bins: pairs are binned by (class, descending target length)
+constexpr int NBIN = NCLS * NTB;            // 672 bins: pairs are binned by (class, descending target length)
+constexpr int HDR = 1024;                   // ints per header array (>= NBIN + 1)
 constexpr int REG_SCORE_LIMIT = 1 << 20;   // register kernels pack (h<<10|j) in 31 bits
 
 struct BswDev {
@@ -51,19 +53,19 @@ struct BswPairs {
     gbx_bsw_result *out;
 };
 
-// workspace layout (ints): counts[512] | cursors[512] | base[512] (exclusive prefix of counts) | misc[512] | order[n] | wband[n]
+// workspace layout (ints): counts[HDR] | cursors[HDR] | base[HDR] (exclusive prefix of counts) | misc[HDR] | order[n] | wband[n]
 //   misc[0] = bad-pair count; order[] = pair indices binned by (class, target length), wband[] = their clamped band width
-constexpr int WS_HDR = 2048;
+constexpr int WS_HDR = 4 * HDR;
 struct BswWork {
     int32_t *counts, *cursors, *base, *bad, *order, *wband;
 };
 
 __host__ __device__ inline int cls_of(int qlen, int bound)
 {
-    if (qlen > 1024 || bound >= REG_SCORE_LIMIT) return 12;
-    if (qlen > 256) return 11;
-    if (qlen <= 128) return (qlen - 1) >> 4;          // CPL 1..8  -> classes 0..7
-    return qlen <= 160 ? 8 : qlen <= 192 ? 9 : 10;    // CPL 10, 12, 16
+    if (qlen > 1024 || bound >= REG_SCORE_LIMIT) return CLS_LDS;
+    if (qlen > 256) return 19;
+    if (qlen <= 128) return (qlen - 1) >> 3;          // 8 columns per class: a pair wastes at most 7
+    return qlen <= 160 ? 16 : qlen <= 192 ? 17 : 18;
 }
 __host__ __device__ inline int bin_of(int cls, int tlen)
 {
@@ -214,14 +216,14 @@ __global__ void __launch_bounds__(CLS_THREADS) bsw_classify_kernel(BswDev prm, B
 }
 
 // exclusive prefix of the bin counts (one block)
-__global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
+__global__ void __launch_bounds__(HDR) bsw_scan_kernel(BswWork W)
 {
-    __shared__ int tmp[512];
+    __shared__ int tmp[HDR];
     const int tid = threadIdx.x;
     const int v = tid < NBIN ? W.counts[tid] : 0;
     tmp[tid] = v;
     __syncthreads();
-    for (int d = 1; d < 512; d <<= 1) {
+    for (int d = 1; d < HDR; d <<= 1) {
         const int add = tid >= d ? tmp[tid - d] : 0;
         __syncthreads();
         tmp[tid] += add;
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(512) bsw_scan_kernel(BswWork W)
 // SYM: o_ins+e_ins == o_del+e_del, the gap-open term of E and F is shared.
 // the register budget is pinned per CPL (second launch-bound = wavefronts per SIMD) so that the wide
 // shapes keep 4 wavefronts per SIMD resident
-constexpr int rows_min_waves(int cpl) { return cpl >= 20 ? 3 : cpl >= 12 ? 4 : cpl >= 9 ? 5 : cpl >= 7 ? 6 : cpl >= 5 ? 7 : 1; }
+constexpr int rows_min_waves(int cpl) { return cpl >= 17 ? 3 : cpl >= 12 ? 4 : cpl >= 9 ? 5 : cpl >= 7 ? 6 : cpl >= 5 ? 7 : 1; }
 
 template <int LPP, int CPL, bool SYM>
 __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswDev prm, BswPairs P, BswWork W, int cls)
@@ -541,18 +543,16 @@ struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
 #define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
 RowKernel row_kernels[] = {
     // the default table (class_shapes) ...
-    GBX_ROW_KERNEL(2, 8),  GBX_ROW_KERNEL(2, 16), GBX_ROW_KERNEL(2, 24),
-    GBX_ROW_KERNEL(4, 16), GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 24),
-    GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 16),
+    GBX_ROW_KERNEL(2, 4),  GBX_ROW_KERNEL(2, 8),  GBX_ROW_KERNEL(2, 12), GBX_ROW_KERNEL(2, 16), GBX_ROW_KERNEL(2, 20), GBX_ROW_KERNEL(2, 24),
+    GBX_ROW_KERNEL(4, 14), GBX_ROW_KERNEL(4, 16), GBX_ROW_KERNEL(4, 18), GBX_ROW_KERNEL(4, 20), GBX_ROW_KERNEL(4, 22), GBX_ROW_KERNEL(4, 24),
+    GBX_ROW_KERNEL(8, 13), GBX_ROW_KERNEL(8, 14), GBX_ROW_KERNEL(8, 15), GBX_ROW_KERNEL(8, 16),
     GBX_ROW_KERNEL(16, 10), GBX_ROW_KERNEL(16, 12), GBX_ROW_KERNEL(16, 16), GBX_ROW_KERNEL(64, 16),
-    // ... and the alternatives scripts/tune_bsw_shapes.sh compares them with
-    GBX_ROW_KERNEL(4, 4),  GBX_ROW_KERNEL(4, 8),  GBX_ROW_KERNEL(4, 12),
-    GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12),
-    GBX_ROW_KERNEL(16, 4), GBX_ROW_KERNEL(16, 6), GBX_ROW_KERNEL(16, 8),
+    // ... and alternatives for scripts/tune_bsw_shapes.sh
+    GBX_ROW_KERNEL(4, 8), GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12), GBX_ROW_KERNEL(16, 8),
 };
 #undef GBX_ROW_KERNEL
 // widest query a class holds: classes 0..7 = 16,32,..,128; 8..11 = 160,192,256,1024
-constexpr int class_qmax[NCLS - 1] = {16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 256, 1024};
+constexpr int class_qmax[NCLS - 1] = {8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 160, 192, 256, 1024};
 
 RowKernel *find_row_kernel(int lpp, int cpl)
 {
@@ -565,8 +565,8 @@ RowKernel *find_row_kernel(int lpp, int cpl)
 // cover their class or have no kernel are ignored.
 const RowShape *class_shapes()
 {
-    static RowShape shapes[NCLS - 1] = {{2, 8}, {2, 16}, {2, 24}, {4, 16}, {4, 20}, {4, 24}, {8, 14}, {8, 16},
-                                        {16, 10}, {16, 12}, {16, 16}, {64, 16}};
+    static RowShape shapes[NCLS - 1] = {{2, 4},  {2, 8},  {2, 12}, {2, 16}, {2, 20}, {2, 24}, {4, 14}, {4, 16}, {4, 18}, {4, 20},
+                                        {4, 22}, {4, 24}, {8, 13}, {8, 14}, {8, 15}, {8, 16}, {16, 10}, {16, 12}, {16, 16}, {64, 16}};
     static bool parsed = false;
     if (!parsed) {
         parsed = true;
@@ -631,13 +631,13 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     if (rc) return rc;
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
     int32_t *wi = (int32_t *)d_work;
-    BswWork W = {wi, wi + 512, wi + 1024, wi + 1536, wi + WS_HDR, wi + WS_HDR + n};
+    BswWork W = {wi, wi + HDR, wi + 2 * HDR, wi + 3 * HDR, wi + WS_HDR, wi + WS_HDR + n};
     GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s));
     const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
         Stage st("bsw_classify", s);
         hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(512), 0, s, W);
+        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(HDR), 0, s, W);
         hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 1);
     }
 
@@ -684,7 +684,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         }
         int blocks = (int)(n < (int64_t)cus * 2 ? n : (int64_t)cus * 2);
         Stage st("bsw_lds", s);
-        hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, 12);
+        hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, CLS_LDS);
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;
