@@ -621,7 +621,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const uint8_t *d_ref, const uint8_t *d_qer,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
-               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s)
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s, const hipStream_t *join_to)
 {
     if (n == 0) return GBX_OK;
     if (n > 0x7fffffffLL - 1024) { set_error("bsw: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
@@ -658,7 +658,12 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     // streams so that a tail overlaps the next class (GBX_BSW_SERIAL=1 keeps them on the caller's stream)
     static const bool serial = getenv("GBX_BSW_SERIAL") != nullptr;
     SideStreams *ss = nullptr;
-    if (!serial && ((rc = side_streams(&ss)) || (rc = ss->fork(s)))) return rc;
+    std::unique_lock<std::mutex> side_lock;
+    if (!serial) {
+        if ((rc = side_streams(&ss))) return rc;
+        side_lock = std::unique_lock<std::mutex>(ss->mu);
+        if ((rc = ss->fork(s))) return rc;
+    }
     for (int c = 0; c < NCLS - 1; ++c) {
         hipStream_t sc = serial || (c & 3) == 0 ? s : ss->side[(c & 3) - 1];
         RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
@@ -674,7 +679,11 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         Stage st(k->name, sc);
         hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, sc, dev, P, W, c);
     }
-    if (!serial && (rc = ss->join(s))) return rc;
+    // join_to == nullptr: the caller's stream waits for the side streams (everything of this call is then
+    // ordered on `s`).  Otherwise only *join_to waits (for the side streams and for `s`), and `s` and the side
+    // streams run on into the caller's next launch: the host pipeline queues chunk after chunk like that, so
+    // the single-wavefront tails of one chunk overlap the next chunk's kernels.
+    if (!serial && !join_to && (rc = ss->join(s))) return rc;
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         static bool attr_set = false;
@@ -685,6 +694,13 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         int blocks = (int)(n < (int64_t)cus * 2 ? n : (int64_t)cus * 2);
         Stage st("bsw_lds", s);
         hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, CLS_LDS);
+    }
+    if (join_to) {
+        if (!ss && (rc = side_streams(&ss))) return rc;
+        if (!side_lock.owns_lock()) side_lock = std::unique_lock<std::mutex>(ss->mu);
+        if (!serial && (rc = ss->join(*join_to))) return rc;
+        GBX_HIP(hipEventRecord(ss->ev_fork, s));
+        GBX_HIP(hipStreamWaitEvent(*join_to, ss->ev_fork, 0));
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;

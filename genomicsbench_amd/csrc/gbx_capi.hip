@@ -3,8 +3,10 @@
 // compute path in this library: without a HIP device every compute entry
 // returns GBX_ERR_NO_DEVICE.
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "gbx_internal.h"
 
@@ -107,6 +109,8 @@ struct DevBuf {
 
 }  // namespace gbx
 
+#include "host_pipeline.h"
+
 using namespace gbx;
 
 struct gbx_timer {
@@ -131,6 +135,15 @@ int gbx_set_device(int dev)
     if (rc) return rc;
     GBX_HIP(hipSetDevice(dev));
     return GBX_OK;
+}
+
+int gbx_host_prepare(void)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    return lane_prepare_staging(lane.l);
 }
 
 int gbx_device_name(char *buf, size_t cap)
@@ -278,41 +291,89 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
         set_error("gbx_bsw_extend_host: null pointer");
         return GBX_ERR_ARG;
     }
-    for (int64_t k = 0; k < n; ++k) {
-        if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 ||
-            idr[k] + len1[k] > ref_bytes || idq[k] + len2[k] > qer_bytes) {
-            set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)k);
-            return GBX_ERR_ARG;
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;     /* timeline of this call on stderr */
+    const double t_begin = wall_s();
+    // one pass over the pairs: validation, and per pipeline chunk the furthest arena byte its pairs need
+    const int64_t chunk = bsw_host_chunk(n);
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    std::vector<int64_t> need_r((size_t)n_chunks), need_q((size_t)n_chunks);
+    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
+        const int64_t b = a + chunk < n ? a + chunk : n;
+        int64_t mr = 0, mq = 0;
+        for (int64_t k = a; k < b; ++k) {
+            const int64_t er = idr[k] + len1[k], eq = idq[k] + len2[k];
+            if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 || er > ref_bytes || eq > qer_bytes) {
+                set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)k);
+                return GBX_ERR_ARG;
+            }
+            if (len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
+                set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)k);
+                return GBX_ERR_UNSUPPORTED;
+            }
+            mr = er > mr ? er : mr; mq = eq > mq ? eq : mq;
         }
-        if (len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
-            set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)k);
-            return GBX_ERR_UNSUPPORTED;
-        }
+        need_r[(size_t)c] = mr; need_q[(size_t)c] = mq;
     }
     int rc = require_device();
     if (rc) return rc;
+    auto mark = [&](const char *what, int64_t k) { if (trace) fprintf(stderr, "[gbx host] %8.3f ms %s %lld\n", (wall_s() - t_begin) * 1e3, what, (long long)k); };
+    mark("validated", n);
+    // Upload, compute and download are pipelined over chunks of pairs (host_pipeline.h).  Chunk k's bases and
+    // index slices go up while earlier chunks run; the arenas are uploaded front to back up to the furthest
+    // byte any pair seen so far needs (a running maximum), which is right for every offset layout and streams
+    // perfectly for the usual monotone one.  The chunks are queued back to back without a barrier between them
+    // (own workspace each; only the lane's join stream waits for a chunk), and their results come back while
+    // later chunks run.  Chunks are multiples of 64 pairs.
+    const size_t wb1 = (bsw_workspace_bytes(chunk < n ? chunk : n) + 255) & ~(size_t)255;
     DevBuf dref, dqer, didr, didq, dl1, dl2, dh0, dout, dwork;
-    const size_t wb = bsw_workspace_bytes(n);
     if ((rc = dref.alloc((size_t)ref_bytes)) || (rc = dqer.alloc((size_t)qer_bytes)) ||
         (rc = didr.alloc(n * 8)) || (rc = didq.alloc(n * 8)) || (rc = dl1.alloc(n * 4)) ||
         (rc = dl2.alloc(n * 4)) || (rc = dh0.alloc(n * 4)) || (rc = dout.alloc(n * sizeof(gbx_bsw_result))) ||
-        (rc = dwork.alloc(wb)))
+        (rc = dwork.alloc(wb1 * (size_t)n_chunks)))
         return rc;
-    hipStream_t s = nullptr;
-    GBX_HIP(hipMemcpyAsync(dref.p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(dqer.p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(didr.p, idr, n * 8, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(didq.p, idq, n * 8, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(dl1.p, len1, n * 4, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(dl2.p, len2, n * 4, hipMemcpyHostToDevice, s));
-    GBX_HIP(hipMemcpyAsync(dh0.p, h0, n * 4, hipMemcpyHostToDevice, s));
-    rc = bsw_launch(p, n, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>(), didq.as<int64_t>(),
-                    dl1.as<int32_t>(), dl2.as<int32_t>(), dh0.as<int32_t>(), dout.as<gbx_bsw_result>(),
-                    dwork.p, wb, s);
-    if (rc) return rc;
-    GBX_HIP(hipMemcpyAsync(out, dout.p, n * sizeof(gbx_bsw_result), hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipStreamSynchronize(s));
-    return GBX_OK;
+    mark("allocated", 0);
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28);
+    if ((rc = pipe.prepare(n_chunks))) return rc;
+    int64_t up_r = 0, up_q = 0;
+    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
+        const int64_t b = a + chunk < n ? a + chunk : n, m = b - a;
+        const int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
+        const int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
+        pipe.stage(c, dref.as<uint8_t>() + up_r, ref + up_r, (size_t)(nr - up_r));
+        pipe.stage(c, dqer.as<uint8_t>() + up_q, qer + up_q, (size_t)(nq - up_q));
+        pipe.stage(c, didr.as<int64_t>() + a, idr + a, m * 8);
+        pipe.stage(c, didq.as<int64_t>() + a, idq + a, m * 8);
+        pipe.stage(c, dl1.as<int32_t>() + a, len1 + a, m * 4);
+        pipe.stage(c, dl2.as<int32_t>() + a, len2 + a, m * 4);
+        pipe.stage(c, dh0.as<int32_t>() + a, h0 + a, m * 4);
+        up_r = nr; up_q = nq;
+    }
+    pipe.start();
+    mark("pipeline started, chunks", n_chunks);
+    const bool barrier = getenv("GBX_BSW_HOST_BARRIER") != nullptr;
+    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
+        const int64_t m = (a + chunk < n ? a + chunk : n) - a;
+        if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
+        mark("uploads queued, chunk", c);
+        rc = bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,
+                        dl1.as<int32_t>() + a, dl2.as<int32_t>() + a, dh0.as<int32_t>() + a,
+                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute,
+                        barrier ? &L->compute : &L->join);
+        if (!rc && barrier) {        /* the join stream follows the compute stream */
+            hipError_t e = hipEventRecord(L->ev_stage, L->compute);
+            if (e == hipSuccess) e = hipStreamWaitEvent(L->join, L->ev_stage, 0);
+            if (e != hipSuccess) rc = hip_fail(e, "gbx_bsw_extend_host join");
+        }
+        if (!rc) rc = pipe.chunk_launched(c, out + a, dout.as<gbx_bsw_result>() + a, m * sizeof(gbx_bsw_result));
+        if (rc) return pipe.finish(rc);
+    }
+    mark("kernels queued", n_chunks);
+    rc = pipe.finish();
+    mark("results downloaded", 0);
+    return rc;
 }
 
 int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t n,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include "../../include/gbx.h"
 
 namespace gbx {
@@ -29,12 +30,14 @@ struct Stage {
 
 // Side streams for independent kernels of one call (the per-class kernels have long single-wave tails that
 // overlap well).  fork(): the side streams wait for everything queued on `main`; join(): `main` waits for
-// them.  One set per device, created on first use; calls on the same device share it (stream order keeps
-// them correct, they just serialise).
+// them.  One set per device, created on first use and shared by every caller on that device: the launch
+// functions hold `mu` from fork() to join() (host enqueue time only), because the events are shared and two
+// host threads recording them in between each other would wait on the wrong record.
 struct SideStreams {
     static constexpr int N = 3;
     hipStream_t side[N];
     hipEvent_t ev_fork, ev_join[N];
+    std::mutex mu;
     int fork(hipStream_t main);
     int join(hipStream_t main);
 };
@@ -46,7 +49,8 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const uint8_t *d_ref, const uint8_t *d_qer,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
-               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s);
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s,
+               const hipStream_t *join_to = nullptr);
 
 // ---- chain (chain_kernels.hip)
 size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors);

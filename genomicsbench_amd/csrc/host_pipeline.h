@@ -1,0 +1,300 @@
+// host_pipeline.h — what the *_host entry points of libgbx.so use to move caller-owned (pageable) buffers to the
+// device and the results back while kernels run.  Included by gbx_capi.hip only.
+//
+// A call takes a Lane (streams + pinned staging slabs, pooled per device, one per concurrent caller) and
+// describes its uploads as an ordered list of stages; stage c is everything chunk c of the input needs.  Large
+// calls spawn a few upload workers for the duration of the call: each takes the next piece (<= 8 MiB) of the
+// list, copies it from the caller's memory into one of its two pinned slabs and queues the DMA on the lane's
+// copy stream.  The caller's pages are never pinned (the runtime would pin them on first touch: about 30 ms
+// per GB), the DMA engine stays busy (one thread's memcpy runs at ~29 GB/s on the GPU box's host, PCIe takes
+// ~75 GB/s from pinned memory), and the calling thread is free to queue kernels as soon as a stage is complete
+// on the copy stream.  A downloader thread brings finished chunks' results back through a pinned slab while
+// later chunks still run.  Small calls (< 8 MiB of input) do the same steps inline with plain pageable copies.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+namespace gbx {
+
+static double wall_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Lane {
+    static constexpr int MAX_WORKERS = 8;
+    static constexpr size_t PIECE = (size_t)8 << 20;        // upload piece = worker slab
+    static constexpr size_t DOWN = (size_t)16 << 20;        // download slab
+    int dev = 0;
+    hipStream_t compute = nullptr, copy = nullptr, join = nullptr, down = nullptr;
+    hipEvent_t ev_stage = nullptr;
+    std::vector<hipEvent_t> ev_chunk;      // one per pipeline chunk of a call, grown on demand
+    char *wslab[MAX_WORKERS][2] = {};
+    hipEvent_t wev[MAX_WORKERS][2] = {};
+    char *dslab = nullptr;
+    bool staged_ready = false;
+};
+
+static int host_workers()
+{
+    const char *env = getenv("GBX_HOST_THREADS");
+    int t = env ? atoi(env) : 6;
+    return t < 1 ? 1 : t > Lane::MAX_WORKERS ? Lane::MAX_WORKERS : t;
+}
+
+// pinned slabs of a lane: allocated and touched once (the pages are pinned by hipHostMalloc but only mapped into
+// this process on the first write, ~0.1 ms per MB)
+static int lane_prepare_staging(Lane *l)
+{
+    if (l->staged_ready) return GBX_OK;
+    for (int w = 0; w < Lane::MAX_WORKERS; ++w)
+        for (int k = 0; k < 2; ++k) {
+            if (!l->wslab[w][k]) GBX_HIP(hipHostMalloc((void **)&l->wslab[w][k], Lane::PIECE, hipHostMallocDefault));
+            if (!l->wev[w][k]) GBX_HIP(hipEventCreateWithFlags(&l->wev[w][k], hipEventDisableTiming));
+        }
+    if (!l->dslab) GBX_HIP(hipHostMalloc((void **)&l->dslab, Lane::DOWN, hipHostMallocDefault));
+    std::vector<std::thread> th;
+    for (int w = 0; w < Lane::MAX_WORKERS; ++w)
+        th.emplace_back([=] { memset(l->wslab[w][0], 0, Lane::PIECE); memset(l->wslab[w][1], 0, Lane::PIECE); });
+    memset(l->dslab, 0, Lane::DOWN);
+    for (auto &x : th) x.join();
+    l->staged_ready = true;
+    return GBX_OK;
+}
+
+struct HostLane {
+    Lane *l = nullptr;
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::vector<Lane *> &idle() { static std::vector<Lane *> v; return v; }
+    int acquire()
+    {
+        int dev = 0;
+        GBX_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto &v = idle();
+            for (size_t k = 0; k < v.size(); ++k)
+                if (v[k]->dev == dev) { l = v[k]; v.erase(v.begin() + (long)k); return GBX_OK; }
+        }
+        Lane *n = new Lane();
+        n->dev = dev;
+        // The transfer streams get the highest priority: the runtime maps streams of one priority onto a few
+        // hardware queues (4 by default), and a copy queued behind a class kernel in the same hardware queue
+        // waits for it: measured, uploads stopped whenever the four kernel streams were busy.  Streams of
+        // another priority use queues of their own.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipError_t e = hipStreamCreateWithFlags(&n->compute, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->copy, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->join, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->down, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage, hipEventDisableTiming);
+        if (e != hipSuccess) { delete n; return hip_fail(e, "host lane"); }
+        l = n;
+        return GBX_OK;
+    }
+    ~HostLane()
+    {
+        if (!l) return;
+        std::lock_guard<std::mutex> lk(mu());
+        idle().push_back(l);
+    }
+};
+
+// One *_host call's transfers.  Usage:
+//   HostPipe P(lane, total_upload_bytes);  P.prepare(n_chunks);
+//   P.stage(c, dst, src, bytes) ... for every chunk c in order;  P.start();
+//   for c: P.wait_stage(c) -> compute stream waits for chunk c's uploads; launch kernels with join_to = &L->join;
+//          P.chunk_launched(c, d_results, host_results, bytes)  -> the downloader fetches them when the chunk is done
+//   P.finish()  -> joins the threads, returns the first error
+struct HostPipe {
+    struct Piece { char *dst; const char *src; size_t len; int chunk; };
+    struct Fetch { void *dst; const void *src; size_t len; };
+    Lane *L;
+    bool staged;
+    int workers;
+    std::vector<Piece> pieces;
+    std::vector<int> remaining;            // pieces of chunk c not yet queued on the copy stream
+    std::vector<Fetch> fetches;
+    std::atomic<size_t> next{0};
+    std::atomic<int> hip_err{0};
+    bool abort_ = false;
+    int64_t launched = 0, n_chunks = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> threads;
+    bool started = false;
+
+    HostPipe(Lane *l, size_t total_bytes)
+        : L(l), staged(total_bytes >= ((size_t)8 << 20) && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()) {}
+    ~HostPipe() { (void)finish(); }
+
+    int prepare(int64_t chunks)
+    {
+        n_chunks = chunks;
+        remaining.assign((size_t)chunks, 0);
+        fetches.assign((size_t)chunks, Fetch{nullptr, nullptr, 0});
+        while ((int64_t)L->ev_chunk.size() < chunks) {
+            hipEvent_t e = nullptr;
+            GBX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            L->ev_chunk.push_back(e);
+        }
+        return staged ? lane_prepare_staging(L) : GBX_OK;
+    }
+    void stage(int64_t chunk, void *dst, const void *src, size_t bytes)
+    {
+        char *d = (char *)dst;
+        const char *s = (const char *)src;
+        const size_t cap = staged ? Lane::PIECE : bytes;
+        while (bytes) {
+            const size_t len = bytes < cap ? bytes : cap;
+            pieces.push_back(Piece{d, s, len, (int)chunk});
+            ++remaining[(size_t)chunk];
+            d += len; s += len; bytes -= len;
+        }
+    }
+    void fail_hip(hipError_t e)
+    {
+        int zero = 0;
+        hip_err.compare_exchange_strong(zero, (int)e);
+        std::lock_guard<std::mutex> lk(mu);
+        abort_ = true;
+        cv.notify_all();
+    }
+    void upload_worker(int w)
+    {
+        if (hipSetDevice(L->dev) != hipSuccess) { fail_hip(hipErrorInvalidDevice); return; }
+        bool busy[2] = {false, false};
+        int slot = 0;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pieces.size() || hip_err.load()) break;
+            const Piece &p = pieces[i];
+            hipError_t e = hipSuccess;
+            if (busy[slot]) e = hipEventSynchronize(L->wev[w][slot]);
+            if (e == hipSuccess) {
+                memcpy(L->wslab[w][slot], p.src, p.len);
+                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.len, hipMemcpyHostToDevice, L->copy);
+            }
+            if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], L->copy);
+            if (e != hipSuccess) { fail_hip(e); return; }
+            busy[slot] = true;
+            slot ^= 1;
+            std::lock_guard<std::mutex> lk(mu);
+            if (--remaining[(size_t)p.chunk] == 0) cv.notify_all();
+        }
+    }
+    // D2H of one chunk's results behind its join event, through the pinned slab when staged
+    hipError_t fetch_chunk(int64_t c)
+    {
+        const Fetch &f = fetches[(size_t)c];
+        hipError_t e = hipStreamWaitEvent(L->down, L->ev_chunk[(size_t)c], 0);
+        if (e != hipSuccess || !f.len) return e;
+        if (!staged) {
+            e = hipMemcpyAsync(f.dst, f.src, f.len, hipMemcpyDeviceToHost, L->down);
+            return e == hipSuccess ? hipStreamSynchronize(L->down) : e;
+        }
+        char *d = (char *)f.dst;
+        const char *s = (const char *)f.src;
+        for (size_t left = f.len; left;) {
+            const size_t len = left < Lane::DOWN ? left : Lane::DOWN;
+            if ((e = hipMemcpyAsync(L->dslab, s, len, hipMemcpyDeviceToHost, L->down)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(L->down)) != hipSuccess) return e;
+            memcpy(d, L->dslab, len);
+            d += len; s += len; left -= len;
+        }
+        return hipSuccess;
+    }
+    void download_worker()
+    {
+        if (hipSetDevice(L->dev) != hipSuccess) { fail_hip(hipErrorInvalidDevice); return; }
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return launched > c || abort_; });
+                if (abort_) return;
+            }
+            hipError_t e = fetch_chunk(c);
+            if (e != hipSuccess) { fail_hip(e); return; }
+        }
+    }
+    void start()
+    {
+        started = true;
+        if (!staged) return;
+        for (int w = 0; w < workers; ++w) threads.emplace_back([this, w] { upload_worker(w); });
+        threads.emplace_back([this] { download_worker(); });
+    }
+    // returns when every upload of chunk c is queued on the copy stream, and makes the compute stream wait for them
+    int wait_stage(int64_t c)
+    {
+        if (!staged) {
+            for (; next < pieces.size() && pieces[next].chunk <= c; ++next) {
+                const Piece &p = pieces[next];
+                GBX_HIP(hipMemcpyAsync(p.dst, p.src, p.len, hipMemcpyHostToDevice, L->copy));
+            }
+        } else {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return remaining[(size_t)c] == 0 || abort_; });
+            if (abort_) return hip_fail((hipError_t)hip_err.load(), "host pipeline upload");
+        }
+        GBX_HIP(hipEventRecord(L->ev_stage, L->copy));
+        GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
+        return GBX_OK;
+    }
+    // chunk c's kernels are queued and the lane's join stream waits for them
+    int chunk_launched(int64_t c, void *host_dst, const void *dev_src, size_t bytes)
+    {
+        GBX_HIP(hipEventRecord(L->ev_chunk[(size_t)c], L->join));
+        fetches[(size_t)c] = Fetch{host_dst, dev_src, bytes};
+        if (!staged) return GBX_OK;
+        std::lock_guard<std::mutex> lk(mu);
+        launched = c + 1;
+        cv.notify_all();
+        return GBX_OK;
+    }
+    void cancel()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_ = true;
+        next = pieces.size();
+        cv.notify_all();
+    }
+    // everything queued: wait for the transfers, return the first error.  Safe to call twice.
+    int finish(int rc_in = GBX_OK)
+    {
+        if (!started) return rc_in;
+        started = false;
+        if (rc_in) cancel();
+        for (auto &t : threads) t.join();
+        threads.clear();
+        int rc = rc_in;
+        if (!rc && hip_err.load()) rc = hip_fail((hipError_t)hip_err.load(), "host pipeline");
+        if (!rc && !staged) {
+            for (int64_t c = 0; c < n_chunks && !rc; ++c) {
+                hipError_t e = fetch_chunk(c);
+                if (e != hipSuccess) rc = hip_fail(e, "host pipeline download");
+            }
+        }
+        // nothing of this call may still be in flight when the caller's device buffers are freed
+        (void)hipStreamSynchronize(L->copy); (void)hipStreamSynchronize(L->compute);
+        (void)hipStreamSynchronize(L->join); (void)hipStreamSynchronize(L->down);
+        if (rc) (void)hipDeviceSynchronize();        // kernels on the shared side streams too
+        return rc;
+    }
+};
+
+// pairs per pipeline chunk of gbx_bsw_extend_host: a multiple of 64.  Every chunk is a full set of class kernels,
+// and a launch needs several hundred thousand pairs to keep 256 CUs busy through the single-wavefront tails
+// (measured: +0.7 ms per extra chunk at 2 M pairs), so: at most 3 chunks, none below 512 Ki pairs.
+static int64_t bsw_host_chunk(int64_t n)
+{
+    const char *env = getenv("GBX_BSW_HOST_CHUNK");      /* read per call: the tests vary it */
+    if (env && atoll(env) > 0) return (atoll(env) + 63) & ~63LL;
+    int64_t c = (n + 2) / 3;
+    if (c < 524288) c = 524288;
+    return (c + 63) & ~63LL;
+}
+
+}  // namespace gbx

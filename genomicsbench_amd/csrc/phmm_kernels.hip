@@ -830,7 +830,9 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     // launched over n_pairs slots and stop there themselves
     // the row classes are independent and each ends in a tail of single long units: they run side by side
     SideStreams *ss = nullptr;
-    if ((rc = side_streams(&ss)) || (rc = ss->fork(s))) return rc;
+    if ((rc = side_streams(&ss))) return rc;
+    std::unique_lock<std::mutex> side_lock(ss->mu);
+    if ((rc = ss->fork(s))) return rc;
 #define GBX_STREAM(RPL_, STREAM_)                                                                                       \
     {                                                                                                                   \
         static int per_cu = 0;                                                                                          \
@@ -848,6 +850,7 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     GBX_STREAM(2, ss->side[0]) GBX_STREAM(7, ss->side[1]) GBX_STREAM(1, ss->side[2]) GBX_STREAM(8, ss->side[1])
 #undef GBX_STREAM
     if ((rc = ss->join(s))) return rc;
+    side_lock.unlock();
     { Stage st("phmm_stream_finish", s); hipLaunchKernelGGL(phmm_stream_finish_kernel, dim3(cb), dim3(256), 0, s, A, W); }
     // reads longer than STREAM_MAX_ROWS rows: one pair per wavefront, row tiles
     { Stage st("phmm_f32_rpl4", s); hipLaunchKernelGGL(phmm_f32_kernel<4>, dim3(grid(20)), dim3(64), 0, s, A, W, 3); }

@@ -39,6 +39,11 @@ const char *gbx_last_error(void);       /* thread-local, never NULL */
 int  gbx_device_count(void);            /* number of HIP devices, 0 if none; never errors  */
 int  gbx_set_device(int dev);           /* selects the device later calls of this thread use */
 int  gbx_device_name(char *buf, size_t cap);
+/* Optional: creates the calling thread's streams and the pinned staging buffers the *_host entries use for
+ * large inputs (about 110 MB of pinned host memory), so that the first large call does not pay for them.  The
+ * counterpart of constructing the reference's aligner object before its timed region
+ * (bsw/main_banded.cpp:262-270).  The *_host entries do this themselves on demand. */
+int  gbx_host_prepare(void);
 
 /* Timing helpers on a stream (HIP events), so that a Python/ctypes host can
  * time the exact stream the kernels are launched on without touching HIP. */

@@ -112,3 +112,38 @@ def test_permutation_and_shard_equivalence_large():
     idx = rng.choice(b.n, 20000, replace=False)
     sb = BswBatch(b.ref, b.qer, b.idr[idx], b.idq[idx], b.len1[idx], b.len2[idx], b.h0[idx])
     assert_same(full[idx], O.bsw_oracle(p, sb, 8), sb)
+
+
+def test_host_entry_pipeline_chunks(monkeypatch):
+    """gbx_bsw_extend_host uploads and computes in chunks of pairs: many small chunks over permuted
+    (non-monotone) arena offsets give the same results as one chunk and as the oracle."""
+    b = gen_bsw(6000, 21)
+    perm = np.random.default_rng(5).permutation(b.n)
+    pb = BswBatch(b.ref, b.qer, b.idr[perm], b.idq[perm], b.len1[perm], b.len2[perm], b.h0[perm])
+    p = make_params()
+    want = O.bsw_oracle(p, pb, 4)
+    for chunk in ("64", "1000", "100000"):
+        monkeypatch.setenv("GBX_BSW_HOST_CHUNK", chunk)
+        assert_same(extend_host(p, pb), want, pb)
+
+
+def test_concurrent_host_threads():
+    """The reference calls one aligner object per OpenMP thread concurrently (main_banded.cpp:279-289): host
+    threads calling the C-ABI at the same time get the same results as one after the other."""
+    import threading
+    p = make_params()
+    batches = [gen_bsw(30000, 100 + t) for t in range(4)]
+    want = [extend_host(p, b) for b in batches]
+    for _ in range(3):
+        got = [None] * len(batches)
+
+        def work(t):
+            got[t] = extend_host(p, batches[t])
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(len(batches))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for t in range(len(batches)):
+            assert_same(got[t], want[t], batches[t])
