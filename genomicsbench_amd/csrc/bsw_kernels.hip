@@ -621,7 +621,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const uint8_t *d_ref, const uint8_t *d_qer,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
-               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s, const hipStream_t *join_to)
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s, hipEvent_t *join_events)
 {
     if (n == 0) return GBX_OK;
     if (n > 0x7fffffffLL - 1024) { set_error("bsw: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
@@ -665,7 +665,13 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         if ((rc = ss->fork(s))) return rc;
     }
     for (int c = 0; c < NCLS - 1; ++c) {
-        hipStream_t sc = serial || (c & 3) == 0 ? s : ss->side[(c & 3) - 1];
+        // Four kernel streams when the inputs are resident.  The host pipeline (join_events) uses three: the
+        // runtime maps streams onto four hardware queues, and with all four busy with class kernels its copy
+        // stream shares one and the uploads stall behind kernels (measured; GBX_BSW_KSTREAMS overrides).
+        static const int nk_env = getenv("GBX_BSW_KSTREAMS") ? atoi(getenv("GBX_BSW_KSTREAMS")) : 0;
+        const int nk = nk_env > 0 ? nk_env : join_events ? 3 : 4;
+        const int lane_k = nk >= 4 ? (c & 3) : c % nk;
+        hipStream_t sc = serial || lane_k == 0 ? s : ss->side[lane_k - 1];
         RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
         if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
         if (!k->bpc[sym]) {
@@ -679,11 +685,12 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         Stage st(k->name, sc);
         hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, sc, dev, P, W, c);
     }
-    // join_to == nullptr: the caller's stream waits for the side streams (everything of this call is then
-    // ordered on `s`).  Otherwise only *join_to waits (for the side streams and for `s`), and `s` and the side
-    // streams run on into the caller's next launch: the host pipeline queues chunk after chunk like that, so
-    // the single-wavefront tails of one chunk overlap the next chunk's kernels.
-    if (!serial && !join_to && (rc = ss->join(s))) return rc;
+    // join_events == nullptr: the caller's stream waits for the side streams (everything of this call is then
+    // ordered on `s`).  Otherwise nothing waits: one event per stream is recorded (join_events[0] on `s`,
+    // join_events[1+k] on side stream k), and `s` and the side streams run on into the caller's next launch:
+    // the host pipeline queues chunk after chunk like that, so that the single-wavefront tails of one chunk
+    // overlap the next chunk's kernels, and its downloader waits for the events.
+    if (!serial && !join_events && (rc = ss->join(s))) return rc;
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         static bool attr_set = false;
@@ -695,12 +702,10 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         Stage st("bsw_lds", s);
         hipLaunchKernelGGL(bsw_lds_kernel, dim3(blocks), dim3(64), lds_bytes, s, dev, P, W, CLS_LDS);
     }
-    if (join_to) {
+    if (join_events) {
         if (!ss && (rc = side_streams(&ss))) return rc;
-        if (!side_lock.owns_lock()) side_lock = std::unique_lock<std::mutex>(ss->mu);
-        if (!serial && (rc = ss->join(*join_to))) return rc;
-        GBX_HIP(hipEventRecord(ss->ev_fork, s));
-        GBX_HIP(hipStreamWaitEvent(*join_to, ss->ev_fork, 0));
+        GBX_HIP(hipEventRecord(join_events[0], s));
+        for (int k = 0; k < SideStreams::N; ++k) GBX_HIP(hipEventRecord(join_events[1 + k], ss->side[k]));
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;

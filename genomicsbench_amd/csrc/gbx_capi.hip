@@ -297,20 +297,48 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     const int64_t chunk = bsw_host_chunk(n);
     const int64_t n_chunks = (n + chunk - 1) / chunk;
     std::vector<int64_t> need_r((size_t)n_chunks), need_q((size_t)n_chunks);
-    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
-        const int64_t b = a + chunk < n ? a + chunk : n;
+    // slices of 64 Ki pairs, a few threads when there are many; the lowest failing pair is reported
+    const int64_t SL = 65536, n_slices = (n + SL - 1) / SL;
+    std::vector<int64_t> slice_r((size_t)n_slices), slice_q((size_t)n_slices), slice_bad((size_t)n_slices, -1);
+    auto check_slice = [&](int64_t sl) {
+        const int64_t a = sl * SL, b = a + SL < n ? a + SL : n;
         int64_t mr = 0, mq = 0;
         for (int64_t k = a; k < b; ++k) {
             const int64_t er = idr[k] + len1[k], eq = idq[k] + len2[k];
-            if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 || er > ref_bytes || eq > qer_bytes) {
-                set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)k);
-                return GBX_ERR_ARG;
-            }
-            if (len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
-                set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)k);
-                return GBX_ERR_UNSUPPORTED;
+            if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 || er > ref_bytes || eq > qer_bytes ||
+                len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
+                slice_bad[(size_t)sl] = k;
+                return;
             }
             mr = er > mr ? er : mr; mq = eq > mq ? eq : mq;
+        }
+        slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq;
+    };
+    {
+        const int vt = n_slices >= 8 ? 4 : 1;
+        std::vector<std::thread> th;
+        for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = t; sl < n_slices; sl += vt) check_slice(sl); });
+        for (int64_t sl = 0; sl < n_slices; sl += vt) check_slice(sl);
+        for (auto &x : th) x.join();
+    }
+    for (int64_t sl = 0; sl < n_slices; ++sl) {
+        const int64_t k = slice_bad[(size_t)sl];
+        if (k < 0) continue;
+        if (len1[k] >= 0 && len2[k] >= 0 && idr[k] >= 0 && idq[k] >= 0 && idr[k] + len1[k] <= ref_bytes &&
+            idq[k] + len2[k] <= qer_bytes) {
+            set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)k);
+            return GBX_ERR_UNSUPPORTED;
+        }
+        set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)k);
+        return GBX_ERR_ARG;
+    }
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        int64_t mr = 0, mq = 0;
+        // chunks are multiples of 64 pairs, slices of 65536: a slice may straddle two chunks, which only makes
+        // the earlier chunk wait for a few more bytes
+        for (int64_t sl = c * chunk / SL; sl < n_slices && sl * SL < (c + 1) * chunk; ++sl) {
+            mr = slice_r[(size_t)sl] > mr ? slice_r[(size_t)sl] : mr;
+            mq = slice_q[(size_t)sl] > mq ? slice_q[(size_t)sl] : mq;
         }
         need_r[(size_t)c] = mr; need_q[(size_t)c] = mq;
     }
@@ -322,8 +350,8 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     // index slices go up while earlier chunks run; the arenas are uploaded front to back up to the furthest
     // byte any pair seen so far needs (a running maximum), which is right for every offset layout and streams
     // perfectly for the usual monotone one.  The chunks are queued back to back without a barrier between them
-    // (own workspace each; only the lane's join stream waits for a chunk), and their results come back while
-    // later chunks run.  Chunks are multiples of 64 pairs.
+    // (own workspace each; the launch records the events a chunk's download waits for), and their results come
+    // back while later chunks run.  Chunks are multiples of 64 pairs.
     const size_t wb1 = (bsw_workspace_bytes(chunk < n ? chunk : n) + 255) & ~(size_t)255;
     DevBuf dref, dqer, didr, didq, dl1, dl2, dh0, dout, dwork;
     if ((rc = dref.alloc((size_t)ref_bytes)) || (rc = dqer.alloc((size_t)qer_bytes)) ||
@@ -335,7 +363,7 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     HostLane lane;
     if ((rc = lane.acquire())) return rc;
     Lane *L = lane.l;
-    HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28);
+    HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28, n_chunks > 1);
     if ((rc = pipe.prepare(n_chunks))) return rc;
     int64_t up_r = 0, up_q = 0;
     for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
@@ -353,21 +381,19 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     }
     pipe.start();
     mark("pipeline started, chunks", n_chunks);
-    const bool barrier = getenv("GBX_BSW_HOST_BARRIER") != nullptr;
     for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
         const int64_t m = (a + chunk < n ? a + chunk : n) - a;
         if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
         mark("uploads queued, chunk", c);
+        // pipelined calls: no barrier between the chunks, the launch records one event per kernel stream
+        hipEvent_t *je = n_chunks > 1 ? pipe.join_events(c) : nullptr;
         rc = bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,
                         dl1.as<int32_t>() + a, dl2.as<int32_t>() + a, dh0.as<int32_t>() + a,
-                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute,
-                        barrier ? &L->compute : &L->join);
-        if (!rc && barrier) {        /* the join stream follows the compute stream */
-            hipError_t e = hipEventRecord(L->ev_stage, L->compute);
-            if (e == hipSuccess) e = hipStreamWaitEvent(L->join, L->ev_stage, 0);
-            if (e != hipSuccess) rc = hip_fail(e, "gbx_bsw_extend_host join");
+                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute, je);
+        if (!rc) {
+            pipe.fetch(c, out + a, dout.as<gbx_bsw_result>() + a, m * sizeof(gbx_bsw_result));
+            rc = pipe.chunk_launched(c, je ? Lane::JOIN_EVENTS : 0);
         }
-        if (!rc) rc = pipe.chunk_launched(c, out + a, dout.as<gbx_bsw_result>() + a, m * sizeof(gbx_bsw_result));
         if (rc) return pipe.finish(rc);
     }
     mark("kernels queued", n_chunks);
@@ -442,24 +468,27 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
         (rc = dh.alloc(n_calls * sizeof(gbx_chain_call))) || (rc = ds.alloc(na * 4)) || (rc = dp.alloc(na * 4)) ||
         (rc = dt.alloc(na * 4)) || (rc = dk.alloc(na * 4)) || (rc = dw.alloc(wb)))
         return rc;
-    hipStream_t s = nullptr;
-    GBX_HIP(hipMemcpyAsync(doff.p, anchor_off, (n_calls + 1) * 8, hipMemcpyHostToDevice, s));
-    if (na) {
-        GBX_HIP(hipMemcpyAsync(dx.p, ax, na * 8, hipMemcpyHostToDevice, s));
-        GBX_HIP(hipMemcpyAsync(dy.p, ay, na * 8, hipMemcpyHostToDevice, s));
-    }
-    GBX_HIP(hipMemcpyAsync(dh.p, hdr, n_calls * sizeof(gbx_chain_call), hipMemcpyHostToDevice, s));
+    // one pipeline chunk (host_pipeline.h): staged uploads, the kernels on the lane's compute stream, staged
+    // downloads.  The calls of a job share one load-balanced launch, so there is nothing to gain from chunks.
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    HostPipe pipe(lane.l, (size_t)na * 16 + (size_t)n_calls * (8 + sizeof(gbx_chain_call)), false);
+    if ((rc = pipe.prepare(1))) return rc;
+    pipe.stage(0, doff.p, anchor_off, (n_calls + 1) * 8);
+    pipe.stage(0, dh.p, hdr, n_calls * sizeof(gbx_chain_call));
+    pipe.stage(0, dx.p, ax, na * 8);
+    pipe.stage(0, dy.p, ay, na * 8);
+    pipe.start();
+    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
     rc = chain_launch(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
-                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, s);
-    if (rc) return rc;
-    if (na) {
-        GBX_HIP(hipMemcpyAsync(score, ds.p, na * 4, hipMemcpyDeviceToHost, s));
-        GBX_HIP(hipMemcpyAsync(parent, dp.p, na * 4, hipMemcpyDeviceToHost, s));
-        if (target) GBX_HIP(hipMemcpyAsync(target, dt.p, na * 4, hipMemcpyDeviceToHost, s));
-        if (peak) GBX_HIP(hipMemcpyAsync(peak, dk.p, na * 4, hipMemcpyDeviceToHost, s));
-    }
-    GBX_HIP(hipStreamSynchronize(s));
-    return GBX_OK;
+                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute);
+    if (rc) return pipe.finish(rc);
+    pipe.fetch(0, score, ds.p, na * 4);
+    pipe.fetch(0, parent, dp.p, na * 4);
+    if (target) pipe.fetch(0, target, dt.p, na * 4);
+    if (peak) pipe.fetch(0, peak, dk.p, na * 4);
+    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    return pipe.finish();
 }
 
 /* -------------------------------------------------------------------- phmm */
@@ -546,24 +575,26 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         (rc = dho.alloc(n_haps * 8)) || (rc = dhl.alloc(n_haps * 4)) || (rc = dh.alloc(hap_bytes)) ||
         (rc = dout.alloc(n_pairs * 8)) || (rc = dw.alloc(wb)))
         return rc;
-    hipStream_t s = nullptr;
-    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
-        if (bytes) GBX_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s));
-        return GBX_OK;
-    };
-    if ((rc = up(dpr, pair_read, n_pairs * 4)) || (rc = up(dph, pair_hap, n_pairs * 4)) ||
-        (rc = up(dro, read_off, n_reads * 8)) || (rc = up(drl, read_len, n_reads * 4)) ||
-        (rc = up(drs, rs, read_bytes)) || (rc = up(dq, q, read_bytes)) || (rc = up(di, i, read_bytes)) ||
-        (rc = up(dd, d, read_bytes)) || (rc = up(dc, c, read_bytes)) || (rc = up(dho, hap_off, n_haps * 8)) ||
-        (rc = up(dhl, hap_len, n_haps * 4)) || (rc = up(dh, hap, hap_bytes)))
-        return rc;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    HostPipe pipe(lane.l, (size_t)read_bytes * 5 + (size_t)hap_bytes + (size_t)n_pairs * 8 + (size_t)(n_reads + n_haps) * 12, false);
+    if ((rc = pipe.prepare(1))) return rc;
+    pipe.stage(0, dpr.p, pair_read, n_pairs * 4); pipe.stage(0, dph.p, pair_hap, n_pairs * 4);
+    pipe.stage(0, dro.p, read_off, n_reads * 8); pipe.stage(0, drl.p, read_len, n_reads * 4);
+    pipe.stage(0, drs.p, rs, read_bytes); pipe.stage(0, dq.p, q, read_bytes); pipe.stage(0, di.p, i, read_bytes);
+    pipe.stage(0, dd.p, d, read_bytes); pipe.stage(0, dc.p, c, read_bytes);
+    pipe.stage(0, dho.p, hap_off, n_haps * 8); pipe.stage(0, dhl.p, hap_len, n_haps * 4);
+    pipe.stage(0, dh.p, hap, hap_bytes);
+    pipe.start();
+    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
     rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), n_reads, dro.as<int64_t>(), drl.as<int32_t>(),
                      drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
-                     dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb, s);
-    if (rc) return rc;
-    GBX_HIP(hipMemcpyAsync(out, dout.p, n_pairs * 8, hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipStreamSynchronize(s));
-    return GBX_OK;
+                     dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb,
+                     lane.l->compute);
+    if (rc) return pipe.finish(rc);
+    pipe.fetch(0, out, dout.p, n_pairs * 8);
+    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    return pipe.finish();
 }
 
 /* --------------------------------------------------------------------- poa */
@@ -680,22 +711,28 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         (rc = dar.alloc(arena_bytes)) || (rc = dcons.alloc(n_windows * cons_stride)) || (rc = dcl.alloc(n_windows * 4)) ||
         (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
         return rc;
-    hipStream_t s = nullptr;
-    GBX_HIP(hipMemcpyAsync(dwf.p, win_first_seq, (n_windows + 1) * 8, hipMemcpyHostToDevice, s));
-    if (n_seqs) {
-        GBX_HIP(hipMemcpyAsync(doff.p, seq_off, n_seqs * 8, hipMemcpyHostToDevice, s));
-        GBX_HIP(hipMemcpyAsync(dlen.p, seq_len, n_seqs * 4, hipMemcpyHostToDevice, s));
-    }
-    if (arena_bytes) GBX_HIP(hipMemcpyAsync(dar.p, arena, arena_bytes, hipMemcpyHostToDevice, s));
-    rc = poa_launch(p, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
-                    plan.max_seq_len, plan.max_seqs_per_window, plan.node_cap, plan.n_slots, dcons.as<uint8_t>(),
-                    dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, s);
-    if (rc) return rc;
     std::vector<int32_t> status(n_windows);
-    GBX_HIP(hipMemcpyAsync(cons, dcons.p, n_windows * cons_stride, hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipMemcpyAsync(cons_len, dcl.p, n_windows * 4, hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipMemcpyAsync(status.data(), dst.p, n_windows * 4, hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipStreamSynchronize(s));
+    {
+        HostLane lane;
+        if ((rc = lane.acquire())) return rc;
+        HostPipe pipe(lane.l, (size_t)arena_bytes + (size_t)n_seqs * 12 + (size_t)n_windows * 8, false);
+        if ((rc = pipe.prepare(1))) return rc;
+        pipe.stage(0, dwf.p, win_first_seq, (n_windows + 1) * 8);
+        pipe.stage(0, doff.p, seq_off, n_seqs * 8);
+        pipe.stage(0, dlen.p, seq_len, n_seqs * 4);
+        pipe.stage(0, dar.p, arena, arena_bytes);
+        pipe.start();
+        if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        rc = poa_launch(p, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
+                        plan.max_seq_len, plan.max_seqs_per_window, plan.node_cap, plan.n_slots, dcons.as<uint8_t>(),
+                        dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, lane.l->compute);
+            if (rc) return pipe.finish(rc);
+        pipe.fetch(0, cons, dcons.p, n_windows * cons_stride);
+        pipe.fetch(0, cons_len, dcl.p, n_windows * 4);
+        pipe.fetch(0, status.data(), dst.p, n_windows * 4);
+        if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+        if ((rc = pipe.finish())) return rc;
+    }
     for (int64_t w = 0; w < n_windows; ++w)
         if (status[w]) {
             set_error("gbx_poa_consensus_host: window %lld exceeded a device capacity (status bits 0x%x, see GBX_POA_ST_*)",

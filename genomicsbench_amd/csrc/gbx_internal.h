@@ -50,7 +50,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
                gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s,
-               const hipStream_t *join_to = nullptr);
+               hipEvent_t *join_events = nullptr);
 
 // ---- chain (chain_kernels.hip)
 size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors);

@@ -27,9 +27,14 @@ struct Lane {
     static constexpr size_t PIECE = (size_t)8 << 20;        // upload piece = worker slab
     static constexpr size_t DOWN = (size_t)16 << 20;        // download slab
     int dev = 0;
-    hipStream_t compute = nullptr, copy = nullptr, join = nullptr, down = nullptr;
-    hipEvent_t ev_stage = nullptr;
-    std::vector<hipEvent_t> ev_chunk;      // one per pipeline chunk of a call, grown on demand
+    // Two streams only.  The runtime maps all streams of a process onto four hardware queues, and streams that
+    // share a queue run in order: with compute + transfer + two of the kernels' side streams every one has a
+    // queue of its own (measured with more: uploads stalled behind class kernels, or two kernel streams lost
+    // their overlap).  Calls that do not overlap transfer and compute use `compute` for everything.
+    hipStream_t compute = nullptr, copy = nullptr;
+    hipEvent_t ev_stage = nullptr, ev_half[2] = {nullptr, nullptr};
+    static constexpr int JOIN_EVENTS = 1 + SideStreams::N;
+    std::vector<hipEvent_t> ev_chunk;      // JOIN_EVENTS per pipeline chunk of a call, grown on demand
     char *wslab[MAX_WORKERS][2] = {};
     hipEvent_t wev[MAX_WORKERS][2] = {};
     char *dslab = nullptr;
@@ -79,17 +84,11 @@ struct HostLane {
         }
         Lane *n = new Lane();
         n->dev = dev;
-        // The transfer streams get the highest priority: the runtime maps streams of one priority onto a few
-        // hardware queues (4 by default), and a copy queued behind a class kernel in the same hardware queue
-        // waits for it: measured, uploads stopped whenever the four kernel streams were busy.  Streams of
-        // another priority use queues of their own.
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         hipError_t e = hipStreamCreateWithFlags(&n->compute, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->copy, hipStreamNonBlocking, prio_hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->join, hipStreamNonBlocking, prio_hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&n->down, hipStreamNonBlocking, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&n->copy, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[1], hipEventDisableTiming);
         if (e != hipSuccess) { delete n; return hip_fail(e, "host lane"); }
         l = n;
         return GBX_OK;
@@ -105,18 +104,21 @@ struct HostLane {
 // One *_host call's transfers.  Usage:
 //   HostPipe P(lane, total_upload_bytes);  P.prepare(n_chunks);
 //   P.stage(c, dst, src, bytes) ... for every chunk c in order;  P.start();
-//   for c: P.wait_stage(c) -> compute stream waits for chunk c's uploads; launch kernels with join_to = &L->join;
-//          P.chunk_launched(c, d_results, host_results, bytes)  -> the downloader fetches them when the chunk is done
+//   for c: P.wait_stage(c) -> compute stream waits for chunk c's uploads; launch kernels (join_events(c));
+//          P.fetch(c, host_results, d_results, bytes) ...; P.chunk_launched(c)  -> the downloader fetches them when
+//          the chunk is done
 //   P.finish()  -> joins the threads, returns the first error
 struct HostPipe {
     struct Piece { char *dst; const char *src; size_t len; int chunk; };
-    struct Fetch { void *dst; const void *src; size_t len; };
+    struct Fetch { void *dst; const void *src; size_t len; int chunk; };
     Lane *L;
     bool staged;
     int workers;
     std::vector<Piece> pieces;
     std::vector<int> remaining;            // pieces of chunk c not yet queued on the copy stream
     std::vector<Fetch> fetches;
+    std::vector<int> chunk_nev;            // join events recorded for chunk c
+    hipStream_t xfer;                      // L->copy, or L->compute for calls that do not overlap
     std::atomic<size_t> next{0};
     std::atomic<int> hip_err{0};
     bool abort_ = false;
@@ -126,16 +128,17 @@ struct HostPipe {
     std::vector<std::thread> threads;
     bool started = false;
 
-    HostPipe(Lane *l, size_t total_bytes)
-        : L(l), staged(total_bytes >= ((size_t)8 << 20) && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()) {}
+    HostPipe(Lane *l, size_t total_bytes, bool overlap)
+        : L(l), staged(total_bytes >= ((size_t)8 << 20) && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
+          xfer(overlap ? l->copy : l->compute) {}
     ~HostPipe() { (void)finish(); }
 
     int prepare(int64_t chunks)
     {
         n_chunks = chunks;
         remaining.assign((size_t)chunks, 0);
-        fetches.assign((size_t)chunks, Fetch{nullptr, nullptr, 0});
-        while ((int64_t)L->ev_chunk.size() < chunks) {
+        chunk_nev.assign((size_t)chunks, 0);
+        while ((int64_t)L->ev_chunk.size() < chunks * Lane::JOIN_EVENTS) {
             hipEvent_t e = nullptr;
             GBX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             L->ev_chunk.push_back(e);
@@ -175,9 +178,9 @@ struct HostPipe {
             if (busy[slot]) e = hipEventSynchronize(L->wev[w][slot]);
             if (e == hipSuccess) {
                 memcpy(L->wslab[w][slot], p.src, p.len);
-                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.len, hipMemcpyHostToDevice, L->copy);
+                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.len, hipMemcpyHostToDevice, xfer);
             }
-            if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], L->copy);
+            if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], xfer);
             if (e != hipSuccess) { fail_hip(e); return; }
             busy[slot] = true;
             slot ^= 1;
@@ -185,24 +188,44 @@ struct HostPipe {
             if (--remaining[(size_t)p.chunk] == 0) cv.notify_all();
         }
     }
-    // D2H of one chunk's results behind its join event, through the pinned slab when staged
+    // D2H of one chunk's results behind its join event, through the two halves of the pinned slab when staged
+    // (the copy of one half to the caller's memory overlaps the DMA into the other)
     hipError_t fetch_chunk(int64_t c)
     {
-        const Fetch &f = fetches[(size_t)c];
-        hipError_t e = hipStreamWaitEvent(L->down, L->ev_chunk[(size_t)c], 0);
-        if (e != hipSuccess || !f.len) return e;
-        if (!staged) {
-            e = hipMemcpyAsync(f.dst, f.src, f.len, hipMemcpyDeviceToHost, L->down);
-            return e == hipSuccess ? hipStreamSynchronize(L->down) : e;
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < chunk_nev[(size_t)c]; ++k)        // the chunk's kernels are done on every stream they ran on
+            if ((e = hipEventSynchronize(L->ev_chunk[(size_t)c * Lane::JOIN_EVENTS + (size_t)k])) != hipSuccess) return e;
+        std::vector<Fetch> mine;           // the launcher thread may be appending later chunks' entries
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (const Fetch &f : fetches) if (f.chunk == c) mine.push_back(f);
         }
-        char *d = (char *)f.dst;
-        const char *s = (const char *)f.src;
-        for (size_t left = f.len; left;) {
-            const size_t len = left < Lane::DOWN ? left : Lane::DOWN;
-            if ((e = hipMemcpyAsync(L->dslab, s, len, hipMemcpyDeviceToHost, L->down)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(L->down)) != hipSuccess) return e;
-            memcpy(d, L->dslab, len);
-            d += len; s += len; left -= len;
+        if (!staged) {
+            for (const Fetch &f : mine)
+                if (f.len && (e = hipMemcpyAsync(f.dst, f.src, f.len, hipMemcpyDeviceToHost, xfer)) != hipSuccess)
+                    return e;
+            return hipStreamSynchronize(xfer);
+        }
+        const size_t HALF = Lane::DOWN / 2;
+        char *pend_dst = nullptr; size_t pend_len = 0; int half = 0;
+        for (const Fetch &f : mine) {
+            char *d = (char *)f.dst;
+            const char *s = (const char *)f.src;
+            for (size_t left = f.len; left;) {
+                const size_t len = left < HALF ? left : HALF;
+                if ((e = hipMemcpyAsync(L->dslab + half * HALF, s, len, hipMemcpyDeviceToHost, xfer)) != hipSuccess) return e;
+                if ((e = hipEventRecord(L->ev_half[half], xfer)) != hipSuccess) return e;
+                if (pend_len) {
+                    if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
+                    memcpy(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
+                }
+                pend_dst = d; pend_len = len; half ^= 1;
+                d += len; s += len; left -= len;
+            }
+        }
+        if (pend_len) {
+            if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
+            memcpy(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
         }
         return hipSuccess;
     }
@@ -232,22 +255,36 @@ struct HostPipe {
         if (!staged) {
             for (; next < pieces.size() && pieces[next].chunk <= c; ++next) {
                 const Piece &p = pieces[next];
-                GBX_HIP(hipMemcpyAsync(p.dst, p.src, p.len, hipMemcpyHostToDevice, L->copy));
+                GBX_HIP(hipMemcpyAsync(p.dst, p.src, p.len, hipMemcpyHostToDevice, xfer));
             }
         } else {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return remaining[(size_t)c] == 0 || abort_; });
             if (abort_) return hip_fail((hipError_t)hip_err.load(), "host pipeline upload");
         }
-        GBX_HIP(hipEventRecord(L->ev_stage, L->copy));
-        GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
+        if (xfer != L->compute) {
+            GBX_HIP(hipEventRecord(L->ev_stage, xfer));
+            GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
+        }
         return GBX_OK;
     }
-    // chunk c's kernels are queued and the lane's join stream waits for them
-    int chunk_launched(int64_t c, void *host_dst, const void *dev_src, size_t bytes)
+    // a result array of chunk c (call before chunk_launched(c))
+    void fetch(int64_t c, void *host_dst, const void *dev_src, size_t bytes)
     {
-        GBX_HIP(hipEventRecord(L->ev_chunk[(size_t)c], L->join));
-        fetches[(size_t)c] = Fetch{host_dst, dev_src, bytes};
+        std::lock_guard<std::mutex> lk(mu);
+        fetches.push_back(Fetch{host_dst, dev_src, bytes, (int)c});
+    }
+    // the events a launch function records when chunk c's kernels are queued (one per stream they run on)
+    hipEvent_t *join_events(int64_t c) { return &L->ev_chunk[(size_t)c * Lane::JOIN_EVENTS]; }
+    // chunk c's kernels are queued; n_events of join_events(c) were recorded (0: everything is ordered on the
+    // compute stream and one is recorded here)
+    int chunk_launched(int64_t c, int n_events = 0)
+    {
+        if (n_events == 0) {
+            GBX_HIP(hipEventRecord(join_events(c)[0], L->compute));
+            n_events = 1;
+        }
+        chunk_nev[(size_t)c] = n_events;
         if (!staged) return GBX_OK;
         std::lock_guard<std::mutex> lk(mu);
         launched = c + 1;
@@ -279,7 +316,6 @@ struct HostPipe {
         }
         // nothing of this call may still be in flight when the caller's device buffers are freed
         (void)hipStreamSynchronize(L->copy); (void)hipStreamSynchronize(L->compute);
-        (void)hipStreamSynchronize(L->join); (void)hipStreamSynchronize(L->down);
         if (rc) (void)hipDeviceSynchronize();        // kernels on the shared side streams too
         return rc;
     }

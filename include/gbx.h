@@ -40,7 +40,7 @@ int  gbx_device_count(void);            /* number of HIP devices, 0 if none; nev
 int  gbx_set_device(int dev);           /* selects the device later calls of this thread use */
 int  gbx_device_name(char *buf, size_t cap);
 /* Optional: creates the calling thread's streams and the pinned staging buffers the *_host entries use for
- * large inputs (about 110 MB of pinned host memory), so that the first large call does not pay for them.  The
+ * large inputs (about 144 MB of pinned host memory), so that the first large call does not pay for them.  The
  * counterpart of constructing the reference's aligner object before its timed region
  * (bsw/main_banded.cpp:262-270).  The *_host entries do this themselves on demand. */
 int  gbx_host_prepare(void);
