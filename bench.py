@@ -63,6 +63,23 @@ class BswWork:
         units = float((b.len1[sel].astype(np.int64) * b.len2[sel]).sum())
         return int(b.len1[sel].astype(np.int64).sum() + b.len2[sel].astype(np.int64).sum() + 36 * sel.sum()), units
 
+    def host_entry(self):
+        """PCIe-inclusive rate of the same shard through gbx_bsw_extend_host (pageable host arrays in, results
+        out): reported beside `value`, never as it."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.bsw import extend_host
+        N.check(N.lib().gbx_host_prepare())
+        ms, out = [], np.full((self.batch.n, 6), -1, dtype=np.int32)      # touched pages, like a caller's SeqPair array
+        for _ in range(3):
+            t0 = time.perf_counter()
+            extend_host(self.params, self.batch, out)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        got = self.d.results()
+        got = np.stack([got[f] for f in ("score", "tle", "gtle", "qle", "gscore", "max_off")], axis=1) if got.dtype.names else got
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": self.batch.nominal_cells / (min(ms) * 1e-3) / 1e9,
+                "unit": "GCUPS", "what": "gbx_bsw_extend_host on the rank-0 shard: H2D + kernels + D2H from pageable memory",
+                "same_as_device_entry": bool(np.array_equal(np.asarray(got), out))}
+
     def cpu_baseline(self, max_units):
         """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
         else the oracle restatement (kind 'port'); all host cores; bounded sample of the same workload."""
@@ -312,6 +329,8 @@ def main():
         }
         if not args.no_cpu:
             line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
+            if hasattr(work, "host_entry"):
+                line["host_entry"] = work.host_entry()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

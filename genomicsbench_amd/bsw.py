@@ -75,9 +75,10 @@ class BswBatch:
         return BswBatch(ref, qer, idr, idq, l1, l2, np.asarray(h0, dtype=np.int32))
 
 
-def extend_host(params, batch):
-    """gbx_bsw_extend_host -> int32[n,6] (score,tle,gtle,qle,gscore,max_off)."""
-    out = np.zeros((batch.n, 6), dtype=np.int32)
+def extend_host(params, batch, out=None):
+    """gbx_bsw_extend_host -> int32[n,6] (score,tle,gtle,qle,gscore,max_off); `out` reuses a caller's array."""
+    if out is None:
+        out = np.zeros((batch.n, 6), dtype=np.int32)
     N.check(N.lib().gbx_bsw_extend_host(C.byref(params), batch.n, N.ptr(batch.ref), batch.ref.size,
                                         N.ptr(batch.qer), batch.qer.size, N.ptr(batch.idr), N.ptr(batch.idq),
                                         N.ptr(batch.len1), N.ptr(batch.len2), N.ptr(batch.h0), N.ptr(out)))

@@ -128,8 +128,13 @@ struct HostPipe {
     std::vector<std::thread> threads;
     bool started = false;
 
+    static size_t stage_min()
+    {
+        const char *env = getenv("GBX_HOST_STAGE_MIN");      /* bytes; the tests set 0 to stage small inputs too */
+        return env ? (size_t)atoll(env) : (size_t)8 << 20;
+    }
     HostPipe(Lane *l, size_t total_bytes, bool overlap)
-        : L(l), staged(total_bytes >= ((size_t)8 << 20) && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
+        : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
           xfer(overlap ? l->copy : l->compute) {}
     ~HostPipe() { (void)finish(); }
 

@@ -147,3 +147,21 @@ def test_concurrent_host_threads():
             x.join()
         for t in range(len(batches)):
             assert_same(got[t], want[t], batches[t])
+
+
+def test_host_entry_staged_small_and_error_in_late_chunk(monkeypatch):
+    """Staging forced on a small input (one and many chunks), and an invalid pair in the last chunk: the call
+    returns the argument error, names the pair, and the next call works."""
+    b = gen_bsw(4000, 33)
+    p = make_params()
+    want = O.bsw_oracle(p, b, 4)
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    assert_same(extend_host(p, b), want, b)
+    monkeypatch.setenv("GBX_BSW_HOST_CHUNK", "512")
+    assert_same(extend_host(p, b), want, b)
+    bad = BswBatch(b.ref, b.qer, b.idr.copy(), b.idq, b.len1, b.len2, b.h0)
+    bad.idr[3999] = b.ref.size            # beyond the arena
+    with pytest.raises(N.GbxError) as e:
+        extend_host(p, bad)
+    assert e.value.code == N.GBX_ERR_ARG and "3999" in str(e.value)
+    assert_same(extend_host(p, b), want, b)

@@ -63,3 +63,16 @@ def test_generated_calls_and_device_entry():
     torch.cuda.synchronize()
     assert_same(d.results(), first)
     assert_same(first, want)
+
+
+def test_host_entry_staged_transfers(monkeypatch):
+    """The staged path of the host entry (pinned slabs, upload workers, downloader thread; normally for inputs of
+    8 MiB and more) gives the same four arrays as the pageable path and the oracle."""
+    case = gen_chain(120, 77)
+    want = O.chain_oracle(*case, nthreads=8)
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    assert_same(chain_host(*case), want)
+    monkeypatch.setenv("GBX_HOST_THREADS", "1")
+    assert_same(chain_host(*case), want)
+    monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
+    assert_same(chain_host(*case), want)

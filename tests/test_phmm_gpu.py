@@ -120,3 +120,13 @@ def test_device_entry_and_batch_subset_equivalence():
     part = forward_host(bs.take_batches(10, 20))
     lo, hi = int(bs.batch_pair_off[10]), int(bs.batch_pair_off[20])
     assert np.array_equal(part, full[lo:hi])              # sharding by whole batches changes nothing
+
+
+def test_host_entry_staged_transfers(monkeypatch):
+    """Staged host path (pinned slabs, upload workers, downloader) against the oracle; see test_chain_gpu."""
+    bs = gen_phmm(30, 515)
+    want, _ = O.phmm_oracle(bs, 8, True)
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    assert_close(forward_host(bs), want)
+    monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
+    assert_close(forward_host(bs), want)

@@ -69,3 +69,14 @@ def test_linear_gap_mode_is_rejected():
     with pytest.raises(N.GbxError) as e:
         consensus_host(make_params(o1=0, e1=2), ws)          # g >= e -> spoa's linear subtype
     assert e.value.code == N.GBX_ERR_UNSUPPORTED
+
+
+def test_host_entry_staged_transfers(monkeypatch):
+    """Staged host path (pinned slabs, upload workers, downloader) against the oracle; see test_chain_gpu."""
+    ws = gen_poa(24, 616)
+    p = make_params()
+    want = O.poa_oracle(p, ws, 8)
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    diff(consensus_host(p, ws), want)
+    monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
+    diff(consensus_host(p, ws), want)
