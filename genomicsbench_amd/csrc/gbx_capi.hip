@@ -93,20 +93,6 @@ int side_streams(SideStreams **out)
     return GBX_OK;
 }
 
-// RAII device buffer for the *_host entry points
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        if (bytes == 0) bytes = 16;
-        hipError_t e = hipMalloc(&p, bytes + 64);   // 64 B slack: kernels may read a few bytes past the last base
-        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
-        return GBX_OK;
-    }
-    template <class T> T *as() { return (T *)p; }
-};
-
 }  // namespace gbx
 
 #include "host_pipeline.h"
@@ -144,6 +130,16 @@ int gbx_host_prepare(void)
     HostLane lane;
     if ((rc = lane.acquire())) return rc;
     return lane_prepare_staging(lane.l);
+}
+
+int gbx_host_release(void)
+{
+    std::lock_guard<std::mutex> lk(HostLane::mu());
+    for (Lane *l : HostLane::idle()) {
+        for (DevBlock &b : l->dev_cache) (void)hipFree(b.p);
+        l->dev_cache.clear();
+    }
+    return GBX_OK;
 }
 
 int gbx_device_name(char *buf, size_t cap)
@@ -353,16 +349,16 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     // (own workspace each; the launch records the events a chunk's download waits for), and their results come
     // back while later chunks run.  Chunks are multiples of 64 pairs.
     const size_t wb1 = (bsw_workspace_bytes(chunk < n ? chunk : n) + 255) & ~(size_t)255;
-    DevBuf dref, dqer, didr, didq, dl1, dl2, dh0, dout, dwork;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    DevBuf dref(L), dqer(L), didr(L), didq(L), dl1(L), dl2(L), dh0(L), dout(L), dwork(L);
     if ((rc = dref.alloc((size_t)ref_bytes)) || (rc = dqer.alloc((size_t)qer_bytes)) ||
         (rc = didr.alloc(n * 8)) || (rc = didq.alloc(n * 8)) || (rc = dl1.alloc(n * 4)) ||
         (rc = dl2.alloc(n * 4)) || (rc = dh0.alloc(n * 4)) || (rc = dout.alloc(n * sizeof(gbx_bsw_result))) ||
         (rc = dwork.alloc(wb1 * (size_t)n_chunks)))
         return rc;
     mark("allocated", 0);
-    HostLane lane;
-    if ((rc = lane.acquire())) return rc;
-    Lane *L = lane.l;
     HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28, n_chunks > 1);
     if ((rc = pipe.prepare(n_chunks))) return rc;
     int64_t up_r = 0, up_q = 0;
@@ -409,20 +405,59 @@ int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t
     if (!p || n < 0) { set_error("gbx_bsw_extend_seqpairs: bad argument"); return GBX_ERR_ARG; }
     if (n == 0) return GBX_OK;
     if (!pairs) { set_error("gbx_bsw_extend_seqpairs: null pointer"); return GBX_ERR_ARG; }
+    if (!ref || !qer || ref_bytes < 0 || qer_bytes < 0) { set_error("gbx_bsw_extend_seqpairs: bad arena"); return GBX_ERR_ARG; }
+    // The reference's driver gives every pair a fixed-stride slot in the two buffers (MAX_SEQ_LEN_REF / _QER bytes,
+    // main_banded.cpp:56-58,160-172), so the arenas are mostly holes: 2 M pairs span 4.6 GB for 0.6 GB of bases.
+    // The flat arrays are extracted with a few threads, and when the layout is that sparse the bases are gathered
+    // into packed arenas first instead of sending the holes over PCIe.
+    const int T = host_workers();
     std::vector<int64_t> idr(n), idq(n);
     std::vector<int32_t> l1(n), l2(n), h0(n);
     std::vector<gbx_bsw_result> out(n);
-    for (int64_t k = 0; k < n; ++k) {
-        idr[k] = pairs[k].idr; idq[k] = pairs[k].idq;
-        l1[k] = pairs[k].len1; l2[k] = pairs[k].len2; h0[k] = pairs[k].h0;
+    std::vector<int64_t> part_r((size_t)T + 1, 0), part_q((size_t)T + 1, 0), part_bad((size_t)T, -1);
+    parallel_ranges(n, T, [&](int t, int64_t lo, int64_t hi) {
+        int64_t sr = 0, sq = 0;
+        for (int64_t k = lo; k < hi; ++k) {
+            const gbx_seqpair &sp = pairs[k];
+            if (sp.len1 < 0 || sp.len2 < 0 || sp.idr < 0 || sp.idq < 0 || sp.idr + sp.len1 > ref_bytes ||
+                sp.idq + sp.len2 > qer_bytes) { part_bad[(size_t)t] = k; return; }
+            idr[k] = sp.idr; idq[k] = sp.idq; l1[k] = sp.len1; l2[k] = sp.len2; h0[k] = sp.h0;
+            sr += (sp.len1 + 3) & ~3; sq += (sp.len2 + 3) & ~3;
+        }
+        part_r[(size_t)t + 1] = sr; part_q[(size_t)t + 1] = sq;
+    });
+    for (int t = 0; t < T; ++t)
+        if (part_bad[(size_t)t] >= 0) {
+            set_error("gbx_bsw_extend_seqpairs: pair %lld lies outside the arenas", (long long)part_bad[(size_t)t]);
+            return GBX_ERR_ARG;
+        }
+    for (int t = 0; t < T; ++t) { part_r[(size_t)t + 1] += part_r[(size_t)t]; part_q[(size_t)t + 1] += part_q[(size_t)t]; }
+    const int64_t packed_r = part_r[(size_t)T], packed_q = part_q[(size_t)T];
+    std::vector<uint8_t> cref, cqer;
+    const bool sparse = n >= 4096 && (ref_bytes + qer_bytes) > 2 * (packed_r + packed_q) + ((int64_t)1 << 20);
+    if (sparse) {
+        cref.resize((size_t)packed_r + 8); cqer.resize((size_t)packed_q + 8);
+        // same thread ranges as above, so every thread knows where its pairs start in the packed arenas
+        parallel_ranges(n, T, [&](int t, int64_t lo, int64_t hi) {
+            int64_t pr = part_r[(size_t)t], pq = part_q[(size_t)t];
+            for (int64_t k = lo; k < hi; ++k) {
+                memcpy(&cref[(size_t)pr], ref + idr[k], (size_t)l1[k]);
+                memcpy(&cqer[(size_t)pq], qer + idq[k], (size_t)l2[k]);
+                idr[k] = pr; idq[k] = pq;
+                pr += (l1[k] + 3) & ~3; pq += (l2[k] + 3) & ~3;
+            }
+        });
+        ref = cref.data(); ref_bytes = packed_r + 8; qer = cqer.data(); qer_bytes = packed_q + 8;
     }
     int rc = gbx_bsw_extend_host(p, n, ref, ref_bytes, qer, qer_bytes, idr.data(), idq.data(), l1.data(),
                                  l2.data(), h0.data(), out.data());
     if (rc) return rc;
-    for (int64_t k = 0; k < n; ++k) {
-        pairs[k].score = out[k].score; pairs[k].tle = out[k].tle; pairs[k].gtle = out[k].gtle;
-        pairs[k].qle = out[k].qle; pairs[k].gscore = out[k].gscore; pairs[k].max_off = out[k].max_off;
-    }
+    parallel_ranges(n, T, [&](int, int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            pairs[k].score = out[k].score; pairs[k].tle = out[k].tle; pairs[k].gtle = out[k].gtle;
+            pairs[k].qle = out[k].qle; pairs[k].gscore = out[k].gscore; pairs[k].max_off = out[k].max_off;
+        }
+    });
     return GBX_OK;
 }
 
@@ -462,7 +497,10 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
     if (na > 0 && (!ax || !ay)) { set_error("gbx_chain_host: null anchors"); return GBX_ERR_ARG; }
     int rc = require_device();
     if (rc) return rc;
-    DevBuf doff, dx, dy, dh, ds, dp, dt, dk, dw;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    DevBuf doff(L), dx(L), dy(L), dh(L), ds(L), dp(L), dt(L), dk(L), dw(L);
     const size_t wb = chain_workspace_bytes(n_calls, na);
     if ((rc = doff.alloc((n_calls + 1) * 8)) || (rc = dx.alloc(na * 8)) || (rc = dy.alloc(na * 8)) ||
         (rc = dh.alloc(n_calls * sizeof(gbx_chain_call))) || (rc = ds.alloc(na * 4)) || (rc = dp.alloc(na * 4)) ||
@@ -470,8 +508,6 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
         return rc;
     // one pipeline chunk (host_pipeline.h): staged uploads, the kernels on the lane's compute stream, staged
     // downloads.  The calls of a job share one load-balanced launch, so there is nothing to gain from chunks.
-    HostLane lane;
-    if ((rc = lane.acquire())) return rc;
     HostPipe pipe(lane.l, (size_t)na * 16 + (size_t)n_calls * (8 + sizeof(gbx_chain_call)), false);
     if ((rc = pipe.prepare(1))) return rc;
     pipe.stage(0, doff.p, anchor_off, (n_calls + 1) * 8);
@@ -567,7 +603,10 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         }
     int rc = require_device();
     if (rc) return rc;
-    DevBuf dpr, dph, dro, drl, drs, dq, di, dd, dc, dho, dhl, dh, dout, dw;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    DevBuf dpr(L), dph(L), dro(L), drl(L), drs(L), dq(L), di(L), dd(L), dc(L), dho(L), dhl(L), dh(L), dout(L), dw(L);
     const size_t wb = phmm_workspace_bytes(n_pairs, n_reads, max_h);
     if ((rc = dpr.alloc(n_pairs * 4)) || (rc = dph.alloc(n_pairs * 4)) || (rc = dro.alloc(n_reads * 8)) ||
         (rc = drl.alloc(n_reads * 4)) || (rc = drs.alloc(read_bytes)) || (rc = dq.alloc(read_bytes)) ||
@@ -575,8 +614,6 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         (rc = dho.alloc(n_haps * 8)) || (rc = dhl.alloc(n_haps * 4)) || (rc = dh.alloc(hap_bytes)) ||
         (rc = dout.alloc(n_pairs * 8)) || (rc = dw.alloc(wb)))
         return rc;
-    HostLane lane;
-    if ((rc = lane.acquire())) return rc;
     HostPipe pipe(lane.l, (size_t)read_bytes * 5 + (size_t)hap_bytes + (size_t)n_pairs * 8 + (size_t)(n_reads + n_haps) * 12, false);
     if ((rc = pipe.prepare(1))) return rc;
     pipe.stage(0, dpr.p, pair_read, n_pairs * 4); pipe.stage(0, dph.p, pair_hap, n_pairs * 4);
@@ -706,15 +743,16 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
     gbx_poa_plan plan;
     if ((rc = gbx_poa_plan_host(n_windows, win_first_seq, seq_len, &plan))) return rc;
     const size_t wb = gbx_poa_workspace_bytes(&plan);
-    DevBuf dwf, doff, dlen, dar, dcons, dcl, dst, dw;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    DevBuf dwf(L), doff(L), dlen(L), dar(L), dcons(L), dcl(L), dst(L), dw(L);
     if ((rc = dwf.alloc((n_windows + 1) * 8)) || (rc = doff.alloc(n_seqs * 8)) || (rc = dlen.alloc(n_seqs * 4)) ||
         (rc = dar.alloc(arena_bytes)) || (rc = dcons.alloc(n_windows * cons_stride)) || (rc = dcl.alloc(n_windows * 4)) ||
         (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
         return rc;
     std::vector<int32_t> status(n_windows);
     {
-        HostLane lane;
-        if ((rc = lane.acquire())) return rc;
         HostPipe pipe(lane.l, (size_t)arena_bytes + (size_t)n_seqs * 12 + (size_t)n_windows * 8, false);
         if ((rc = pipe.prepare(1))) return rc;
         pipe.stage(0, dwf.p, win_first_seq, (n_windows + 1) * 8);

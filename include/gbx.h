@@ -44,6 +44,8 @@ int  gbx_device_name(char *buf, size_t cap);
  * counterpart of constructing the reference's aligner object before its timed region
  * (bsw/main_banded.cpp:262-270).  The *_host entries do this themselves on demand. */
 int  gbx_host_prepare(void);
+/* Frees the device memory the *_host entries keep cached between calls (idle lanes only).  Optional. */
+int  gbx_host_release(void);
 
 /* Timing helpers on a stream (HIP events), so that a Python/ctypes host can
  * time the exact stream the kernels are launched on without touching HIP. */

@@ -165,3 +165,25 @@ def test_host_entry_staged_small_and_error_in_late_chunk(monkeypatch):
         extend_host(p, bad)
     assert e.value.code == N.GBX_ERR_ARG and "3999" in str(e.value)
     assert_same(extend_host(p, b), want, b)
+
+
+def test_seqpair_dropin_strided_slots():
+    """The reference driver's buffer layout (main_banded.cpp:56-58,160-172): pair k owns a fixed-stride slot, the
+    arenas are mostly holes.  The SeqPair entry packs the bases before upload; results as for the packed layout."""
+    b = gen_bsw(6000, 44)
+    SR, SQ = 2048, 256
+    ref = np.full(b.n * SR, 9, dtype=np.uint8)
+    qer = np.full(b.n * SQ, 9, dtype=np.uint8)
+    pairs = np.zeros(b.n, dtype=N.SEQPAIR_DTYPE)
+    for k in range(b.n):
+        ref[k * SR:k * SR + b.len1[k]] = b.ref[b.idr[k]:b.idr[k] + b.len1[k]]
+        qer[k * SQ:k * SQ + b.len2[k]] = b.qer[b.idq[k]:b.idq[k] + b.len2[k]]
+    pairs["idr"], pairs["idq"], pairs["id"] = np.arange(b.n) * SR, np.arange(b.n) * SQ, np.arange(b.n)
+    pairs["len1"], pairs["len2"], pairs["h0"] = b.len1, b.len2, b.h0
+    for f in FIELDS:
+        pairs[f] = -1
+    sw = BandedPairWiseSW(6, 1, 6, 1, 100, 5, fill_scmat(1, 4, -1), 1, 4, 1)
+    sw.getScores16(pairs, ref, qer, b.n, 1, 100)
+    got = np.stack([pairs[f] for f in FIELDS], axis=1)
+    assert_same(got, O.bsw_oracle(make_params(), b, 4), b)
+    assert np.array_equal(pairs["idr"], np.arange(b.n) * SR)       # the caller's records keep their offsets
