@@ -44,6 +44,7 @@ struct BswDev {
     int32_t col4[5];       // col4[q]    = mat[4][q]
     uint32_t row0[5];      // row0[t]    = bytes mat[t][0], mat[t][1], mat[t][2], mat[t][3]
     uint32_t row1[5];      // row1[t]    = byte  mat[t][4]
+    uint8_t remap[24];     // query class -> the class whose kernel runs it (identity, or a wider class for small jobs)
 };
 
 struct BswPairs {
@@ -196,7 +197,7 @@ __global__ void __launch_bounds__(CLS_THREADS) bsw_classify_kernel(BswDev prm, B
             }
         } else {
             const int bound = max(h0, 0) + qlen * max(prm.max_mat, 0);
-            bin = bin_of(cls_of(qlen, bound), tlen);
+            bin = bin_of(prm.remap[cls_of(qlen, bound)], tlen);
             slot = atomicAdd(&lcount[bin], 1);
         }
     }
@@ -554,6 +555,23 @@ RowKernel row_kernels[] = {
 // widest query a class holds: classes 0..7 = 16,32,..,128; 8..11 = 160,192,256,1024
 constexpr int class_qmax[NCLS - 1] = {8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 160, 192, 256, 1024};
 
+// Class modes.  Every class is a kernel launch that lasts at least as long as its longest pair, and a stream runs
+// its classes one after the other: with few pairs the 20 fine classes are latency, not work (512 pairs: 1.3 ms on
+// the device for 0.05 ms of arithmetic).  Small jobs therefore run narrower queries on a wider class's kernel
+// (idle lanes are free there): mode 2 = three classes, mode 1 = six, mode 0 = all twenty.  Thresholds from
+// `bench.py --size` sweeps; GBX_BSW_CLASSMODE overrides.
+constexpr uint8_t CLASS_REMAP[3][NCLS] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20},
+    {3, 3, 3, 3, 7, 7, 7, 7, 11, 11, 11, 11, 15, 15, 15, 15, 18, 18, 18, 19, 20},
+    {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 18, 18, 18, 19, 20},
+};
+int class_mode_for(int64_t n)
+{
+    const char *e = getenv("GBX_BSW_CLASSMODE");           /* read per call: the tests vary it */
+    if (e && *e >= '0' && *e <= '2') return *e - '0';
+    return n < 32768 ? 2 : n < 300000 ? 1 : 0;
+}
+
 RowKernel *find_row_kernel(int lpp, int cpl)
 {
     for (RowKernel &k : row_kernels)
@@ -629,6 +647,8 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     BswDev dev;
     int rc = make_dev_params(p, &dev);
     if (rc) return rc;
+    const int mode = class_mode_for(n);
+    for (int c = 0; c < NCLS; ++c) dev.remap[c] = CLASS_REMAP[mode][c];
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
     int32_t *wi = (int32_t *)d_work;
     BswWork W = {wi, wi + HDR, wi + 2 * HDR, wi + 3 * HDR, wi + WS_HDR, wi + WS_HDR + n};
@@ -664,13 +684,15 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         side_lock = std::unique_lock<std::mutex>(ss->mu);
         if ((rc = ss->fork(s))) return rc;
     }
+    int launched = 0;
     for (int c = 0; c < NCLS - 1; ++c) {
+        if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
         // Four kernel streams when the inputs are resident.  The host pipeline (join_events) uses three: the
         // runtime maps streams onto four hardware queues, and with all four busy with class kernels its copy
         // stream shares one and the uploads stall behind kernels (measured; GBX_BSW_KSTREAMS overrides).
         static const int nk_env = getenv("GBX_BSW_KSTREAMS") ? atoi(getenv("GBX_BSW_KSTREAMS")) : 0;
         const int nk = nk_env > 0 ? nk_env : join_events ? 3 : 4;
-        const int lane_k = nk >= 4 ? (c & 3) : c % nk;
+        const int lane_k = mode ? launched++ % (nk > 4 ? 4 : nk) : nk >= 4 ? (c & 3) : c % nk;
         hipStream_t sc = serial || lane_k == 0 ? s : ss->side[lane_k - 1];
         RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
         if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }

@@ -23,26 +23,34 @@ def assert_same(got, want, batch=None):
         raise AssertionError(msg)
 
 
+@pytest.fixture(params=["0", "1", "2"])
+def classmode(request, monkeypatch):
+    """The library picks fewer, wider query classes for small jobs (GBX_BSW_CLASSMODE: 0 = all twenty class
+    kernels, 1 = six, 2 = three); the small parity cases run in every mode so that each kernel is covered."""
+    monkeypatch.setenv("GBX_BSW_CLASSMODE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["realistic", "adversarial", "edge"])
-def test_goldens(name):
+def test_goldens(name, classmode):
     b, scalar, avx2 = load_bsw_golden(name)
     got = extend_host(make_params(), b)
     assert_same(got, scalar, b)
     assert np.array_equal(got[:, [0, 1, 3, 5]], avx2[:, [0, 1, 3, 5]])
 
 
-def test_edge_cases_including_empty_sequences():
+def test_edge_cases_including_empty_sequences(classmode):
     b = edge_bsw()
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_adversarial_random(seed):
+def test_adversarial_random(seed, classmode):
     b = adversarial_bsw(6000, seed)
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
 
 
-def test_long_queries_all_kernel_classes():
+def test_long_queries_all_kernel_classes(classmode):
     b = adversarial_bsw(300, 9, max_q=3000, max_t=4000)
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
 
@@ -53,14 +61,14 @@ def test_long_queries_all_kernel_classes():
     dict(w=1000, zdrop=10),
     dict(o_del=0, e_del=1, o_ins=0, e_ins=1, mat=fill_scmat(3, 1, 0)),
 ])
-def test_non_default_scoring(kw):
+def test_non_default_scoring(kw, classmode):
     p = make_params(**kw)
     b = adversarial_bsw(3000, 21)
     assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
 
 
 def test_bsw_small_config_100k():
-    """BASELINE config[0] workload (bsw 'small', 100k pairs) against the oracle."""
+    """BASELINE config[0] workload (bsw 'small', 100k pairs) against the oracle (default class mode for that size)."""
     b = gen_bsw(100_000, 1001)
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
 
