@@ -88,7 +88,8 @@ struct PhmmWork {
     int32_t *dlist;      // [n_pairs] pairs to redo in fp64
     char *scratch;       // TILED_BLOCKS * scratch_stride bytes of tile boundary rows
     int64_t scratch_stride;
-    // stream path (reads of <= STREAM_MAX_ROWS rows), all indexed by read id unless noted
+    // stream path (reads of <= stream_rows rows), all indexed by read id unless noted
+    int32_t stream_rows; // STREAM_MAX_ROWS, or 0 for small jobs: every pair takes the one-pair-per-wavefront kernels
     int64_t n_reads;
     int32_t *rcount;     // pairs of the read
     int32_t *rslen;      // stream symbols of the read: sum (H+1)
@@ -162,12 +163,12 @@ __global__ void __launch_bounds__(256) phmm_classify_kernel(PhmmArgs A, int64_t 
             // cannot produce an empty string).  Empty read: the result row is DP row 0 (M=X=0),
             // log10(0) = -inf; empty haplotype: INITIAL_CONSTANT/0 -> treat the same way.
             if (pass == 0) A.out[k] = -HUGE_VAL;
-        } else if (R <= STREAM_MAX_ROWS) {
+        } else if (R <= W.stream_rows) {
             const int rd = A.pair_read[k];
             if (pass == 0) { atomicAdd(&W.rcount[rd], 1); atomicAdd(&W.rslen[rd], H + 1); }
             else W.porder[W.rfirst[rd] + atomicAdd(&W.rcur[rd], 1)] = (int)k;
         } else {
-            cls = class_of_rows(R);
+            cls = max(class_of_rows(R), 3);       // kernels exist for classes 3..5; shorter reads (small jobs) fit class 3
             slot = atomicAdd(&lcount[cls], 1);
         }
     }
@@ -792,6 +793,13 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     W.scratch = wb + L.scratch;
     W.scratch_stride = (int64_t)scratch_stride_bytes(max_hap_len);
     W.n_reads = n_reads;
+    // Small jobs: grouping the pairs by read and laying out the haplotype streams is seven dependent launches
+    // before the first cell is computed, and the eight stream classes end in single-unit tails; below a few
+    // thousand pairs one pair per wavefront on the tiled kernels (one round of the chip) is faster.  The
+    // reference's driver calls per batch of a few hundred pairs (PairHMMUnitTest.cpp:228-245), so this is its path.
+    const char *small_env = getenv("GBX_PHMM_SMALL");
+    const bool small_job = small_env ? atoi(small_env) != 0 : n_pairs < 24000;
+    W.stream_rows = small_job ? 0 : STREAM_MAX_ROWS;
     W.rcount = (int32_t *)(wb + L.rcount); W.rslen = (int32_t *)(wb + L.rslen); W.rcur = (int32_t *)(wb + L.rcur);
     W.rfirst = (int32_t *)(wb + L.rfirst); W.rsbase = (int64_t *)(wb + L.rsbase);
     W.porder = (int32_t *)(wb + L.porder); W.soff = (int64_t *)(wb + L.soff);
@@ -808,13 +816,13 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
         // group the pairs by read, lay the haplotype streams out
         Stage st("phmm_group", s);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 0);
-        const int nblk = (int)((n_reads + SCAN_THREADS - 1) / SCAN_THREADS);
+        const int nblk = small_job ? 0 : (int)((n_reads + SCAN_THREADS - 1) / SCAN_THREADS);
         if (nblk) hipLaunchKernelGGL(phmm_read_sum_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, A, W);
-        hipLaunchKernelGGL(phmm_read_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, W, nblk);
+        if (!small_job) hipLaunchKernelGGL(phmm_read_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, W, nblk);
         if (nblk) hipLaunchKernelGGL(phmm_read_place_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, A, W);
         hipLaunchKernelGGL(phmm_classify_kernel, dim3(cb), dim3(256), 0, s, A, n_pairs, W, 1);
-        if (rb) hipLaunchKernelGGL(phmm_unit_walk_kernel, dim3(rb), dim3(256), 0, s, A, W);
-        {
+        if (rb && !small_job) hipLaunchKernelGGL(phmm_unit_walk_kernel, dim3(rb), dim3(256), 0, s, A, W);
+        if (!small_job) {
             int dev_c = 0, cus_c = 256;
             (void)hipGetDevice(&dev_c);
             (void)hipDeviceGetAttribute(&cus_c, hipDeviceAttributeMultiprocessorCount, dev_c);
@@ -829,6 +837,7 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     // the number of grouped pairs is only known on the device (work.next[0]): the copy / finish kernels are
     // launched over n_pairs slots and stop there themselves
     // the row classes are independent and each ends in a tail of single long units: they run side by side
+    if (!small_job) {
     SideStreams *ss = nullptr;
     if ((rc = side_streams(&ss))) return rc;
     std::unique_lock<std::mutex> side_lock(ss->mu);
@@ -852,6 +861,7 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     if ((rc = ss->join(s))) return rc;
     side_lock.unlock();
     { Stage st("phmm_stream_finish", s); hipLaunchKernelGGL(phmm_stream_finish_kernel, dim3(cb), dim3(256), 0, s, A, W); }
+    }
     // reads longer than STREAM_MAX_ROWS rows: one pair per wavefront, row tiles
     { Stage st("phmm_f32_rpl4", s); hipLaunchKernelGGL(phmm_f32_kernel<4>, dim3(grid(20)), dim3(64), 0, s, A, W, 3); }
     { Stage st("phmm_f32_rpl6", s); hipLaunchKernelGGL(phmm_f32_kernel<6>, dim3(grid(12)), dim3(64), 0, s, A, W, 4); }
