@@ -140,7 +140,9 @@ struct DevBuf {
             c.erase(c.begin() + (long)best);
             return GBX_OK;
         }
-        if (c.size() >= 48) {                            // sizes keep changing: do not hoard
+        size_t held = 0;
+        for (const DevBlock &b : c) held += b.cap;
+        if (c.size() >= 48 || held > cache_cap()) {      // sizes keep changing: do not hoard
             for (DevBlock &b : c) (void)hipFree(b.p);
             c.clear();
         }
@@ -156,6 +158,12 @@ struct DevBuf {
         return GBX_OK;
     }
     template <class T> T *as() { return (T *)p; }
+    // idle blocks a lane may hold before a miss empties its cache: 8 GiB of the 288 GB, GBX_HOST_CACHE_MB overrides
+    static size_t cache_cap()
+    {
+        const char *env = getenv("GBX_HOST_CACHE_MB");
+        return env ? (size_t)atoll(env) << 20 : (size_t)8 << 30;
+    }
 };
 
 // One *_host call's transfers.  Usage:
