@@ -787,20 +787,31 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    const unsigned long long below = (1ull << lane) - 1;
     int sp = 0, nr = 0;
 #ifdef GBX_POA_PHASE_STATS
     unsigned long long tv0_ = __builtin_readcyclecounter(), nvis_ = 0, nblk_ = 0;
 #endif
-    for (int i = 0; i < n; ++i) {
-        if ((st8[i] & 3) != 0) continue;
+    // The node on top of the stack and its state byte are carried in registers whenever they are known: after a
+    // push the new top is the last candidate pushed and its state was just read for the push decision, and the
+    // outer loop has read the state of the node it pushes.  Only a pop has to read them back.  The walk is
+    // bound by instruction issue (every wavefront of the CU is in some serial phase), so the loop is kept
+    // short: one overflow check per visit with a single exit, 32-bit ballots (lanes 0..11 hold the list),
+    // v_mbcnt for a lane's push slot.
+    bool overflow = false;
+    for (int i = 0; i < n && !overflow; ++i) {
+        const int st_i = st8[i];
+        if ((st_i & 3) != 0) continue;
         stk[sp++] = (short)i;
+        int top = i, top_st = st_i;
+        bool top_known = true;
         while (sp) {
 #ifdef GBX_POA_PHASE_STATS
             ++nvis_;
 #endif
-            const int id = stk[sp - 1];
-            const int stv = st8[id];
+            if (sp > POA_LDS_STACK16 - 16) { overflow = true; break; }     // a visit pushes at most 4 + 8 (+ cold, checked there)
+            const int id = top_known ? top : (int)stk[sp - 1];
+            const int stv = top_known ? top_st : (int)st8[id];
+            top_known = false;
             if ((stv & 3) == 2) { --sp; continue; }
             const int o = old[id];
             if (o >= 0 && (unsigned)(o - rb) >= 64u) {          // ranked before, outside the block
@@ -829,24 +840,29 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
             const bool need = (sa & 3) != 2;
             bool valid = true;
             // pushes in list order: hot in-edge sources, cold ones (rare, serial), aligned nodes
-            const unsigned long long pin = __ballot(is_in && need);
+            const uint32_t pin = (uint32_t)__ballot(is_in && need);
             if (pin) {
-                if (sp + __builtin_popcountll(pin) > POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
-                if (is_in && need) stk[sp + __builtin_popcountll(pin & below)] = (short)cand;
-                sp += __builtin_popcountll(pin); valid = false;
+                if (is_in && need) stk[sp + (int)__builtin_amdgcn_mbcnt_lo(pin, 0u)] = (short)cand;
+                sp += __builtin_popcount(pin); valid = false;
+                const int hi = 31 - __builtin_clz(pin);
+                top = __builtin_amdgcn_readlane(cand, hi); top_st = __builtin_amdgcn_readlane(sa, hi);
+                top_known = true;
             }
             for (int k = 4; k < ic; ++k) {
                 const int b = PG_IN_SRC(g, id, k);
                 if ((st8[b] & 3) != 2) {
-                    if (sp >= POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
+                    if (sp >= POA_LDS_STACK16 - 16) { overflow = true; break; }
                     stk[sp++] = (short)b; valid = false;
+                    top_known = false;
                 }
             }
-            const unsigned long long pal = __ballot(is_al && need);
+            const uint32_t pal = (uint32_t)__ballot(is_al && need);
             if (pal) {
-                if (sp + __builtin_popcountll(pal) > POA_LDS_STACK16) { g.err |= POA_ERR_STACK; return; }
-                if (is_al && need) { stk[sp + __builtin_popcountll(pal & below)] = (short)cand; st8[cand] = (unsigned char)(sa & 3); }
-                sp += __builtin_popcountll(pal); valid = false;
+                if (is_al && need) { stk[sp + (int)__builtin_amdgcn_mbcnt_lo(pal, 0u)] = (short)cand; st8[cand] = (unsigned char)(sa & 3); }
+                sp += __builtin_popcount(pal); valid = false;
+                const int hi = 31 - __builtin_clz(pal);
+                top = __builtin_amdgcn_readlane(cand, hi); top_st = __builtin_amdgcn_readlane(sa, hi) & 3;
+                top_known = true;
             }
             if (valid) {
                 if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 2);
@@ -859,6 +875,7 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
             } else if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 1);
         }
     }
+    if (overflow) { g.err |= POA_ERR_STACK; return; }
 #ifdef GBX_POA_PHASE_STATS
     if (lane == 0) { atomicAdd(&g_topo_dfs_cycles, __builtin_readcyclecounter() - tv0_); atomicAdd(&g_topo_visits, nvis_); atomicAdd(&g_topo_blocks, nblk_); }
 #endif
