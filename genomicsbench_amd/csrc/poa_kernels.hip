@@ -616,16 +616,30 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
     int plo = -1, phi = -1;                      // positions come out in descending order
 #define PG_PUSH(nd, ps) do { const int ps_ = (ps); if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = ps_; } \
                              if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; } while (0)
+    // A step is two dependent memory round trips: the row descriptor (first predecessor's row, letter, in-degree,
+    // node) and then the predecessor's cell.  Most steps go to the first predecessor, so that row's descriptor is
+    // requested together with its cell, and the cell that decided the move is the next step's H(i,j): a step
+    // that follows the first predecessor (or stays in the row) starts with everything but one cell in registers.
+    int Hcur = 0, d_p0 = 0, d_info = 0, d_node = 0;
+    bool h_known = false, d_known = false;
     while (!(i == 0 && j == 0)) {
-        const int Hij = PG_AT(M.H, i, j);
+        const int Hij = h_known ? Hcur : PG_AT(M.H, i, j);
         bool found = false, ext_left = false, ext_up = false;
         int node = -1, ic = 0, p0 = 0;
-        if (i != 0) { p0 = rd_pred[i - 1]; const int info = rd_info[i - 1]; ic = (info >> 8) & 0xff; node = g.r2n[i - 1];
+        int n_p0 = 0, n_info = 0, n_node = 0, Hnext = 0, info = 0;
+        bool hn_known = false, dn_first = false;          // next step: H known / descriptor = the prefetched one
+        if (i != 0) {
+            if (d_known) { p0 = d_p0; info = d_info; node = d_node; }
+            else { p0 = rd_pred[i - 1]; info = rd_info[i - 1]; node = g.r2n[i - 1]; }
+            ic = (info >> 8) & 0xff;
+            const int pr = p0 > 0 ? p0 - 1 : 0;            // descriptor of the first predecessor's row, in flight with its cell
+            n_p0 = rd_pred[pr]; n_info = rd_info[pr]; n_node = g.r2n[pr];
             if (j != 0) {
                 const int mc = (info & 0xff) == seq[j - 1] ? S.m : S.n;
                 for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
                     const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
-                    if (Hij == PG_AT(M.H, pi, j - 1) + mc) { prev_i = pi; prev_j = j - 1; found = true; }
+                    const int hd = PG_AT(M.H, pi, j - 1);
+                    if (Hij == hd + mc) { prev_i = pi; prev_j = j - 1; found = true; Hnext = hd; hn_known = true; dn_first = p == 0 && p0 > 0; }
                 }
             }
             if (!found) {
@@ -637,10 +651,11 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
                     const bool c3 = !c1 && !c2 && Hij == ov + S.c;
                     const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
                     ext_up = ext_up || c1 || c3;
-                    if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; }
+                    if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; Hnext = hv; hn_known = true; dn_first = p == 0 && p0 > 0; }
                 }
             }
         }
+        bool same_row = false;
         if (!found && j != 0) {
             const int ev = E_at(i, j - 1), hv = PG_AT(M.H, i, j - 1), qv = Q_at(i, j - 1);
             const bool c1 = Hij == ev + S.e;
@@ -648,8 +663,14 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
             const bool c3 = !c1 && !c2 && Hij == qv + S.c;
             const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
             ext_left = c1 || c3;
-            if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; }
+            if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; Hnext = hv; hn_known = true; same_row = i != 0; }
         }
+        // state for the next step
+        if (same_row) { d_p0 = p0; d_info = info; d_node = node; d_known = true; }
+        else if (dn_first) { d_p0 = n_p0; d_info = n_info; d_node = n_node; d_known = true; }
+        else d_known = false;
+        Hcur = Hnext; h_known = hn_known && !ext_left && !ext_up;
+        if (ext_left || ext_up) d_known = d_known && ext_left;      // the extension loops below move on; a left run stays in the row
         PG_PUSH(i == prev_i ? -1 : node, j == prev_j ? -1 : j - 1);
         i = prev_i; j = prev_j;
         if (ext_left) {
