@@ -622,7 +622,37 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
     // that follows the first predecessor (or stays in the row) starts with everything but one cell in registers.
     int Hcur = 0, d_p0 = 0, d_info = 0, d_node = 0;
     bool h_known = false, d_known = false;
+    // On top of that the lanes keep an 8x8 block of the H cells behind the position (rows bi-8..bi-1, columns
+    // bj-8..bj-1, one cell per lane, with the row's descriptor and the column's letter): a run of diagonal moves
+    // to first predecessors is served from registers, one gather per 4-5 steps instead of one round trip each.
+    int bi = -(1 << 20), bj = -(1 << 20), bH = 0, bP0 = 0, bInfo = 0, bNode = 0, bS = 0;
+    auto fill_block = [&](int oi, int oj) {
+        bi = oi; bj = oj;
+        const int row = max(oi - 1 - (lane >> 3), 0), col = max(oj - 1 - (lane & 7), 0);
+        bH = PG_AT(M.H, row, col);
+        const int dr = max(row - 1, 0);
+        bP0 = rd_pred[dr]; bInfo = rd_info[dr]; bNode = g.r2n[dr];
+        bS = seq[col];
+    };
     while (!(i == 0 && j == 0)) {
+        if (i != 0 && j != 0 && d_known && h_known) {
+            const int p0f = d_p0;
+            int rr = bi - 1 - p0f, cc = bj - j;
+            if ((unsigned)rr >= 8u || (unsigned)cc >= 8u) { fill_block(i, j); rr = i - 1 - p0f; cc = 0; }
+            if ((unsigned)rr < 8u) {
+                const int L = rr * 8 + cc;
+                const int hd = __builtin_amdgcn_readlane(bH, L);
+                const int mc = (d_info & 0xff) == __builtin_amdgcn_readlane(bS, L) ? S.m : S.n;
+                if (Hcur == hd + mc) {
+                    PG_PUSH(d_node, j - 1);
+                    i = p0f; j = j - 1; Hcur = hd;
+                    d_p0 = __builtin_amdgcn_readlane(bP0, L); d_info = __builtin_amdgcn_readlane(bInfo, L);
+                    d_node = __builtin_amdgcn_readlane(bNode, L); d_known = p0f > 0;
+                    if (np > g.aln_path_cap) { g.err |= POA_ERR_NODES; break; }
+                    continue;
+                }
+            }
+        }
         const int Hij = h_known ? Hcur : PG_AT(M.H, i, j);
         bool found = false, ext_left = false, ext_up = false;
         int node = -1, ic = 0, p0 = 0;
