@@ -981,6 +981,35 @@ __device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len,
         const int scode = pos >= 0 ? (int)g.coder[seq[pos]] : -1;
         const int ncode = node >= 0 ? (int)g.code[node] : -1;
         const int cnt = min(64, t0 + 1);
+        // Lane-parallel part.  Most elements land on an existing node whose predecessor element did too, over an
+        // edge that already exists: all that add_edge does then is add 2 to the edge's weight (distinct edges, so
+        // the lanes do not collide, and weights commute with everything the serial loop below appends).  Lane k
+        // looks its edge up among the first four out-edges of its predecessor's node; what it cannot settle
+        // (new nodes, new or cold edges, the first element of a chunk) stays with the serial loop.
+        unsigned long long settled;
+        {
+            const bool valid_l = pos >= 0;
+            const int simple = valid_l && node >= 0 && ncode == scode;
+            const unsigned long long vb = __ballot(valid_l) & ((1ull << lane) - 1);
+            const int prev_l = vb ? 63 - __builtin_clzll(vb) : lane;
+            const int b = __builtin_amdgcn_ds_bpermute(prev_l << 2, node);
+            const int simple_prev = __builtin_amdgcn_ds_bpermute(prev_l << 2, simple);
+            bool done = false;
+            if (simple && vb && simple_prev) {
+                const int oc = g.out_cnt[b];
+                const PoaInt4 d4 = *(const PoaInt4 *)(g.out_dst + (int64_t)b * 4);
+                int kk = -1;
+#pragma unroll
+                for (int z = 3; z >= 0; --z) if (z < oc && d4.v[z] == node) kk = z;
+                if (kk >= 0) {
+                    const int sl = g.out_slot[(int64_t)b * 4 + kk];
+                    int32_t *wp = sl < 4 ? g.in_wt + (int64_t)node * 4 + sl : g.in_wt_x + (int64_t)node * (g.deg - 4) + (sl - 4);
+                    *wp += 2;
+                    done = true;
+                }
+            }
+            settled = __ballot(done);
+        }
         for (int k = 0; k < cnt; ++k) {
             const int pos_k = rl(pos, k);
             if (pos_k == -1) continue;
@@ -1012,7 +1041,7 @@ __device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len,
                     }
                 } else id = found;
             }
-            if (head != -1) poa_add_edge_wave(g, head, id, prev_w + 1);
+            if (head != -1 && !((settled >> k) & 1)) poa_add_edge_wave(g, head, id, prev_w + 1);
             head = id;
             prev_w = 1;
         }
