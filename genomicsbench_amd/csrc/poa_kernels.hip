@@ -1149,12 +1149,13 @@ int poa_waves_per_cu(int ncap)
         (void)hipGetLastError();
         q = 8;
     }
-    // measured on MI355X (6144 windows): 6 per CU 743 ms, 8: 628, 10: 607, 12: 632 - the kernel is bound by
-    // instruction issue from ~8 wavefronts per CU on, more windows in flight only cost workspace
-    if (q > 10) q = 10;
-    if (const char *e = getenv("GBX_POA_WAVES_PER_CU")) {      // tuning aid: fewer windows in flight than the hardware admits
+    // measured on MI355X (6000 windows): 8 per CU 531 ms, 9: 528, 10: 490-500, 11: 480 (LDS admits 11 at the
+    // default node capacity) - the kernel is bound by instruction issue from ~8 wavefronts per CU on
+    const int hw = q;
+    if (q > 11) q = 11;
+    if (const char *e = getenv("GBX_POA_WAVES_PER_CU")) {      // tuning aid: another number of windows in flight (up to what the hardware admits)
         const int v = atoi(e);
-        if (v >= 1 && v < q) q = v;
+        if (v >= 1 && v <= hw) q = v;
     }
     return q;
 }
