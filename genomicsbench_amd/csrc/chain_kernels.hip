@@ -323,7 +323,12 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    const int64_t cap = (int64_t)cus * 16;
+    // One call per block, in the longest-first order of the list: the hardware dispatcher hands the next call to
+    // whichever slot frees up, i.e. a dynamic LPT schedule (a persistent grid with a static stride over the list
+    // was 102 ms on the 'large' job, this is 97 ms; calls in flight per CU: 4: 149 ms, 8: 117, 16: 103, 19 =
+    // what the 8.4 KB LDS ring admits).  GBX_CHAIN_WAVES_PER_CU caps the grid at that many blocks per CU instead.
+    const char *wenv = getenv("GBX_CHAIN_WAVES_PER_CU");
+    const int64_t cap = wenv && atoi(wenv) > 0 ? (int64_t)cus * atoi(wenv) : (int64_t)1 << 20;
     const int blocks = (int)(n_calls < cap ? n_calls : cap);
     {
         Stage st("chain_dp", s);

@@ -1088,7 +1088,13 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 #define PH_T0
 #define PH_ACC(x)
 #endif
-    for (int64_t w = blockIdx.x; w < A.n_windows; w += gridDim.x) {
+    // windows are handed out by an atomic cursor (A.cells[15]): a slot that finishes early takes the next one.  A
+    // static stride left the slots with three windows running alone for a third of the kernel.
+    for (;;) {
+        unsigned long long wq = 0;
+        if ((threadIdx.x & 63) == 0) wq = atomicAdd(A.cells + 15, 1ull);
+        const int64_t w = (int64_t)__builtin_amdgcn_readfirstlane((int)wq);
+        if (w >= A.n_windows) break;
         poa_graph_reset(g);
         T.n_sorted = 0;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
