@@ -1051,6 +1051,13 @@ __device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len,
     TOPO_TIMED(g)
 }
 
+constexpr int POA_SWEEPS = 8;
+// cells[14] = number of sequences of the job (for the window classes of the cursor sweep)
+__global__ void poa_job_stats_kernel(PoaArgs A)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) A.cells[14] = (unsigned long long)(A.win_first_seq[A.n_windows] - A.win_first_seq[0]);
+}
+
 __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
@@ -1088,13 +1095,27 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 #define PH_T0
 #define PH_ACC(x)
 #endif
-    // windows are handed out by an atomic cursor (A.cells[15]): a slot that finishes early takes the next one.  A
-    // static stride left the slots with three windows running alone for a third of the kernel.
+    // Windows are handed out by an atomic cursor (A.cells[15]): a slot that finishes early takes the next one (a
+    // static stride left the slots with three windows running alone for a third of the kernel).  The cursor
+    // sweeps the list POA_SWEEPS times, heaviest class first (sequences per window against the job's mean, A.cells[14] =
+    // their sum; the cost of a window grows with the square of that), so the tail of the kernel is made of light
+    // windows.
+    const unsigned long long nw = (unsigned long long)A.n_windows;
+    const long long seq_sum = (long long)A.cells[14];
     for (;;) {
         unsigned long long wq = 0;
         if ((threadIdx.x & 63) == 0) wq = atomicAdd(A.cells + 15, 1ull);
-        const int64_t w = (int64_t)__builtin_amdgcn_readfirstlane((int)wq);
-        if (w >= A.n_windows) break;
+        const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane((int)wq);
+        if (q32 >= (unsigned)POA_SWEEPS * (unsigned)nw) break;
+        const int pass = (int)(q32 / (unsigned)nw);
+        const int64_t w = (int64_t)(q32 % (unsigned)nw);
+        {
+            // class = floor((1.4 - sequences / mean) * 10) clamped to [0, POA_SWEEPS): 0 = 1.4 x the mean and more
+            const long long ns10 = 10ll * (long long)(A.win_first_seq[w + 1] - A.win_first_seq[w]) * (long long)nw;
+            const long long d = 14 * seq_sum - ns10;
+            const int cls = d <= 0 ? 0 : (int)min((long long)(POA_SWEEPS - 1), d / max(seq_sum, 1ll));
+            if (cls != pass) continue;
+        }
         poa_graph_reset(g);
         T.n_sorted = 0;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
@@ -1214,6 +1235,8 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
     const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
+    if (n_windows >= ((int64_t)1 << 30)) { set_error("poa: more than 2^30 windows in one call"); return GBX_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(poa_job_stats_kernel, dim3(1), dim3(64), 0, s, A);
     {
         Stage st("poa_window", s);
         hipLaunchKernelGGL(poa_kernel, dim3(grid), dim3(64), A.lds_marks ? lds_need : 0, s, A, L);
