@@ -124,8 +124,8 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     const int lane = threadIdx.x;
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
 
-    // static round-robin over the longest-first list (an LPT schedule); everything derived from `slot`
-    // stays wave-uniform
+    // one call per block when the grid allows it (chain_launch), else a stride over the longest-first list;
+    // everything derived from `slot` stays wave-uniform
     for (int slot = blockIdx.x; slot < n_calls; slot += gridDim.x) {
         const int call = W.order[slot];
         const int64_t o = off[call];
