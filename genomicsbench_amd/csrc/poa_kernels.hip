@@ -1235,7 +1235,7 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
     const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
     A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
-    if (n_windows >= ((int64_t)1 << 30)) { set_error("poa: more than 2^30 windows in one call"); return GBX_ERR_UNSUPPORTED; }
+    if (n_windows >= ((int64_t)1 << 28)) { set_error("poa: more than 2^28 windows in one call"); return GBX_ERR_UNSUPPORTED; }   // cursor: POA_SWEEPS x windows in 32 bits
     hipLaunchKernelGGL(poa_job_stats_kernel, dim3(1), dim3(64), 0, s, A);
     {
         Stage st("poa_window", s);
