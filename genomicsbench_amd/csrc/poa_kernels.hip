@@ -926,7 +926,18 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
             } else if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 1);
         }
     }
-    if (overflow) { g.err |= POA_ERR_STACK; return; }
+    if (overflow) {
+        // deeper than the LDS stack (a long fresh chain walked back node by node): redo this sort with the
+        // global-memory version, same order, and refresh the ranks kept in LDS
+        poa_topo_sort(g);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (g.err == 0) for (int r = lane; r < n; r += 64) old[g.r2n[r]] = (short)r;
+        T.n_sorted = n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return;
+    }
 #ifdef GBX_POA_PHASE_STATS
     if (lane == 0) { atomicAdd(&g_topo_dfs_cycles, __builtin_readcyclecounter() - tv0_); atomicAdd(&g_topo_visits, nvis_); atomicAdd(&g_topo_blocks, nblk_); }
 #endif
@@ -1176,7 +1187,7 @@ int poa_waves_per_cu(int ncap)
         (void)hipGetLastError();
         q = 8;
     }
-    // measured on MI355X (6000 windows): 8 per CU 531 ms, 9: 528, 10: 490-500, 11: 480 (LDS admits 11 at the
+    // measured on MI355X (6000 windows): 8 per CU 531 ms, 9: 528, 10: 490-500, 11: 480, 12: slower than 11 (LDS admits 11 at the
     // default node capacity) - the kernel is bound by instruction issue from ~8 wavefronts per CU on
     const int hw = q;
     if (q > 11) q = 11;

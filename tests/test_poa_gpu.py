@@ -80,3 +80,17 @@ def test_host_entry_staged_transfers(monkeypatch):
     diff(consensus_host(p, ws), want)
     monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
     diff(consensus_host(p, ws), want)
+
+
+def test_long_insertion_chain_deeper_than_the_lds_stack():
+    """A read with a 900-base insertion adds a chain of 900 fresh nodes; the topological sort walks it back node by
+    node, deeper than its LDS stack (768 entries), and has to fall back to the global-memory sort.  Same consensus
+    as the oracle, also for the reads added afterwards."""
+    rng = np.random.default_rng(11)
+    base = "".join(rng.choice(list("ACGT"), 300))
+    ins = "".join(rng.choice(list("ACGT"), 900))
+    long_read = base[:150] + ins + base[150:]
+    ws = PoaWindowSet.from_lists([[base, long_read, base, long_read, base[:290]],
+                                  [long_read, base, base]])
+    p = make_params()
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws))
