@@ -65,6 +65,7 @@ struct PoaArgs {
     unsigned long long *cells;        // DP cells (graph nodes x sequence length, summed over alignments)
     int ncap, deg, lmax;
     int lds_marks;                    // 1: mark/check/DFS stack live in LDS (dynamic shared memory)
+    int lds_stack;                    // entries of the DFS stack in LDS (poa_lds_plan)
     PoaScore S;
     Mat2 Tc[2][4];                    // [CPL 8 | CPL 16][(T^CPL)^(1,2,4,8)]: uniform factors of the row_shr scan steps
 };
@@ -788,7 +789,8 @@ __device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
 // "check aligned nodes" in bit 2), the DFS stack and the order being built (16-bit node ids).  The loop
 // issues no global stores (on gfx9 a load behind a store waits for the store's acknowledgement); the
 // order is written to r2n / n2r by all lanes at the end.  Same order as poa_topo_sort (poa_graph.h).
-constexpr int POA_LDS_STACK16 = 768;
+constexpr int POA_LDS_STACK16 = 256;       // largest DFS stack kept in LDS (sweep: 64 entries 436 ms, 128: 356, 192-320: 331-349,
+                                           // 376: 362); the launch may choose less (PoaTopoLds::stk_cap)
 
 #ifdef GBX_POA_PHASE_STATS
 __device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo_blocks, g_topo_dfs_cycles;
@@ -798,7 +800,8 @@ constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cac
 struct PoaTopoLds {
     unsigned char *st8;      // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
     short *old;              // [ncp] rank of the node in the previous sort (-1: node added since)
-    short *stk;              // [POA_LDS_STACK16] DFS stack
+    short *stk;              // [stk_cap] DFS stack
+    int stk_cap;             // entries; a deeper walk falls back to the global-memory sort
     short *rec;              // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
     int n_sorted;            // nodes ranked by the previous sort
 };
@@ -859,7 +862,7 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 #ifdef GBX_POA_PHASE_STATS
             ++nvis_;
 #endif
-            if (sp > POA_LDS_STACK16 - 16) { overflow = true; break; }     // a visit pushes at most 4 + 8 (+ cold, checked there)
+            if (sp > T.stk_cap - 16) { overflow = true; break; }     // a visit pushes at most 4 + 8 (+ cold, checked there)
             const int id = top_known ? top : (int)stk[sp - 1];
             const int stv = top_known ? top_st : (int)st8[id];
             top_known = false;
@@ -902,7 +905,7 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
             for (int k = 4; k < ic; ++k) {
                 const int b = PG_IN_SRC(g, id, k);
                 if ((st8[b] & 3) != 2) {
-                    if (sp >= POA_LDS_STACK16 - 16) { overflow = true; break; }
+                    if (sp >= T.stk_cap - 16) { overflow = true; break; }
                     stk[sp++] = (short)b; valid = false;
                     top_known = false;
                 }
@@ -1092,7 +1095,8 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     T.st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
     T.old = (short *)(lds_raw + ncp);
     T.stk = (short *)(lds_raw + 3 * ncp);
-    T.rec = T.stk + POA_LDS_STACK16;
+    T.stk_cap = A.lds_stack;
+    T.rec = T.stk + A.lds_stack;
     T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
@@ -1178,19 +1182,42 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 
 // wavefronts (= windows in flight) one CU keeps resident for this node capacity: registers and the LDS of
 // the topological sort decide
+// LDS of the topological sort per window: state byte + previous rank per node, the block cache, and a DFS stack
+// sized so that as many windows as the registers allow (12 per CU at 168 VGPRs) fit the CU's 160 KB: the stack
+// takes what is left of a window's share, between 128 and POA_LDS_STACK16 entries (a deeper walk falls back to the
+// global-memory sort).  Returns the bytes, or 0 when the node capacity does not fit LDS at all.
+static size_t poa_lds_plan(int ncap, int *stack_entries)
+{
+    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + 64 * POA_REC_SHORTS * 2;
+    if (ncap >= 32768) return 0;
+    for (int waves = 12; waves >= 8; --waves) {
+        // measured (node capacity 3364): twelve windows of 12304 B run together (336 ms); at 13024 B the twelfth is
+        // resident only some of the time (362-386 ms), so the budget is 12 x 12544 B, not the nominal 160 KB
+        const size_t share = ((size_t)12 * 12544 / (size_t)waves) & ~(size_t)31;
+        if (share < fixed + 128 * 2) continue;
+        size_t st = (share - fixed) / 2;
+        if (st > (size_t)POA_LDS_STACK16) st = POA_LDS_STACK16;
+        if (const char *e = getenv("GBX_POA_LDS_STACK")) { const size_t v = (size_t)atoi(e); if (v >= 32 && v <= st) st = v; }   // tuning aid
+        *stack_entries = (int)st;
+        return fixed + st * 2;
+    }
+    return 0;
+}
+
 int poa_waves_per_cu(int ncap)
 {
-    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
-    const bool lds_marks = lds_need <= 20 * 1024 && ncap < 32768;
+    int lds_stack = 0;
+    const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
+    const bool lds_marks = lds_need != 0;
     int q = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
         (void)hipGetLastError();
         q = 8;
     }
-    // measured on MI355X (6000 windows): 8 per CU 531 ms, 9: 528, 10: 490-500, 11: 480, 12: slower than 11 (LDS admits 11 at the
-    // default node capacity) - the kernel is bound by instruction issue from ~8 wavefronts per CU on
+    // measured on MI355X (6000 windows, cursor schedule): 8 per CU 410 ms, 9: 393, 10: 378, 11: 361, 12: 329 - twelve is what
+    // 168 VGPRs admit; poa_lds_plan sizes the LDS stack so that twelve fit
     const int hw = q;
-    if (q > 11) q = 11;
+    if (q > 12) q = 12;
     if (const char *e = getenv("GBX_POA_WAVES_PER_CU")) {      // tuning aid: another number of windows in flight (up to what the hardware admits)
         const int v = atoi(e);
         if (v >= 1 && v <= hw) q = v;
@@ -1244,8 +1271,10 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         }
     }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
-    const size_t lds_need = (size_t)3 * ((ncap + 15) & ~15) + (size_t)POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2;
-    A.lds_marks = (lds_need <= 20 * 1024 && ncap < 32768) ? 1 : 0;   // 8 waves per CU x 20 KB = the whole 160 KB
+    int lds_stack = 0;
+    const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
+    A.lds_marks = lds_need != 0 ? 1 : 0;
+    A.lds_stack = lds_stack;
     if (n_windows >= ((int64_t)1 << 28)) { set_error("poa: more than 2^28 windows in one call"); return GBX_ERR_UNSUPPORTED; }   // cursor: POA_SWEEPS x windows in 32 bits
     hipLaunchKernelGGL(poa_job_stats_kernel, dim3(1), dim3(64), 0, s, A);
     {

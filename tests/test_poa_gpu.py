@@ -84,7 +84,7 @@ def test_host_entry_staged_transfers(monkeypatch):
 
 def test_long_insertion_chain_deeper_than_the_lds_stack():
     """A read with a 900-base insertion adds a chain of 900 fresh nodes; the topological sort walks it back node by
-    node, deeper than its LDS stack (768 entries), and has to fall back to the global-memory sort.  Same consensus
+    node, deeper than its LDS stack (256 entries), and has to fall back to the global-memory sort.  Same consensus
     as the oracle, also for the reads added afterwards."""
     rng = np.random.default_rng(11)
     base = "".join(rng.choice(list("ACGT"), 300))
