@@ -596,11 +596,20 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         }
         if (hap_len[k] > max_h) max_h = hap_len[k];
     }
-    for (int64_t k = 0; k < n_pairs; ++k)
-        if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) {
-            set_error("gbx_phmm_forward_host: pair %lld names a read/haplotype out of range", (long long)k);
-            return GBX_ERR_ARG;
-        }
+    {
+        // the pair list is the long one (10.9 M entries in the 'large' job): a few threads, lowest bad index reported
+        const int T = host_workers();
+        std::vector<int64_t> bad((size_t)T, -1);
+        parallel_ranges(n_pairs, T, [&](int t, int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; ++k)
+                if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) { bad[(size_t)t] = k; return; }
+        });
+        for (int t = 0; t < T; ++t)
+            if (bad[(size_t)t] >= 0) {
+                set_error("gbx_phmm_forward_host: pair %lld names a read/haplotype out of range", (long long)bad[(size_t)t]);
+                return GBX_ERR_ARG;
+            }
+    }
     int rc = require_device();
     if (rc) return rc;
     HostLane lane;
