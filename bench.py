@@ -60,7 +60,7 @@ class BswWork:
         b = self.batch
         lo, hi = BSW_CLASS.get(kernel, (1, 1 << 30))
         # small jobs run several query classes on one kernel (bsw_kernels.hip: class_mode_for)
-        mode = int(os.environ.get("GBX_BSW_CLASSMODE", 2 if b.n < 32768 else 1 if b.n < 300000 else 0))
+        mode = int(os.environ.get("GBX_BSW_CLASSMODE", 2 if b.n < 32768 else 1 if b.n < 250000 else 0))
         if mode == 1:
             lo, hi = {"bsw_rows_2x16": (1, 32), "bsw_rows_4x16": (33, 64), "bsw_rows_4x24": (65, 96),
                       "bsw_rows_8x16": (97, 128), "bsw_rows_16x16": (129, 256)}.get(kernel, (lo, hi))

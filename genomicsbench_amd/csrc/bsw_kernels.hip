@@ -569,7 +569,7 @@ int class_mode_for(int64_t n)
 {
     const char *e = getenv("GBX_BSW_CLASSMODE");           /* read per call: the tests vary it */
     if (e && *e >= '0' && *e <= '2') return *e - '0';
-    return n < 32768 ? 2 : n < 300000 ? 1 : 0;
+    return n < 32768 ? 2 : n < 250000 ? 1 : 0;
 }
 
 RowKernel *find_row_kernel(int lpp, int cpl)
