@@ -73,6 +73,7 @@ def _declare(L):
     L.gbx_set_device.argtypes = [C.c_int]
     L.gbx_device_name.argtypes = [C.c_char_p, sz]
     L.gbx_host_prepare.argtypes = []
+    L.gbx_host_release.argtypes = []
     L.gbx_timer_create.argtypes = [C.POINTER(vp)]
     L.gbx_timer_start.argtypes = [vp, vp]
     L.gbx_timer_stop.argtypes = [vp, vp]

@@ -45,3 +45,16 @@ def test_mixed_kernels_from_concurrent_threads():
             t.join()
         for k, (name, _) in enumerate(jobs):
             assert same(got[k], want[k]), "%s differs when run concurrently" % name
+
+
+def test_host_cache_release_between_calls():
+    """gbx_host_release() drops the device blocks the host entries keep between calls; the next call allocates
+    afresh and gives the same results."""
+    from genomicsbench_amd import _native as N
+    pb = bsw_params()
+    b = gen_bsw(20000, 81)
+    first = extend_host(pb, b)
+    N.check(N.lib().gbx_host_release())
+    N.check(N.lib().gbx_host_prepare())
+    assert np.array_equal(extend_host(pb, b), first)
+    N.check(N.lib().gbx_host_release())
