@@ -259,8 +259,10 @@ __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswD
     const int ngroups = gridDim.x * GROUPS_PER_BLOCK;
     int next = blockIdx.x * GROUPS_PER_BLOCK + tid / LPP;
 
-    const int first = W.base[cls * NTB];
-    const int cnt = W.base[(cls + 1) * NTB] - first;
+    // cls < 0: direct mode (bsw_launch_direct) - the job's pairs 0..-cls-1 in input order, no binning pass
+    const bool direct = cls < 0;
+    const int first = direct ? 0 : W.base[cls * NTB];
+    const int cnt = direct ? -cls : W.base[(cls + 1) * NTB] - first;
     const int32_t *order = W.order + first;
     const int32_t *wband = W.wband + first;
 
@@ -296,8 +298,8 @@ __global__ void __launch_bounds__(256, rows_min_waves(CPL)) bsw_rows_kernel(BswD
             tptr = P.ref; tlen = 1; i = 0;
         }
         if (!active && next < cnt) {                                  // fetch + first row (:155-168)
-            pair = order[next];
-            w = wband[next];
+            pair = direct ? next : order[next];
+            w = direct ? band_width(prm, P.len2[pair]) : wband[next];
             next += ngroups;
             qlen = P.len2[pair]; tlen = P.len1[pair];
             const int h0 = P.h0[pair];
@@ -633,6 +635,33 @@ int make_dev_params(const gbx_bsw_params *p, BswDev *d)
 size_t bsw_workspace_bytes(int64_t n)
 {
     return (size_t)(WS_HDR + 2 * (n > 0 ? n : 0)) * sizeof(int32_t);
+}
+
+// Small jobs whose queries all fit one register class (1..256 columns, no empty sequence, scores below the
+// packed-key limit; the caller has checked): one launch of the 8x16 or 16x16 kernel over the pairs in input order, without
+// the binning passes, the stream fork and the join - the dependent launch chain is what a 512-pair call costs.
+int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,
+                      const uint8_t *d_ref, const uint8_t *d_qer, const int64_t *d_idr, const int64_t *d_idq,
+                      const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0, gbx_bsw_result *d_out, hipStream_t s)
+{
+    if (n <= 0) return GBX_OK;
+    BswDev dev;
+    int rc = make_dev_params(p, &dev);
+    if (rc) return rc;
+    for (int c = 0; c < NCLS; ++c) dev.remap[c] = (uint8_t)c;
+    BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
+    BswWork W = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (max_qlen > 256) { set_error("bsw: direct launch needs queries of at most 256"); return GBX_ERR_ARG; }
+    const int lpp = max_qlen <= 128 ? 8 : 16;
+    RowKernel *k = find_row_kernel(lpp, 16);
+    if (!k) { set_error("bsw: no %dx16 row kernel", lpp); return GBX_ERR_UNSUPPORTED; }
+    const bool sym = dev.oe_ins == dev.oe_del;
+    const int gpb = 256 / lpp;                                // groups (pairs in flight) per block
+    const int blocks = (int)((n + gpb - 1) / gpb);
+    Stage st(k->name, s);
+    hipLaunchKernelGGL(k->fn[sym], dim3(blocks), dim3(256), 0, s, dev, P, W, -(int)n);
+    GBX_HIP(hipGetLastError());
+    return GBX_OK;
 }
 
 int bsw_launch(const gbx_bsw_params *p, int64_t n,

@@ -296,10 +296,15 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     // slices of 64 Ki pairs, a few threads when there are many; the lowest failing pair is reported
     const int64_t SL = 65536, n_slices = (n + SL - 1) / SL;
     std::vector<int64_t> slice_r((size_t)n_slices), slice_q((size_t)n_slices), slice_bad((size_t)n_slices, -1);
+    std::vector<int> slice_plain((size_t)n_slices, 0);      // longest query if every pair has 1 <= qlen <= 256, tlen >= 1 and a small h0 (bsw_launch_direct), else 0
     auto check_slice = [&](int64_t sl) {
         const int64_t a = sl * SL, b = a + SL < n ? a + SL : n;
         int64_t mr = 0, mq = 0;
+        bool plain = true;
+        int maxq = 1;
         for (int64_t k = a; k < b; ++k) {
+            plain = plain && len2[k] >= 1 && len2[k] <= 256 && len1[k] >= 1 && h0[k] < 1000000;
+            maxq = len2[k] > maxq ? len2[k] : maxq;
             const int64_t er = idr[k] + len1[k], eq = idq[k] + len2[k];
             if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 || er > ref_bytes || eq > qer_bytes ||
                 len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN) {
@@ -308,7 +313,7 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
             }
             mr = er > mr ? er : mr; mq = eq > mq ? eq : mq;
         }
-        slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq;
+        slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0;
     };
     {
         const int vt = n_slices >= 8 ? 4 : 1;
@@ -377,6 +382,20 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     }
     pipe.start();
     mark("pipeline started, chunks", n_chunks);
+    // small jobs of plain pairs: one kernel launch instead of the binning passes and the class kernels
+    bool direct = n <= 16384 && n_chunks == 1 && !(getenv("GBX_BSW_DIRECT") && atoi(getenv("GBX_BSW_DIRECT")) == 0);
+    int direct_q = 1;
+    for (int64_t sl = 0; sl < n_slices && direct; ++sl) {
+        direct = slice_plain[(size_t)sl] != 0;
+        direct_q = slice_plain[(size_t)sl] > direct_q ? slice_plain[(size_t)sl] : direct_q;
+    }
+    if (direct) {
+        if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        rc = bsw_launch_direct(p, n, direct_q, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>(), didq.as<int64_t>(),
+                               dl1.as<int32_t>(), dl2.as<int32_t>(), dh0.as<int32_t>(), dout.as<gbx_bsw_result>(), L->compute);
+        if (!rc) { pipe.fetch(0, out, dout.p, n * sizeof(gbx_bsw_result)); rc = pipe.chunk_launched(0, 0); }
+        return pipe.finish(rc);
+    }
     for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
         const int64_t m = (a + chunk < n ? a + chunk : n) - a;
         if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);

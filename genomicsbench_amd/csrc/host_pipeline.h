@@ -198,9 +198,15 @@ struct HostPipe {
         const char *env = getenv("GBX_HOST_STAGE_MIN");      /* bytes; the tests set 0 to stage small inputs too */
         return env ? (size_t)atoll(env) : (size_t)8 << 20;
     }
+    // small calls on a prepared lane: the pieces are packed into one pinned slab by the calling thread and sent
+    // from there (a pageable hipMemcpyAsync of a few KB is a blocking staged copy of ~20 us each, and a call has
+    // seven to twelve of them); results come back through the pinned download slab
+    bool packed;
+    size_t pack_off = 0;
     HostPipe(Lane *l, size_t total_bytes, bool overlap)
         : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
-          xfer(overlap ? l->copy : l->compute) {}
+          xfer(overlap ? l->copy : l->compute),
+          packed(!staged && l->staged_ready && total_bytes <= Lane::PIECE / 2 && !getenv("GBX_HOST_PAGEABLE")) {}
     ~HostPipe() { (void)finish(); }
 
     int prepare(int64_t chunks)
@@ -271,6 +277,19 @@ struct HostPipe {
             for (const Fetch &f : fetches) if (f.chunk == c) mine.push_back(f);
         }
         if (!staged) {
+            size_t total = 0;
+            for (const Fetch &f : mine) total += (f.len + 63) & ~(size_t)63;
+            if (packed && total <= Lane::DOWN) {              // into the pinned slab, one wait, then out to the caller
+                size_t off = 0;
+                for (const Fetch &f : mine) {
+                    if (f.len && (e = hipMemcpyAsync(L->dslab + off, f.src, f.len, hipMemcpyDeviceToHost, xfer)) != hipSuccess) return e;
+                    off += (f.len + 63) & ~(size_t)63;
+                }
+                if ((e = hipStreamSynchronize(xfer)) != hipSuccess) return e;
+                off = 0;
+                for (const Fetch &f : mine) { memcpy(f.dst, L->dslab + off, f.len); off += (f.len + 63) & ~(size_t)63; }
+                return hipSuccess;
+            }
             for (const Fetch &f : mine)
                 if (f.len && (e = hipMemcpyAsync(f.dst, f.src, f.len, hipMemcpyDeviceToHost, xfer)) != hipSuccess)
                     return e;
@@ -325,7 +344,14 @@ struct HostPipe {
         if (!staged) {
             for (; next < pieces.size() && pieces[next].chunk <= c; ++next) {
                 const Piece &p = pieces[next];
-                GBX_HIP(hipMemcpyAsync(p.dst, p.src, p.len, hipMemcpyHostToDevice, xfer));
+                const void *src = p.src;
+                if (packed && pack_off + p.len <= Lane::PIECE) {
+                    char *slab = L->wslab[0][0] + pack_off;
+                    memcpy(slab, p.src, p.len);
+                    pack_off += (p.len + 63) & ~(size_t)63;
+                    src = slab;
+                }
+                GBX_HIP(hipMemcpyAsync(p.dst, src, p.len, hipMemcpyHostToDevice, xfer));
             }
         } else {
             std::unique_lock<std::mutex> lk(mu);

@@ -28,6 +28,7 @@ def classmode(request, monkeypatch):
     """The library picks fewer, wider query classes for small jobs (GBX_BSW_CLASSMODE: 0 = all twenty class
     kernels, 1 = six, 2 = three); the small parity cases run in every mode so that each kernel is covered."""
     monkeypatch.setenv("GBX_BSW_CLASSMODE", request.param)
+    monkeypatch.setenv("GBX_BSW_DIRECT", "0")        # small plain jobs would otherwise skip the class kernels altogether
     return request.param
 
 
@@ -195,3 +196,24 @@ def test_seqpair_dropin_strided_slots():
     got = np.stack([pairs[f] for f in FIELDS], axis=1)
     assert_same(got, O.bsw_oracle(make_params(), b, 4), b)
     assert np.array_equal(pairs["idr"], np.arange(b.n) * SR)       # the caller's records keep their offsets
+
+
+def test_direct_launch_for_small_plain_jobs(monkeypatch):
+    """Host-entry jobs of up to 16 Ki pairs whose queries are 1..256 long (no empty sequence) run as a single
+    launch of the 8x16 or 16x16 kernel in input order, without the binning passes: same results as the class path and the
+    oracle; a job with one empty or long query takes the class path."""
+    p = make_params()
+    for n, seed in ((1, 5), (63, 6), (512, 7), (5000, 8), (16384, 9)):
+        b = gen_bsw(n, seed)
+        assert b.len2.max() <= 256 and b.len2.min() >= 1 and b.len1.min() >= 1
+        want = O.bsw_oracle(p, b, 4)
+        monkeypatch.setenv("GBX_BSW_DIRECT", "1")
+        assert_same(extend_host(p, b), want, b)
+        monkeypatch.setenv("GBX_BSW_DIRECT", "0")
+        assert_same(extend_host(p, b), want, b)
+    monkeypatch.setenv("GBX_BSW_DIRECT", "1")
+    e = edge_bsw()                                     # empty sequences and long queries: not plain
+    assert_same(extend_host(p, e), O.bsw_oracle(p, e, 4), e)
+    pq = make_params(o_del=5, e_del=2, o_ins=7, e_ins=3, zdrop=50, end_bonus=9, w=37, mat=fill_scmat(2, 5, -2))
+    b = gen_bsw(3000, 10)
+    assert_same(extend_host(pq, b), O.bsw_oracle(pq, b, 4), b)      # asymmetric gaps through the direct launch
