@@ -74,6 +74,7 @@ def _declare(L):
     L.gbx_device_name.argtypes = [C.c_char_p, sz]
     L.gbx_host_prepare.argtypes = []
     L.gbx_host_release.argtypes = []
+    L.gbx_host_reserve.argtypes = [sz]
     L.gbx_timer_create.argtypes = [C.POINTER(vp)]
     L.gbx_timer_start.argtypes = [vp, vp]
     L.gbx_timer_stop.argtypes = [vp, vp]

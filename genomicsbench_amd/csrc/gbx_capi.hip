@@ -132,6 +132,21 @@ int gbx_host_prepare(void)
     return lane_prepare_staging(lane.l);
 }
 
+int gbx_host_reserve(size_t bytes)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    DevBuf b(lane.l);
+    if ((rc = b.alloc(bytes))) return rc;
+    // touch it: the allocation is committed lazily, and the wait for memory another process has just released
+    // (seconds for 10 GB) would otherwise hit whichever call uses or allocates device memory next
+    GBX_HIP(hipMemsetAsync(b.p, 0, b.cap, lane.l->compute));
+    GBX_HIP(hipStreamSynchronize(lane.l->compute));
+    return GBX_OK;                  // the block goes to the lane's cache when `b` goes out of scope
+}
+
 int gbx_host_release(void)
 {
     std::lock_guard<std::mutex> lk(HostLane::mu());
@@ -771,6 +786,9 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
     gbx_poa_plan plan;
     if ((rc = gbx_poa_plan_host(n_windows, win_first_seq, seq_len, &plan))) return rc;
     const size_t wb = gbx_poa_workspace_bytes(&plan);
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;
+    const double t_begin = wall_s();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[gbx poa host] %9.3f ms %s\n", (wall_s() - t_begin) * 1e3, what); };
     HostLane lane;
     if ((rc = lane.acquire())) return rc;
     Lane *L = lane.l;
@@ -779,6 +797,7 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         (rc = dar.alloc(arena_bytes)) || (rc = dcons.alloc(n_windows * cons_stride)) || (rc = dcl.alloc(n_windows * 4)) ||
         (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
         return rc;
+    mark("allocated");
     std::vector<int32_t> status(n_windows);
     {
         HostPipe pipe(lane.l, (size_t)arena_bytes + (size_t)n_seqs * 12 + (size_t)n_windows * 8, false);
@@ -797,7 +816,9 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         pipe.fetch(0, cons_len, dcl.p, n_windows * 4);
         pipe.fetch(0, status.data(), dst.p, n_windows * 4);
         if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+        mark("kernels queued");
         if ((rc = pipe.finish())) return rc;
+        mark("results fetched");
     }
     for (int64_t w = 0; w < n_windows; ++w)
         if (status[w]) {

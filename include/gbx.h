@@ -44,6 +44,11 @@ int  gbx_device_name(char *buf, size_t cap);
  * counterpart of constructing the reference's aligner object before its timed region
  * (bsw/main_banded.cpp:262-270).  The *_host entries do this themselves on demand. */
 int  gbx_host_prepare(void);
+/* Optional: puts one device block of `bytes` into the calling thread's lane cache, where the next *_host call
+ * that needs a buffer of about that size finds it (e.g. the poa workspace, gbx_poa_workspace_bytes of the plan:
+ * ~10 GB for the 'large' job, whose allocation can take seconds right after another process released its
+ * memory).  Like gbx_host_prepare this keeps one-time setup out of a caller's timed region. */
+int  gbx_host_reserve(size_t bytes);
 /* Frees the device memory the *_host entries keep cached between calls (idle lanes only).  Optional. */
 int  gbx_host_release(void);
 
