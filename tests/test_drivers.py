@@ -142,7 +142,8 @@ def test_drivers_fail_loudly_without_gpu(data):
 @pytest.mark.gpu
 def test_bsw_driver_end_to_end(data):
     d, b = data[0], data[1]
-    r = run([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", "1", "-b", "512", "--dump", str(d / "bsw.out")])
+    r = run([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", "1", "-b", "512", "--repeat", "2",
+             "--dump", str(d / "bsw.out")])
     assert r.returncode == 0, r.stderr
     assert "Number of input pairs: %d" % b.n in r.stdout
     got = np.loadtxt(str(d / "bsw.out"), dtype=np.int32)
@@ -182,7 +183,7 @@ def test_phmm_driver_end_to_end(data):
 @pytest.mark.gpu
 def test_poa_driver_end_to_end(data):
     d, po = data[0], data[4]
-    r = run([os.path.join(BIN, "poa"), "-s", str(d / "poa.fasta"), "-t", "1", "--print"])
+    r = run([os.path.join(BIN, "poa"), "-s", str(d / "poa.fasta"), "-t", "1", "--print", "--warmup"])
     assert r.returncode == 0, r.stderr
     lines = [ln for ln in r.stdout.split("\n") if ln]
     assert lines[0::2] == [">Consensus_sequence"] * po.n_windows
