@@ -320,6 +320,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if not args.size and os.path.exists(tpath):
             traffic = json.load(open(tpath))["bytes_per_launch"].get(name)
+        valu = None                         # VALU issue fraction of the dominant kernel, same kind of committed PMC pass
+        vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
+        if not args.size and os.path.exists(vpath):
+            valu = json.load(open(vpath))["valu_busy"].get(name)
         cfg = {"workload": work.workload,
                "parallelism": "units sharded over %d rank(s), no data-path collective" % world}
         cfg.update(work.extra)
@@ -329,7 +333,7 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy": valu, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
             "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
