@@ -112,7 +112,13 @@ class BswWork:
         got = self.d.results()[:n]
         got = np.stack([got[f] for f in ("score", "tle", "gtle", "qle", "gscore", "max_off")], axis=1) if got.dtype.names else got
         same = bool(np.array_equal(np.asarray(got)[:, cols], np.asarray(out)[:, cols]))
+        # in-band cells the algorithm actually visits (SURVEY 8d asks for them beside the nominal len1*len2): the
+        # oracle counts them on a small sample
+        m = min(n, 20000)
+        _, inband = O.bsw_oracle(self.params, self.batch.slice(0, m), min(cores, 16), return_cells=True)
+        inband_frac = inband / max(1.0, float(self.batch.slice(0, m).nominal_cells))
         return {"value": sample.nominal_cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+                "computed_over_nominal_cells": inband_frac,
                 "sample": "first %d pairs of the rank-0 shard, %s, %.2f s" % (n, what, dt),
                 "verified": "device results of these %d pairs %s the CPU run's (%d of 6 fields compared)"
                             % (n, "identical to" if same else "DIFFER from", len(cols))}
