@@ -90,14 +90,25 @@ class DeviceBswBatch:
 
     def __init__(self, batch, device):
         import torch
-        self.n = batch.n
-        self.device = device
         t = lambda a: torch.from_numpy(a).to(device)
         pad = np.zeros(64, dtype=np.uint8)
-        self.ref = t(np.concatenate([batch.ref, pad]))
-        self.qer = t(np.concatenate([batch.qer, pad]))
-        self.idr, self.idq = t(batch.idr), t(batch.idq)
-        self.len1, self.len2, self.h0 = t(batch.len1), t(batch.len2), t(batch.h0)
+        self._init(dict(ref=t(np.concatenate([batch.ref, pad])), qer=t(np.concatenate([batch.qer, pad])),
+                        idr=t(batch.idr), idq=t(batch.idq), len1=t(batch.len1), len2=t(batch.len2), h0=t(batch.h0)),
+                   device)
+
+    @classmethod
+    def from_tensors(cls, d, device):
+        """Device tensors as shard.scatter_arrays delivers them (arenas followed by >= 16 readable bytes)."""
+        self = cls.__new__(cls)
+        self._init(d, device)
+        return self
+
+    def _init(self, d, device):
+        import torch
+        self.device = device
+        self.ref, self.qer, self.idr, self.idq = d["ref"], d["qer"], d["idr"], d["idq"]
+        self.len1, self.len2, self.h0 = d["len1"], d["len2"], d["h0"]
+        self.n = int(self.len1.shape[0])
         self.out = torch.empty((max(self.n, 1), 6), dtype=torch.int32, device=device)
         self.work_bytes = N.lib().gbx_bsw_workspace_bytes(self.n)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)

@@ -33,13 +33,25 @@ class DeviceChainBatch:
 
     def __init__(self, off, ax, ay, hdr, device):
         import torch
-        self.n_calls = len(off) - 1
-        self.n_anchors = int(off[-1])
         t = lambda a: torch.from_numpy(a).to(device)
-        self.off = t(np.ascontiguousarray(off, dtype=np.int64))
-        self.ax = t(np.ascontiguousarray(ax, dtype=np.uint64).view(np.int64))
-        self.ay = t(np.ascontiguousarray(ay, dtype=np.uint64).view(np.int64))
-        self.hdr = t(np.ascontiguousarray(hdr, dtype=N.CHAIN_CALL_DTYPE).view(np.uint8))
+        self._init(dict(off=t(np.ascontiguousarray(off, dtype=np.int64)),
+                        ax=t(np.ascontiguousarray(ax, dtype=np.uint64).view(np.int64)),
+                        ay=t(np.ascontiguousarray(ay, dtype=np.uint64).view(np.int64)),
+                        hdr=t(np.ascontiguousarray(hdr, dtype=N.CHAIN_CALL_DTYPE).view(np.uint8))),
+                   int(off[-1]) if len(off) else 0, device)
+
+    @classmethod
+    def from_tensors(cls, d, device):
+        """Device tensors as shard.scatter_arrays delivers them (off int64, ax/ay int64 views, hdr bytes)."""
+        self = cls.__new__(cls)
+        self._init(d, int(d["off"][-1].item()) if d["off"].numel() else 0, device)
+        return self
+
+    def _init(self, d, n_anchors, device):
+        import torch
+        self.off, self.ax, self.ay, self.hdr = d["off"], d["ax"], d["ay"], d["hdr"]
+        self.n_calls = max(int(self.off.numel()) - 1, 0)
+        self.n_anchors = n_anchors
         n = max(self.n_anchors, 1)
         self.score, self.parent, self.target, self.peak = (torch.empty(n, dtype=torch.int32, device=device)
                                                            for _ in range(4))

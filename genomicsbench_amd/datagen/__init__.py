@@ -12,9 +12,8 @@ _lib = None
 def _L():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
-            from ..build import build_datagen
-            build_datagen()
+        from ..build import build_datagen
+        build_datagen()                      # no-op when the library is newer than datagen.c
         _lib = C.CDLL(_LIB)
         vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
         _lib.gbx_gen_bsw_lengths.argtypes = [u64, i64, i64, vp, vp, vp]
@@ -29,6 +28,16 @@ def _L():
         _lib.gbx_gen_phmm_batch.restype = None
         _lib.gbx_gen_poa_window.argtypes = [u64, i64, C.c_int, vp, vp, vp]
         _lib.gbx_gen_poa_window.restype = None
+        _lib.gbx_gen_chain_counts_many.argtypes = [u64, i64, i64, vp]
+        _lib.gbx_gen_chain_fill_many.argtypes = [u64, i64, i64, vp, vp, vp]
+        _lib.gbx_gen_phmm_counts_many.argtypes = [u64, i64, i64, vp, vp]
+        _lib.gbx_gen_phmm_lengths_many.argtypes = [u64, i64, i64, vp, vp, vp, vp]
+        _lib.gbx_gen_phmm_fill_many.argtypes = [u64, i64, i64] + [vp] * 10
+        _lib.gbx_gen_poa_counts_many.argtypes = [u64, i64, i64, vp]
+        _lib.gbx_gen_poa_many.argtypes = [u64, i64, i64, C.c_int, vp, vp, vp, vp]
+        for f in ("chain_counts_many", "chain_fill_many", "phmm_counts_many", "phmm_lengths_many", "phmm_fill_many",
+                  "poa_counts_many", "poa_many"):
+            getattr(_lib, "gbx_gen_" + f).restype = None
     return _lib
 
 
@@ -58,15 +67,16 @@ def gen_chain(n_calls, seed, first=0, n_override=None):
     """chain 'large' = (10_000, seed 2001).  Returns (anchor_off, ax, ay, hdr)."""
     from .._native import CHAIN_CALL_DTYPE
     L = _L()
-    counts = np.array([L.gbx_gen_chain_count(seed, first + c) if n_override is None else n_override[c]
-                       for c in range(n_calls)], dtype=np.int64)
+    if n_override is None:
+        counts = np.zeros(n_calls, dtype=np.int64)
+        L.gbx_gen_chain_counts_many(seed, first, n_calls, _p(counts))
+    else:
+        counts = np.array([n_override[c] for c in range(n_calls)], dtype=np.int64)
     off = np.zeros(n_calls + 1, dtype=np.int64)
     np.cumsum(counts, out=off[1:])
     ax = np.zeros(int(off[-1]), dtype=np.uint64)
     ay = np.zeros(int(off[-1]), dtype=np.uint64)
-    for c in range(n_calls):
-        L.gbx_gen_chain_fill(seed, first + c, int(counts[c]), C.c_void_p(ax.ctypes.data + 8 * int(off[c])),
-                             C.c_void_p(ay.ctypes.data + 8 * int(off[c])))
+    L.gbx_gen_chain_fill_many(seed, first, n_calls, _p(off), _p(ax), _p(ay))
     hdr = np.zeros(n_calls, dtype=CHAIN_CALL_DTYPE)
     hdr["avg_qspan"] = 15.0
     hdr["max_dist_x"] = 5000
@@ -82,26 +92,18 @@ def gen_phmm(n_batches, seed, first=0):
     L = _L()
     nr = np.zeros(n_batches, dtype=np.int32)
     nh = np.zeros(n_batches, dtype=np.int32)
-    one = lambda a, k: C.c_void_p(a.ctypes.data + a.itemsize * int(k))
-    for b in range(n_batches):
-        L.gbx_gen_phmm_batch(seed, first + b, 0, one(nr, b), one(nh, b), *([None] * 8))
+    L.gbx_gen_phmm_counts_many(seed, first, n_batches, _p(nr), _p(nh))
     roff = np.zeros(n_batches + 1, dtype=np.int64); np.cumsum(nr, out=roff[1:])
     hoff = np.zeros(n_batches + 1, dtype=np.int64); np.cumsum(nh, out=hoff[1:])
     read_len = np.zeros(int(roff[-1]), dtype=np.int32)
     hap_len = np.zeros(int(hoff[-1]), dtype=np.int32)
-    t1, t2 = C.c_int32(), C.c_int32()
-    for b in range(n_batches):
-        L.gbx_gen_phmm_batch(seed, first + b, 1, C.byref(t1), C.byref(t2), one(read_len, roff[b]),
-                             one(hap_len, hoff[b]), *([None] * 6))
+    L.gbx_gen_phmm_lengths_many(seed, first, n_batches, _p(roff), _p(hoff), _p(read_len), _p(hap_len))
     read_off = np.zeros(len(read_len) + 1, dtype=np.int64); np.cumsum(read_len, out=read_off[1:])
     hap_off = np.zeros(len(hap_len) + 1, dtype=np.int64); np.cumsum(hap_len, out=hap_off[1:])
     rs, q, qi, qd, qc = (np.zeros(int(read_off[-1]) + 8, dtype=np.uint8) for _ in range(5))
     hap = np.zeros(int(hap_off[-1]) + 8, dtype=np.uint8)
-    tl, th = np.zeros(128, np.int32), np.zeros(16, np.int32)
-    for b in range(n_batches):
-        ro, ho = read_off[roff[b]], hap_off[hoff[b]]
-        L.gbx_gen_phmm_batch(seed, first + b, 2, C.byref(t1), C.byref(t2), _p(tl), _p(th), one(rs, ro), one(q, ro),
-                             one(qi, ro), one(qd, ro), one(qc, ro), one(hap, ho))
+    L.gbx_gen_phmm_fill_many(seed, first, n_batches, _p(roff), _p(hoff), _p(read_off), _p(hap_off), _p(rs), _p(q),
+                             _p(qi), _p(qd), _p(qc), _p(hap))
     return PhmmBatchSet(nr, nh, read_off[:-1].copy(), read_len, rs, q, qi, qd, qc, hap_off[:-1].copy(), hap_len, hap)
 
 
@@ -110,17 +112,12 @@ def gen_poa(n_windows, seed, first=0):
     from ..poa import PoaWindowSet
     L = _L()
     nr = np.zeros(n_windows, dtype=np.int32)
-    one = lambda a, k: C.c_void_p(a.ctypes.data + a.itemsize * int(k))
-    for w in range(n_windows):
-        L.gbx_gen_poa_window(seed, first + w, 0, one(nr, w), None, None)
+    L.gbx_gen_poa_counts_many(seed, first, n_windows, _p(nr))
     wf = np.zeros(n_windows + 1, dtype=np.int64); np.cumsum(nr, out=wf[1:])
     lens = np.zeros(int(wf[-1]), dtype=np.int32)
-    t = C.c_int32()
-    for w in range(n_windows):
-        L.gbx_gen_poa_window(seed, first + w, 1, C.byref(t), one(lens, wf[w]), None)
-    off = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=off[1:])
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    L.gbx_gen_poa_many(seed, first, n_windows, 1, _p(wf), _p(lens), _p(off), None)
+    np.cumsum(lens, out=off[1:])
     arena = np.zeros(int(off[-1]) + 8, dtype=np.uint8)
-    tl = np.zeros(64, np.int32)
-    for w in range(n_windows):
-        L.gbx_gen_poa_window(seed, first + w, 2, C.byref(t), _p(tl), one(arena, off[wf[w]]))
+    L.gbx_gen_poa_many(seed, first, n_windows, 2, _p(wf), _p(lens), _p(off), _p(arena))
     return PoaWindowSet(wf, off[:-1].copy(), lens, arena)

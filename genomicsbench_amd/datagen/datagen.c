@@ -235,3 +235,70 @@ void gbx_gen_poa_window(uint64_t seed, int64_t window, int mode, int32_t *n_read
         if (mode == 2) { memcpy(out, buf, (size_t)o); out += o; }
     }
 }
+
+/* ---------------------------------------------------------- batched fills
+ * The per-item generators above are deterministic per (seed, item), so whole
+ * ranges are filled with one OpenMP loop (a multi-GPU bench generates every
+ * rank's shard on rank 0 before scattering it).
+ */
+void gbx_gen_chain_fill_many(uint64_t seed, int64_t first, int64_t n_calls, const int64_t *off, uint64_t *ax, uint64_t *ay)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t c = 0; c < n_calls; ++c)
+        gbx_gen_chain_fill(seed, first + c, off[c + 1] - off[c], ax + off[c], ay + off[c]);
+}
+
+void gbx_gen_phmm_counts_many(uint64_t seed, int64_t first, int64_t n_batches, int32_t *n_reads, int32_t *n_haps)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < n_batches; ++b)
+        gbx_gen_phmm_batch(seed, first + b, 0, n_reads + b, n_haps + b, 0, 0, 0, 0, 0, 0, 0, 0);
+}
+
+/* roff/hoff: first read / haplotype index of each batch (n_batches+1 entries). */
+void gbx_gen_phmm_lengths_many(uint64_t seed, int64_t first, int64_t n_batches, const int64_t *roff, const int64_t *hoff,
+                               int32_t *read_len, int32_t *hap_len)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t b = 0; b < n_batches; ++b) {
+        int32_t nr, nh;
+        gbx_gen_phmm_batch(seed, first + b, 1, &nr, &nh, read_len + roff[b], hap_len + hoff[b], 0, 0, 0, 0, 0, 0);
+    }
+}
+
+/* read_off/hap_off: byte offset of each read / haplotype in its arena. */
+void gbx_gen_phmm_fill_many(uint64_t seed, int64_t first, int64_t n_batches, const int64_t *roff, const int64_t *hoff,
+                            const int64_t *read_off, const int64_t *hap_off,
+                            char *rs, char *q, char *qi, char *qd, char *qc, char *hap)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t b = 0; b < n_batches; ++b) {
+        int32_t nr, nh, tl[128], th[16];
+        const int64_t ro = read_off[roff[b]], ho = hap_off[hoff[b]];
+        gbx_gen_phmm_batch(seed, first + b, 2, &nr, &nh, tl, th, rs + ro, q + ro, qi + ro, qd + ro, qc + ro, hap + ho);
+    }
+}
+
+void gbx_gen_poa_counts_many(uint64_t seed, int64_t first, int64_t n_windows, int32_t *n_reads)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t w = 0; w < n_windows; ++w) gbx_gen_poa_window(seed, first + w, 0, n_reads + w, 0, 0);
+}
+
+/* wf: first sequence of each window (n_windows+1); mode 1 fills seq_len, mode 2 the bytes at seq_off[wf[w]]. */
+void gbx_gen_poa_many(uint64_t seed, int64_t first, int64_t n_windows, int mode, const int64_t *wf,
+                      int32_t *seq_len, const int64_t *seq_off, char *arena)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t w = 0; w < n_windows; ++w) {
+        int32_t nr, tl[64];
+        if (mode == 1) gbx_gen_poa_window(seed, first + w, 1, &nr, seq_len + wf[w], 0);
+        else gbx_gen_poa_window(seed, first + w, 2, &nr, tl, arena + seq_off[wf[w]]);
+    }
+}
+
+void gbx_gen_chain_counts_many(uint64_t seed, int64_t first, int64_t n_calls, int64_t *counts)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < n_calls; ++c) counts[c] = gbx_gen_chain_count(seed, first + c);
+}

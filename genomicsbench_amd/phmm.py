@@ -24,16 +24,14 @@ class PhmmBatchSet:
         self.hap = u8(hap)
         # pair list: batch-major, read-major, hap-minor
         nb = len(self.n_reads)
-        rbase = np.concatenate([[0], np.cumsum(self.n_reads)])[:-1] if nb else np.zeros(0, np.int64)
         hbase = np.concatenate([[0], np.cumsum(self.n_haps)])[:-1] if nb else np.zeros(0, np.int64)
-        pr, ph = [], []
-        for b in range(nb):
-            r = np.arange(self.n_reads[b], dtype=np.int32) + np.int32(rbase[b])
-            h = np.arange(self.n_haps[b], dtype=np.int32) + np.int32(hbase[b])
-            pr.append(np.repeat(r, self.n_haps[b]))
-            ph.append(np.tile(h, self.n_reads[b]))
-        self.pair_read = np.ascontiguousarray(np.concatenate(pr) if pr else np.zeros(0), dtype=np.int32)
-        self.pair_hap = np.ascontiguousarray(np.concatenate(ph) if ph else np.zeros(0), dtype=np.int32)
+        per_read = np.repeat(self.n_haps.astype(np.int64), self.n_reads)          # pairs of each read
+        start = np.concatenate([[0], np.cumsum(per_read)])
+        total = int(start[-1])
+        self.pair_read = np.ascontiguousarray(np.repeat(np.arange(len(per_read), dtype=np.int32), per_read))
+        first_hap = np.repeat(hbase.astype(np.int64), self.n_reads)                # first haplotype of each read's batch
+        self.pair_hap = np.ascontiguousarray(np.arange(total, dtype=np.int64) - np.repeat(start[:-1], per_read)
+                                             + np.repeat(first_hap, per_read), dtype=np.int32)
         self.n_pairs = len(self.pair_read)
         self.batch_pair_off = np.concatenate([[0], np.cumsum(self.n_reads.astype(np.int64) * self.n_haps)])
 
@@ -76,13 +74,40 @@ class DevicePhmmBatchSet:
     def __init__(self, bs, device):
         import torch
         t = lambda a: torch.from_numpy(np.concatenate([a, np.zeros(16, a.dtype)])).to(device)
-        self.n_pairs, self.n_reads, self.n_haps = bs.n_pairs, len(bs.read_len), len(bs.hap_len)
-        self.pair_read, self.pair_hap = t(bs.pair_read), t(bs.pair_hap)
-        self.read_off, self.read_len = t(bs.read_off), t(bs.read_len)
-        self.rs, self.q, self.qi, self.qd, self.qc = t(bs.rs), t(bs.q), t(bs.qi), t(bs.qd), t(bs.qc)
-        self.hap_off, self.hap_len, self.hap = t(bs.hap_off), t(bs.hap_len), t(bs.hap)
+        d = {k: t(getattr(bs, k)) for k in ("read_off", "read_len", "rs", "q", "qi", "qd", "qc", "hap_off", "hap_len", "hap")}
+        self._init(d, t(bs.pair_read), t(bs.pair_hap), bs.n_pairs, len(bs.read_len), len(bs.hap_len),
+                   int(bs.hap_len.max()) if len(bs.hap_len) else 1, device)
+
+    @classmethod
+    def from_tensors(cls, d, device):
+        """Device tensors as shard.scatter_arrays delivers them: the batch table (n_reads, n_haps) and the arenas;
+        the pair list (read-major, hap-minor per batch, PairHMMUnitTest.cpp:232-244) is rebuilt on the device."""
+        import torch
+        nr, nh = d["n_reads"].long(), d["n_haps"].long()
+        per_read = torch.repeat_interleave(nh, nr)                              # pairs of each read
+        start = torch.cumsum(per_read, 0) - per_read
+        n_pairs = int(per_read.sum().item()) if per_read.numel() else 0
+        hbase = torch.cumsum(nh, 0) - nh
+        first_hap = torch.repeat_interleave(hbase, nr)
+        pair_read = torch.repeat_interleave(torch.arange(per_read.numel(), device=device), per_read)
+        pair_hap = (torch.arange(n_pairs, device=device) - torch.repeat_interleave(start, per_read)
+                    + torch.repeat_interleave(first_hap, per_read))
+        pad = torch.zeros(16, dtype=torch.int32, device=device)
+        self = cls.__new__(cls)
+        self._init(d, torch.cat([pair_read.int(), pad]), torch.cat([pair_hap.int(), pad]), n_pairs,
+                   int(d["read_len"].numel()), int(d["hap_len"].numel()),
+                   int(d["hap_len"].max().item()) if d["hap_len"].numel() else 1, device)
+        return self
+
+    def _init(self, d, pair_read, pair_hap, n_pairs, n_reads, n_haps, max_hap_len, device):
+        import torch
+        self.n_pairs, self.n_reads, self.n_haps = n_pairs, n_reads, n_haps
+        self.pair_read, self.pair_hap = pair_read, pair_hap
+        self.read_off, self.read_len = d["read_off"], d["read_len"]
+        self.rs, self.q, self.qi, self.qd, self.qc = d["rs"], d["q"], d["qi"], d["qd"], d["qc"]
+        self.hap_off, self.hap_len, self.hap = d["hap_off"], d["hap_len"], d["hap"]
         self.out = torch.empty(max(self.n_pairs, 1), dtype=torch.float64, device=device)
-        self.max_hap_len = int(bs.hap_len.max()) if len(bs.hap_len) else 1
+        self.max_hap_len = max_hap_len
         self.work_bytes = N.lib().gbx_phmm_workspace_bytes(self.n_pairs, self.n_reads, self.max_hap_len)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
 

@@ -72,14 +72,32 @@ class DevicePoaWindowSet:
 
     def __init__(self, ws, device, stride=None):
         import torch
-        self.ws = ws
-        self.n_windows = ws.n_windows
-        self.stride = stride or ws.default_stride
-        self.plan = PoaPlan()
-        N.check(N.lib().gbx_poa_plan_host(ws.n_windows, N.ptr(ws.win_first_seq), N.ptr(ws.seq_len), C.byref(self.plan)))
         t = lambda a: torch.from_numpy(a).to(device)
-        self.win_first_seq, self.seq_off, self.seq_len = t(ws.win_first_seq), t(ws.seq_off), t(ws.seq_len)
-        self.arena = t(np.concatenate([ws.arena, np.zeros(16, np.uint8)]))
+        self._init(dict(win_first_seq=t(ws.win_first_seq), seq_off=t(ws.seq_off), seq_len=t(ws.seq_len),
+                        arena=t(np.concatenate([ws.arena, np.zeros(16, np.uint8)]))),
+                   ws.win_first_seq, ws.seq_len, stride or ws.default_stride, device)
+        self.ws = ws
+
+    @classmethod
+    def from_tensors(cls, d, device, stride=None):
+        """Device tensors as shard.scatter_arrays delivers them; the plan is made from the (small) host copies of
+        the window table and the sequence lengths."""
+        wf = d["win_first_seq"].cpu().numpy()
+        sl = d["seq_len"].cpu().numpy()
+        self = cls.__new__(cls)
+        self._init(d, wf, sl, stride or int(2 * (sl.max() if len(sl) else 0) + 64), device)
+        self.ws = None
+        return self
+
+    def _init(self, d, wf_host, seq_len_host, stride, device):
+        import torch
+        wf_host = np.ascontiguousarray(wf_host, dtype=np.int64)
+        seq_len_host = np.ascontiguousarray(seq_len_host, dtype=np.int32)
+        self.n_windows = len(wf_host) - 1
+        self.stride = stride
+        self.plan = PoaPlan()
+        N.check(N.lib().gbx_poa_plan_host(self.n_windows, N.ptr(wf_host), N.ptr(seq_len_host), C.byref(self.plan)))
+        self.win_first_seq, self.seq_off, self.seq_len, self.arena = d["win_first_seq"], d["seq_off"], d["seq_len"], d["arena"]
         n = max(self.n_windows, 1)
         self.cons = torch.zeros((n, self.stride), dtype=torch.uint8, device=device)
         self.cons_len = torch.zeros(n, dtype=torch.int32, device=device)

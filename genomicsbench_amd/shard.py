@@ -29,38 +29,56 @@ def _dist():
     return dist
 
 
+_ALIGN = 256
+
+
+def pack_arrays(d):
+    """dict name -> numpy array  =>  (one uint8 buffer, [(name, dtype, shape, byte offset)]); 256-byte aligned pieces."""
+    meta, pos = [], 0
+    for k, v in d.items():
+        v = np.ascontiguousarray(v)
+        meta.append((k, str(v.dtype), tuple(v.shape), pos))
+        pos += (v.nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+    buf = np.zeros(pos + _ALIGN, dtype=np.uint8)           # trailing slack: kernels may read 16 B past an arena
+    for (k, _, _, off), v in zip(meta, d.values()):
+        v = np.ascontiguousarray(v)
+        buf[off:off + v.nbytes] = v.reshape(-1).view(np.uint8)
+    return buf, meta
+
+
+def unpack_tensor(buf, meta):
+    """Views of the pieces of a packed buffer (a uint8 torch tensor on any device) as typed tensors."""
+    out = {}
+    for k, dt, shape, off in meta:
+        tdt = _torch_dtype(dt)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+        out[k] = buf[off:off + nbytes].view(tdt).reshape(shape)
+    return out
+
+
 def scatter_arrays(per_rank, device="cpu", root=0):
     """root passes a list (one dict name -> numpy array per rank); every rank returns its own dict of torch tensors.
 
-    Implemented as a size header broadcast followed by grouped send/recv of the raw arrays."""
+    One message per rank: the arrays of a shard are packed into one byte buffer (offset table broadcast beforehand as
+    a small object), all sends posted as one group (RCCL: one grouped ncclSend/ncclRecv launch)."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
-    if rank == root:
-        meta = [{k: (str(v.dtype), tuple(v.shape)) for k, v in d.items()} for d in per_rank]
-    else:
-        meta = None
-    box = [meta]
+    packed = [pack_arrays(d) for d in per_rank] if rank == root else None
+    box = [[(m, int(b.size)) for b, m in packed] if rank == root else None]
     dist.broadcast_object_list(box, src=root)
-    meta = box[0]
-    mine = {}
+    meta, nbytes = box[0][rank]
     if rank == root:
-        reqs = []
-        for r in range(world):
-            for k, v in per_rank[r].items():
-                t = torch.from_numpy(np.ascontiguousarray(_as_signed(v))).to(device)
-                if r == root:
-                    mine[k] = t
-                else:
-                    reqs.append(dist.isend(t, dst=r))
-        for q in reqs:
-            q.wait()
+        bufs = [torch.from_numpy(b).to(device) for b, _ in packed]
+        ops = [dist.P2POp(dist.isend, bufs[r], r) for r in range(world) if r != root]
+        mine = bufs[root]
     else:
-        for k, (dt, shape) in meta[rank].items():
-            t = torch.empty(shape, dtype=_torch_dtype(dt), device=device)
-            dist.recv(t, src=root)
-            mine[k] = t
-    return mine, meta[rank]
+        mine = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ops = [dist.P2POp(dist.irecv, mine, root)]
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return unpack_tensor(mine, meta), meta
 
 
 def gather_array(local, root=0):
@@ -70,18 +88,23 @@ def gather_array(local, root=0):
     rank, world = dist.get_rank(), dist.get_world_size()
     shapes = [None] * world
     dist.all_gather_object(shapes, (tuple(local.shape), str(local.dtype)))
+    local = local.contiguous()
     if rank != root:
-        dist.send(local.contiguous(), dst=root)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root)]):
+            q.wait()
         return None
-    out = []
+    out, ops = [], []
     for r in range(world):
         if r == root:
             out.append(local)
         else:
             shape, dt = shapes[r]
             t = torch.empty(shape, dtype=getattr(torch, dt.split(".")[-1]), device=local.device)
-            dist.recv(t, src=r)
+            ops.append(dist.P2POp(dist.irecv, t, r))
             out.append(t)
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return out
 
 
@@ -104,14 +127,165 @@ def _torch_dtype(name):
 
 
 # ---- per-kernel shard builders (host side, rank 0) ---------------------------------------------------
-def bsw_shards(batch, parts):
-    """Slices a BswBatch into `parts` BswBatch views balanced by nominal cells (arenas are re-packed per shard)."""
+# A shard is a contiguous range of units, cut where the prefix sum of a per-unit cost crosses k/parts
+# of the total.  Every builder returns `parts` objects of the kernel's own batch type with arenas cut down to the
+# shard and offsets re-based, so that a shard is a self-contained input of the C-ABI; `*_to_arrays` / `*_from_arrays`
+# turn one into the flat dict scatter_arrays() ships and back.  Reference units: bsw pairs
+# (R/benchmarks/bsw/main_banded.cpp:279-291), chain calls (chain/src/host_kernel.cpp:98-107), phmm batches
+# (phmm/PairHMMUnitTest.cpp:224-247), poa windows (poa/msa_spoa_omp.cpp:230-260).
+
+def _cut_arena(arena, off, lens, align=1):
+    """Bytes [off[k], off[k]+lens[k]) of a run of units as (sub-arena, re-based offsets).
+
+    A monotone, non-overlapping layout (what every loader and generator here produces) is one slice; anything else
+    is re-packed with a vectorised gather in bounded pieces."""
+    n = len(off)
+    if n == 0:
+        return np.zeros(8, dtype=arena.dtype), np.zeros(0, dtype=np.int64)
+    off = np.asarray(off, dtype=np.int64)
+    lens64 = np.asarray(lens, dtype=np.int64)
+    if n == 1 or bool(np.all(off[1:] >= off[:-1] + lens64[:-1])):
+        lo, hi = int(off[0]), int(off[-1] + lens64[-1])
+        sub = np.empty(hi - lo + 8, dtype=arena.dtype)
+        sub[:hi - lo] = arena[lo:hi]
+        sub[hi - lo:] = 0
+        return sub, off - lo
+    al = (lens64 + align - 1) // align * align
+    new_off = np.concatenate([[0], np.cumsum(al)[:-1]]).astype(np.int64)
+    sub = np.zeros(int(al.sum()) + 8, dtype=arena.dtype)
+    step = 1 << 16
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        ln = lens64[a:b]
+        tot = int(ln.sum())
+        if tot == 0:
+            continue
+        within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+        sub[np.repeat(new_off[a:b], ln) + within] = arena[np.repeat(off[a:b], ln) + within]
+    return sub, new_off
+
+
+def bsw_cost(batch):
+    return batch.len1.astype(np.int64) * batch.len2
+
+
+def bsw_shards(batch, parts, ranges=None):
+    """`parts` BswBatch objects over contiguous pair ranges balanced by nominal cells (len1*len2)."""
     from .bsw import BswBatch
-    cost = batch.len1.astype(np.int64) * batch.len2
     out = []
-    for lo, hi in split_by_cost(cost, parts):
-        ts = [batch.ref[batch.idr[k]:batch.idr[k] + batch.len1[k]] for k in range(lo, hi)]
-        qs = [batch.qer[batch.idq[k]:batch.idq[k] + batch.len2[k]] for k in range(lo, hi)]
-        out.append(BswBatch.from_sequences(ts, qs, batch.h0[lo:hi]) if hi > lo else
-                   BswBatch(np.zeros(4, np.uint8), np.zeros(4, np.uint8), [], [], [], [], []))
+    for lo, hi in (ranges or split_by_cost(bsw_cost(batch), parts)):
+        ref, idr = _cut_arena(batch.ref, batch.idr[lo:hi], batch.len1[lo:hi], 4)
+        qer, idq = _cut_arena(batch.qer, batch.idq[lo:hi], batch.len2[lo:hi], 4)
+        out.append(BswBatch(ref, qer, idr, idq, batch.len1[lo:hi], batch.len2[lo:hi], batch.h0[lo:hi]))
     return out
+
+
+def bsw_to_arrays(b):
+    return dict(ref=b.ref, qer=b.qer, idr=b.idr, idq=b.idq, len1=b.len1, len2=b.len2, h0=b.h0)
+
+
+def bsw_from_arrays(d):
+    from .bsw import BswBatch
+    return BswBatch(*(np.asarray(d[k]) for k in ("ref", "qer", "idr", "idq", "len1", "len2", "h0")))
+
+
+def chain_cost(off):
+    """Anchors per call: every anchor looks back over a bounded window, so a call's work is linear in its length."""
+    return np.diff(np.asarray(off, dtype=np.int64))
+
+
+def chain_shards(off, ax, ay, hdr, parts, ranges=None):
+    """`parts` tuples (anchor_off, ax, ay, hdr) over contiguous call ranges balanced by anchors."""
+    off = np.asarray(off, dtype=np.int64)
+    out = []
+    for lo, hi in (ranges or split_by_cost(chain_cost(off), parts)):
+        a, b = int(off[lo]), int(off[hi])
+        out.append((off[lo:hi + 1] - a, np.ascontiguousarray(ax[a:b]), np.ascontiguousarray(ay[a:b]),
+                    np.ascontiguousarray(hdr[lo:hi])))
+    return out
+
+
+def chain_to_arrays(case):
+    off, ax, ay, hdr = case
+    return dict(off=np.ascontiguousarray(off, dtype=np.int64), ax=np.ascontiguousarray(ax, dtype=np.uint64),
+                ay=np.ascontiguousarray(ay, dtype=np.uint64), hdr=np.ascontiguousarray(hdr).view(np.uint8))
+
+
+def chain_from_arrays(d):
+    from ._native import CHAIN_CALL_DTYPE
+    return (np.asarray(d["off"]), np.asarray(d["ax"]).view(np.uint64), np.asarray(d["ay"]).view(np.uint64),
+            np.ascontiguousarray(d["hdr"]).view(np.uint8).view(CHAIN_CALL_DTYPE))
+
+
+def phmm_cost(bs):
+    """Cells of a batch = (sum of its read lengths) x (sum of its haplotype lengths): every read meets every haplotype
+    of its batch (PairHMMUnitTest.cpp:137,232-244)."""
+    rb = np.concatenate([[0], np.cumsum(bs.n_reads.astype(np.int64))])
+    hb = np.concatenate([[0], np.cumsum(bs.n_haps.astype(np.int64))])
+    rl = np.concatenate([[0], np.cumsum(bs.read_len.astype(np.int64))])
+    hl = np.concatenate([[0], np.cumsum(bs.hap_len.astype(np.int64))])
+    return (rl[rb[1:]] - rl[rb[:-1]]) * (hl[hb[1:]] - hl[hb[:-1]])
+
+
+def phmm_shards(bs, parts, ranges=None):
+    """`parts` PhmmBatchSet objects over contiguous runs of WHOLE batches (a batch's reads and haplotypes stay
+    together, so its arenas are shared by its pairs exactly as in the unsharded job), balanced by cells."""
+    from .phmm import PhmmBatchSet
+    rb = np.concatenate([[0], np.cumsum(bs.n_reads.astype(np.int64))])
+    hb = np.concatenate([[0], np.cumsum(bs.n_haps.astype(np.int64))])
+    out = []
+    for lo, hi in (ranges or split_by_cost(phmm_cost(bs), parts)):
+        r0, r1, h0, h1 = int(rb[lo]), int(rb[hi]), int(hb[lo]), int(hb[hi])
+        roff, rlen = bs.read_off[r0:r1], bs.read_len[r0:r1]
+        tracks = []
+        new_roff = None
+        for tr in (bs.rs, bs.q, bs.qi, bs.qd, bs.qc):
+            sub, new_roff = _cut_arena(tr, roff, rlen)
+            tracks.append(sub)
+        hap, new_hoff = _cut_arena(bs.hap, bs.hap_off[h0:h1], bs.hap_len[h0:h1])
+        out.append(PhmmBatchSet(bs.n_reads[lo:hi], bs.n_haps[lo:hi], new_roff, rlen, *tracks,
+                                new_hoff, bs.hap_len[h0:h1], hap))
+    return out
+
+
+_PHMM_KEYS = ("n_reads", "n_haps", "read_off", "read_len", "rs", "q", "qi", "qd", "qc", "hap_off", "hap_len", "hap")
+
+
+def phmm_to_arrays(bs):
+    return {k: getattr(bs, k) for k in _PHMM_KEYS}
+
+
+def phmm_from_arrays(d):
+    from .phmm import PhmmBatchSet
+    return PhmmBatchSet(*(np.asarray(d[k]) for k in _PHMM_KEYS))
+
+
+def poa_cost(ws):
+    """DP cells of a window ~ sum over its sequences of (graph nodes when it is aligned) x (its length); the graph
+    starts as the first sequence and grows by about a tenth of every later one, so with n sequences of mean length
+    L the sum is ~ n L^2 (1 + n/20): quadratic in the window's depth (poa/msa_spoa_omp.cpp:237-252)."""
+    wf = ws.win_first_seq
+    cl = np.concatenate([[0], np.cumsum(ws.seq_len.astype(np.int64))])
+    tot = (cl[wf[1:]] - cl[wf[:-1]]).astype(np.float64)
+    n = np.maximum(np.diff(wf), 1).astype(np.float64)
+    return tot * (tot / n) * (1.0 + n / 20.0)
+
+
+def poa_shards(ws, parts, ranges=None):
+    """`parts` PoaWindowSet objects over contiguous window ranges balanced by poa_cost."""
+    from .poa import PoaWindowSet
+    out = []
+    for lo, hi in (ranges or split_by_cost(poa_cost(ws), parts)):
+        a, b = int(ws.win_first_seq[lo]), int(ws.win_first_seq[hi])
+        arena, off = _cut_arena(ws.arena, ws.seq_off[a:b], ws.seq_len[a:b])
+        out.append(PoaWindowSet(ws.win_first_seq[lo:hi + 1] - a, off, ws.seq_len[a:b], arena))
+    return out
+
+
+def poa_to_arrays(ws):
+    return dict(win_first_seq=ws.win_first_seq, seq_off=ws.seq_off, seq_len=ws.seq_len, arena=ws.arena)
+
+
+def poa_from_arrays(d):
+    from .poa import PoaWindowSet
+    return PoaWindowSet(*(np.asarray(d[k]) for k in ("win_first_seq", "seq_off", "seq_len", "arena")))
