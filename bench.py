@@ -1,14 +1,24 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark: bsw 'large' GCUPS on N MI355X (BASELINE.json), one JSON line on rank 0.
 
-    python bench.py [--gpus N --steps K --warmup W]            # bsw large (the headline metric)
-    python bench.py --kernel chain|phmm|poa                    # the other three DP kernels, same JSON shape
+    python bench.py [--gpus N --steps K --warmup W]     # bsw large = the headline; chain, phmm and poa 'large' follow
+                                                        # under "kernels" in the same JSON line
+    python bench.py --kernel bsw|chain|phmm|poa         # one kernel only, same JSON shape
+    python bench.py --mode local                        # every rank generates its own shard (no scatter / gather)
 
-A step = one pass of the kernel's hot path (every launch of the *_device entry point) over this
-rank's shard of the synthetic dataset, inputs resident in HBM.  Work units are independent, so ranks
-shard them with no data-path collective ("weak": per-GPU work fixed); value = units of ALL ranks per
-second of the slowest rank.  Per-kernel durations come from HIP events recorded around every launch on
-the launch stream inside the timed region (gbx_profile_begin/end).
+A step = one pass of the kernel's hot path (every launch of the *_device entry point) over this rank's shard of the
+synthetic dataset, inputs resident in HBM.  Work units are independent (pairs / calls / batches / windows), so
+the job shards over ranks with no data-path collective ("weak": the dataset is N x the 'large' config):
+
+  mode "scatter" (default): rank 0 owns the whole dataset, cuts it into N cost-balanced contiguous shards
+  (genomicsbench_amd/shard.py), ships each shard as one packed message over RCCL point-to-point (scatter_ms),
+  every rank runs the timed steps on its HBM-resident shard, rank 0 gathers the fixed-stride outputs (gather_ms)
+  and checks units from every rank's shard against the CPU oracle.  With N = 1 the scatter is the H2D copy and the
+  gather the D2H copy.
+
+value = units of ALL ranks per second of the slowest rank over the K timed steps (barrier + synchronize on both
+sides).  Per-kernel durations come from HIP events recorded around every launch on the launch stream inside the
+timed region (gbx_profile_begin/end).
 """
 import argparse
 import ctypes as C
@@ -41,17 +51,48 @@ PHMM_CLASS.update({"phmm_f32_rpl4": (249, 256), "phmm_f32_rpl6": (257, 384), "ph
 class BswWork:
     metric, unit, dtype = "bsw_large_gcups", "GCUPS", "int32"
 
-    def __init__(self, args, rank, dev):
-        from genomicsbench_amd.bsw import DeviceBswBatch, make_params
-        from genomicsbench_amd.datagen import gen_bsw
-        self.n = args.size or 2_000_000
+    large, seed = 2_000_000, 1002
+
+    def __init__(self, args):
+        from genomicsbench_amd.bsw import make_params
+        self.n = args.size or self.large
         self.params = make_params()
-        self.batch = gen_bsw(self.n, 1002, first=rank * self.n)
-        self.d = DeviceBswBatch(self.batch, dev)
-        self.units = float(self.batch.nominal_cells)
-        self.workload = ("bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), "
-                         "nominal cells = sum len1*len2" % self.n)
-        self.extra = {"pairs_per_gpu": self.n, "nominal_cells_per_gpu": self.batch.nominal_cells}
+        self.workload = ("bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), inputs resident "
+                         "in HBM, nominal cells = sum len1*len2" % self.n)
+
+    # host side (rank 0 in scatter mode, every rank in local mode)
+    def generate(self, first, n_units):
+        from genomicsbench_amd.datagen import gen_bsw
+        return gen_bsw(n_units, self.seed, first=first)
+
+    def shards(self, full, parts):
+        return S.bsw_shards(full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.bsw_to_arrays(sh))
+    n_units = staticmethod(lambda sh: sh.n)
+
+    def attach(self, tensors, dev, host_shard):
+        """tensors: this rank's shard in HBM (from the scatter); host_shard: its host copy where it exists (rank 0)."""
+        from genomicsbench_amd.bsw import DeviceBswBatch
+        self.d = DeviceBswBatch.from_tensors(tensors, dev)
+        self.batch = host_shard
+        self.units = float((self.d.len1.long() * self.d.len2.long()).sum().item())
+        self.extra = {"pairs_this_gpu": self.d.n, "nominal_cells_this_gpu": int(self.units)}
+
+    def output_tensor(self):
+        return self.d.out[:self.d.n]
+
+    def check_gathered(self, full, ranges, parts, sample):
+        """Units from the front of every rank's shard: gathered device results == the oracle's, all 6 fields."""
+        from oracle import oracle_py as O
+        bad = checked = 0
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                want = O.bsw_oracle(self.params, full.slice(lo, lo + m), min(os.cpu_count() or 1, 32))
+                bad += int(not np.array_equal(got[:m].cpu().numpy(), want))
+                checked += m
+        return "%d pairs (front of every shard) vs oracle, all 6 fields: %s" % (checked, "identical" if not bad else "DIFFER")
 
     def run(self, stream):
         self.d.run(self.params, stream)
@@ -97,17 +138,21 @@ class BswWork:
         ref = O.ref_lib("bsw")
         if ref is not None and hasattr(ref, "ref_bsw_getscores16_mt"):
             out = np.zeros((n, 6), dtype=np.int32)
-            secs, best = C.c_double(0.0), None
-            for _ in range(3):      # best of 3; the driver's own timed region (objects are built outside it)
+            secs, runs = C.c_double(0.0), []
+            for _ in range(5):      # median of 5; the driver's own timed region (objects built outside it)
                 ref.ref_bsw_getscores16_mt(*O._bsw_args(self.params, sample, out), C.c_int32(512), C.c_int32(cores),
                                            C.byref(secs))
-                best = secs.value if best is None else min(best, secs.value)
-            kind, dt, what = "reference", best, "reference AVX2 getScores16 -b 512, one object per thread"
+                runs.append(secs.value)
+            kind, dt = "reference", float(np.median(runs))
+            what = "reference AVX2 getScores16 -b 512, one object per thread, median of 5"
             cols = [0, 1, 3, 5]     # score, tle, qle, max_off: the fields the AVX2 path defines like the scalar one
         else:
-            t0 = time.perf_counter()
-            out = O.bsw_oracle(self.params, sample, cores)
-            kind, dt, what = "port", time.perf_counter() - t0, "oracle/bsw_oracle.c scalar restatement, OpenMP"
+            runs = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                out = O.bsw_oracle(self.params, sample, cores)
+                runs.append(time.perf_counter() - t0)
+            kind, dt, what = "port", float(np.median(runs)), "oracle/bsw_oracle.c scalar restatement, OpenMP, median of 5"
             cols = [0, 1, 2, 3, 4, 5]
         got = self.d.results()[:n]
         got = np.stack([got[f] for f in ("score", "tle", "gtle", "qle", "gscore", "max_off")], axis=1) if got.dtype.names else got
@@ -127,16 +172,48 @@ class BswWork:
 class ChainWork:
     metric, unit, dtype = "chain_large_gcups", "GCUPS", "int32+f64"
 
-    def __init__(self, args, rank, dev):
-        from genomicsbench_amd.chain import DeviceChainBatch
-        from genomicsbench_amd.datagen import gen_chain
-        self.n = args.size or 10_000
-        self.case = gen_chain(self.n, 2001, first=rank * self.n)
-        self.d = DeviceChainBatch(*self.case, dev)
-        self.units = None                                   # evaluated predecessor pairs: read from the device counter
-        self.workload = ("chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), "
+    large, seed = 10_000, 2001
+
+    def __init__(self, args):
+        self.n = args.size or self.large
+        self.workload = ("chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), inputs resident in HBM, "
                          "cell = evaluated predecessor pair" % self.n)
-        self.extra = {"calls_per_gpu": self.n, "anchors_per_gpu": int(self.case[0][-1])}
+
+    def generate(self, first, n_units):
+        from genomicsbench_amd.datagen import gen_chain
+        return gen_chain(n_units, self.seed, first=first)
+
+    def shards(self, full, parts):
+        return S.chain_shards(*full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.chain_to_arrays(sh))
+    n_units = staticmethod(lambda sh: len(sh[0]) - 1)
+
+    def attach(self, tensors, dev, host_shard):
+        from genomicsbench_amd.chain import DeviceChainBatch
+        self.d = DeviceChainBatch.from_tensors(tensors, dev)
+        self.case = host_shard
+        self.units = None                                   # evaluated predecessor pairs: read from the device counter
+        self.extra = {"calls_this_gpu": self.d.n_calls, "anchors_this_gpu": self.d.n_anchors}
+
+    def output_tensor(self):
+        import torch
+        k = self.d.n_anchors
+        return torch.stack([self.d.score[:k], self.d.parent[:k], self.d.target[:k], self.d.peak[:k]], dim=1)
+
+    def check_gathered(self, full, ranges, parts, sample):
+        from oracle import oracle_py as O
+        off = full[0]
+        bad = checked = 0
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                sub = S.chain_shards(*full, 1, ranges=[(lo, lo + m)])[0]
+                want = np.stack(O.chain_oracle(*sub, nthreads=min(os.cpu_count() or 1, 32)), axis=1)
+                bad += int(not np.array_equal(got[:len(want)].cpu().numpy(), want))
+                checked += len(want)
+        return ("%d anchors (front of every shard) vs oracle, score/parent/target/peak: %s"
+                % (checked, "identical" if not bad else "DIFFER"))
 
     def run(self, stream):
         self.d.run(stream)
@@ -146,13 +223,13 @@ class ChainWork:
         self.extra["evaluated_pairs_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        return 40 * int(self.case[0][-1]), self.units        # 16 B anchor + 4x4 B outputs + 8 B re-read of score/parent
+        return 32 * self.d.n_anchors, self.units             # 16 B anchor in + 4 x 4 B outputs (16 in + 8 out + 8)
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
-        n = min(self.n, max_units or 2000)
         off, ax, ay, hdr = self.case
+        n = min(len(off) - 1, max_units or 2000)
         sub = (off[:n + 1], ax[:off[n]], ay[:off[n]], hdr[:n])
         ref = O.ref_lib("chain")
         t0 = time.perf_counter()
@@ -175,16 +252,53 @@ class ChainWork:
 class PhmmWork:
     metric, unit, dtype = "phmm_large_gcups", "GCUPS", "f32"
 
-    def __init__(self, args, rank, dev):
+    large, seed = 20_000, 3001
+
+    def __init__(self, args):
+        self.n = args.size or self.large
+        self.workload = ("phmm large: %d synthetic GATK batches per GPU (seed 3001), inputs resident in HBM, "
+                         "cell = rslen*haplen; fp32 with fp64 redo below 1e-28" % self.n)
+
+    def generate(self, first, n_units):
         from genomicsbench_amd.datagen import gen_phmm
+        return gen_phmm(n_units, self.seed, first=first)
+
+    def shards(self, full, parts):
+        return S.phmm_shards(full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.phmm_to_arrays(sh))
+    n_units = staticmethod(lambda sh: len(sh.n_reads))
+
+    def attach(self, tensors, dev, host_shard):
         from genomicsbench_amd.phmm import DevicePhmmBatchSet
-        self.n = args.size or 20_000
-        self.bs = gen_phmm(self.n, 3001, first=rank * self.n)
-        self.d = DevicePhmmBatchSet(self.bs, dev)
-        self.units = float(self.bs.cells)
-        self.workload = ("phmm large: %d synthetic GATK batches per GPU (seed 3001), %d read x haplotype pairs, "
-                         "cell = rslen*haplen; fp32 with fp64 redo below 1e-28" % (self.n, self.bs.n_pairs))
-        self.extra = {"batches_per_gpu": self.n, "pairs_per_gpu": self.bs.n_pairs, "cells_per_gpu": self.bs.cells}
+        self.d = DevicePhmmBatchSet.from_tensors(tensors, dev)
+        self.bs = host_shard
+        d = self.d
+        rl = d.read_len[d.pair_read[:d.n_pairs].long()].long()
+        hl = d.hap_len[d.pair_hap[:d.n_pairs].long()].long()
+        self.units = float((rl * hl).sum().item())
+        self.extra = {"batches_this_gpu": int(tensors["n_reads"].numel()), "pairs_this_gpu": d.n_pairs,
+                      "cells_this_gpu": int(self.units)}
+
+    def output_tensor(self):
+        return self.d.out[:self.d.n_pairs]
+
+    def check_gathered(self, full, ranges, parts, sample):
+        from oracle import oracle_py as O
+        worst, checked, ok = 0.0, 0, True
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                sub = full.take_batches(lo, lo + m)
+                want = O.phmm_oracle(sub, min(os.cpu_count() or 1, 32))
+                g = got[:sub.n_pairs].cpu().numpy()
+                fin = np.isfinite(want)
+                ok &= bool(np.array_equal(np.isfinite(g), fin))
+                if fin.any():
+                    worst = max(worst, float(np.max(np.abs(g[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0))))
+                checked += sub.n_pairs
+        return ("%d pairs (front of every shard) vs oracle: max rel err %.2e (bound 1e-5): %s"
+                % (checked, worst, "within tolerance" if ok and worst <= 1e-5 else "DIFFER"))
 
     def run(self, stream):
         self.d.run(stream)
@@ -199,7 +313,7 @@ class PhmmWork:
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
-        sub = self.bs.take_batches(0, min(self.n, max_units or 400))
+        sub = self.bs.take_batches(0, min(len(self.bs.n_reads), max_units or 400))
         t0 = time.perf_counter()
         want = O.phmm_oracle(sub, cores)
         dt = time.perf_counter() - t0
@@ -217,18 +331,60 @@ class PhmmWork:
 class PoaWork:
     metric, unit, dtype = "poa_large_gcups", "GCUPS", "int16"
 
-    def __init__(self, args, rank, dev):
-        from genomicsbench_amd.datagen import gen_poa
-        from genomicsbench_amd.poa import DevicePoaWindowSet, make_params
-        self.n = args.size or 6_000
+    large, seed = 6_000, 4001
+
+    def __init__(self, args):
+        from genomicsbench_amd.poa import make_params
+        self.n = args.size or self.large
         self.params = make_params()
-        self.ws = gen_poa(self.n, 4001, first=rank * self.n)
-        self.d = DevicePoaWindowSet(self.ws, dev)
-        self.units = None                                   # graph nodes x sequence length, device counter
-        self.workload = ("poa large: %d synthetic 500-bp consensus windows per GPU (seed 4001), "
+        self.workload = ("poa large: %d synthetic 500-bp consensus windows per GPU (seed 4001), inputs resident in HBM, "
                          "cell = graph node x sequence position per alignment" % self.n)
-        self.extra = {"windows_per_gpu": self.n, "sequences_per_gpu": self.ws.n_seqs,
+
+    def generate(self, first, n_units):
+        from genomicsbench_amd.datagen import gen_poa
+        return gen_poa(n_units, self.seed, first=first)
+
+    def shards(self, full, parts):
+        return S.poa_shards(full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.poa_to_arrays(sh))
+    n_units = staticmethod(lambda sh: sh.n_windows)
+
+    def attach(self, tensors, dev, host_shard):
+        from genomicsbench_amd.poa import DevicePoaWindowSet
+        self.d = DevicePoaWindowSet.from_tensors(tensors, dev)
+        self.ws = host_shard
+        self.units = None                                   # graph nodes x sequence length, device counter
+        self.extra = {"windows_this_gpu": self.d.n_windows, "sequences_this_gpu": int(tensors["seq_len"].numel()),
                       "workspace_gb": round(self.d.work_bytes / 1e9, 2)}
+
+    def output_tensor(self):
+        """Fixed-stride records: int32 status, int32 length, consensus bytes."""
+        import torch
+        d = self.d
+        n = d.n_windows
+        head = torch.stack([d.status[:n], d.cons_len[:n]], dim=1).contiguous().view(torch.uint8)
+        return torch.cat([head, d.cons[:n]], dim=1)
+
+    @staticmethod
+    def decode(rec):
+        rec = rec.cpu().numpy()
+        if not len(rec):
+            return []
+        head = np.ascontiguousarray(rec[:, :8]).view(np.int32)
+        assert not head[:, 0].any(), "a window overflowed a device capacity"
+        return [rec[w, 8:8 + head[w, 1]].tobytes().decode() for w in range(len(rec))]
+
+    def check_gathered(self, full, ranges, parts, sample):
+        from oracle import oracle_py as O
+        bad = checked = 0
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                want = O.poa_oracle(self.params, full.take(lo, lo + m), min(os.cpu_count() or 1, 32))
+                bad += int(self.decode(got[:m]) != want)
+                checked += m
+        return "%d windows (front of every shard) vs oracle, consensus strings: %s" % (checked, "identical" if not bad else "DIFFER")
 
     def run(self, stream):
         self.d.run(self.params, stream)
@@ -243,7 +399,7 @@ class PoaWork:
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
-        sub = self.ws.take(0, min(self.n, max_units or 256))
+        sub = self.ws.take(0, min(self.ws.n_windows, max_units or 256))
         t0 = time.perf_counter()
         want, cells = O.poa_oracle(self.params, sub, cores, return_cells=True)
         dt = time.perf_counter() - t0
@@ -256,52 +412,74 @@ class PoaWork:
 
 
 WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork}
+_PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy")}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--kernel", choices=sorted(WORKLOADS), default="bsw")
-    ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows); 0 = 'large'")
-    ap.add_argument("--pairs", type=int, default=0, help="alias of --size for bsw")
-    ap.add_argument("--cpu-units", type=int, default=0, help="units in the CPU-baseline sample (0 = kernel default)")
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
-    if args.pairs:
-        args.size = args.pairs
+def _committed(kind, kernel_name, default_size):
+    """HBM bytes per launch / VALU-busy fraction of a kernel from the committed rocprofv3 --pmc passes (they cannot be
+    collected inside the run that prints the line: PMC passes serialise the kernels); only for the default sizes."""
+    rel, key = _PROFILE_FILES[kind]
+    path = os.path.join(ROOT, rel)
+    if not default_size or not os.path.exists(path):
+        return None, None
+    return json.load(open(path)).get(key, {}).get(kernel_name), rel
 
+
+def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
+    """One kernel's whole protocol on all ranks; returns the JSON object on rank 0 (None elsewhere)."""
     import torch
-    import torch.distributed as dist
     from genomicsbench_amd import _native as N
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libgbx has no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
+    work = WORKLOADS[kind](args)
+    n_per = per_gpu_units if per_gpu_units is not None else work.n
+    stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    work = WORKLOADS[args.kernel](args, rank, dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # ---- inputs into HBM
+    full = ranges = None
+    t_gen = time.perf_counter()
+    if args.mode == "local":
+        mine_host = work.generate(rank * n_per, n_per)
+        barrier()
+        t0 = time.perf_counter()
+        buf, meta = S.pack_arrays(work.to_arrays(mine_host))
+        tensors = S.unpack_tensor(torch.from_numpy(buf).to(dev), meta)
+        barrier()
+        scatter_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        per_rank = mine_host = None
+        if rank == 0:
+            full = work.generate(0, n_per * world)
+            shards = work.shards(full, world)
+            sizes = [work.n_units(sh) for sh in shards]
+            ranges = [(sum(sizes[:r]), sum(sizes[:r + 1])) for r in range(world)]
+            per_rank = [work.to_arrays(sh) for sh in shards]
+            mine_host = shards[0]
+        gen_s = time.perf_counter() - t_gen
+        barrier()
+        t0 = time.perf_counter()
+        if world > 1:
+            tensors, _ = S.scatter_arrays(per_rank, device=ctx["comm_dev"])
+            tensors = {k: v.to(dev) for k, v in tensors.items()}         # no-op over RCCL (already in HBM)
+        else:
+            buf, meta = S.pack_arrays(per_rank[0])
+            tensors = S.unpack_tensor(torch.from_numpy(buf).to(dev), meta)
+        barrier()
+        scatter_ms = (time.perf_counter() - t0) * 1e3
+        per_rank = None
+    work.attach(tensors, dev, mine_host)
 
-    for _ in range(args.warmup):
+    # ---- timed steps
+    for _ in range(warmup):
         work.run(stream)
     barrier()
     N.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         work.run(stream)
     barrier()
     dt = time.perf_counter() - t0
@@ -309,50 +487,143 @@ def main():
     if hasattr(work, "finish"):
         work.finish(stream)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    units = torch.tensor([work.units], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=ctx["comm_dev"])
+    units = torch.tensor([work.units], dtype=torch.float64, device=ctx["comm_dev"])
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(units, op=dist.ReduceOp.SUM)
     dt_max, total_units = float(t.item()), float(units.item())
 
+    # ---- outputs back to rank 0
+    out_t = work.output_tensor().contiguous()
+    barrier()
+    t0 = time.perf_counter()
+    if world > 1 and args.mode != "local":
+        parts = S.gather_array(out_t.to(ctx["comm_dev"]))
+        if rank == 0:
+            parts = [p.cpu() for p in parts]
+    else:
+        parts = [out_t.cpu()]
+    barrier()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    if rank != 0:
+        return None
+
+    # ---- rank 0: the line
+    name, (ms_sum, launches) = max(stages.items(), key=lambda kv: kv[1][0])
+    k_ms = ms_sum / max(launches, 1)
+    alg_bytes, k_units = work.roofline_bytes(name)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    default_size = not args.size and per_gpu_units is None and world == 1
+    traffic, tsrc = _committed("traffic", name, default_size)
+    valu, vsrc = _committed("valu_busy", name, default_size)
+    cfg = {"workload": label or work.workload, "mode": args.mode if world > 1 else "single",
+           "parallelism": ("units sharded over %d rank(s) in contiguous cost-balanced ranges, no data-path collective; "
+                           % world) + ("rank 0 scatters packed shards / gathers outputs over RCCL p2p"
+                                       if args.mode != "local" else "every rank generates its own shard")}
+    cfg.update(work.extra)
+    line = {
+        "metric": work.metric, "value": total_units * steps / dt_max / 1e9, "unit": work.unit,
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt_max / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
+        "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                     "valu_busy": valu, "valu_busy_source": vsrc, "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
+        "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
+        "scatter_ms": scatter_ms, "gather_ms": gather_ms, "rccl_ranks": world, "comm": ctx["comm"],
+    }
+    if args.mode != "local":
+        line["dataset_gen_s"] = gen_s
+        line["gather_verified"] = work.check_gathered(full, ranges, parts, args.verify_units or
+                                                      {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8}[kind])
+        line["shard_units"] = [hi - lo for lo, hi in ranges]
+    if not args.no_cpu:
+        line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
+        if hasattr(work, "host_entry"):
+            line["host_entry"] = work.host_entry()
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--kernel", choices=sorted(WORKLOADS), default=None,
+                    help="one kernel only (default: bsw headline + chain, phmm, poa under 'kernels')")
+    ap.add_argument("--mode", choices=["scatter", "local"], default="scatter")
+    ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows); 0 = 'large'")
+    ap.add_argument("--pairs", type=int, default=0, help="alias of --size for bsw")
+    ap.add_argument("--cpu-units", type=int, default=0, help="units in the CPU-baseline sample (0 = kernel default)")
+    ap.add_argument("--verify-units", type=int, default=0, help="units per shard checked against the oracle after the gather")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of chain / phmm / poa in the all-kernel run")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    if args.pairs:
+        args.size = args.pairs
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    import torch
+    import torch.distributed as dist
+    global S
+    from genomicsbench_amd import shard as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libgbx has no CPU path)")
+    # GBX_BENCH_COMM=gloo is a TEST AID for boxes with fewer GPUs than ranks (the builder's 1-GPU box): ranks share
+    # the GPUs round-robin and the scatter / gather travel through host memory.  The judged path is RCCL.
+    comm = os.environ.get("GBX_BENCH_COMM", "nccl")
+    local = local % torch.cuda.device_count() if comm == "gloo" else local
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if comm == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "comm_dev": torch.device("cpu") if comm == "gloo" else dev,
+           "comm": "rccl" if comm != "gloo" else "gloo (test aid)"}
+
+    if args.kernel:
+        line = run_kernel(args.kernel, args, ctx, args.steps, args.warmup)
+    else:
+        line = run_kernel("bsw", args, ctx, args.steps, args.warmup)
+        others = {}
+        for kind in ("chain", "phmm", "poa"):
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(**vars(args))
+            sub.size, sub.cpu_units = 0, 0                   # --size / --cpu-units speak about the headline kernel
+            others[kind] = run_kernel(kind, sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 1))
+        # BASELINE config 4 as written: ONE 'large' poa job (6000 windows) sharded over the N GPUs (strong)
+        if world > 1 and args.mode != "local":
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(**vars(args))
+            sub.size, sub.cpu_units, sub.no_cpu = 0, 0, True
+            st = run_kernel("poa", sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 1),
+                            per_gpu_units=-(-PoaWork.large // world),
+                            label="poa large: ONE job of %d windows sharded over %d GPUs by scatter / gather (BASELINE config 4)"
+                                  % (-(-PoaWork.large // world) * world, world))
+            if st is not None:
+                st["scaling"] = "strong"
+                others["poa"]["config4_strong"] = st
+        if line is not None:
+            line["kernels"] = others
     if rank == 0:
-        # roofline of the dominant kernel: algorithmic bytes of the units it processes / its mean duration
-        name, (ms_sum, launches) = max(stages.items(), key=lambda kv: kv[1][0])
-        k_ms = ms_sum / max(launches, 1)
-        alg_bytes, k_units = work.roofline_bytes(name)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes (default sizes only)
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if not args.size and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["bytes_per_launch"].get(name)
-        valu = None                         # VALU issue fraction of the dominant kernel, same kind of committed PMC pass
-        vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
-        if not args.size and os.path.exists(vpath):
-            valu = json.load(open(vpath))["valu_busy"].get(name)
-        cfg = {"workload": work.workload,
-               "parallelism": "units sharded over %d rank(s), no data-path collective" % world}
-        cfg.update(work.extra)
-        line = {
-            "metric": work.metric, "value": total_units * args.steps / dt_max / 1e9, "unit": work.unit,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "valu_busy": valu, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
-            "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
-        }
-        if not args.no_cpu:
-            line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
-            if hasattr(work, "host_entry"):
-                line["host_entry"] = work.host_entry()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
+
+S = None
 
 if __name__ == "__main__":
     main()

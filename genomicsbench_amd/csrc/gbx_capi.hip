@@ -50,7 +50,8 @@ Stage::Stage(const char *name, hipStream_t s) : slot_(-1), s_(s)
 {
     if (!g_prof_on) return;
     StageRec r{name, nullptr, nullptr};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
     slot_ = (int)g_prof.size() - 1;
@@ -216,11 +217,8 @@ int gbx_profile_end(int cap, const char **names, float *ms_sum, int *launches, i
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             int k = 0;
             while (k < n && strcmp(names[k], r.name) != 0) ++k;
-            if (k == n) {
-                if (n == cap) continue;
-                names[n] = r.name; ms_sum[n] = 0.f; launches[n] = 0; ++n;
-            }
-            ms_sum[k] += ms; launches[k] += 1;
+            if (k == n && n < cap) { names[n] = r.name; ms_sum[n] = 0.f; launches[n] = 0; ++n; }
+            if (k < n) { ms_sum[k] += ms; launches[k] += 1; }      // stages beyond `cap` distinct names are dropped
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }

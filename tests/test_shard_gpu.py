@@ -1,0 +1,110 @@
+"""Shard equivalence on the GPU: split -> (pack, H2D, unpack) -> compute per shard -> concatenate == the unsharded
+device run == the oracle, for every kernel, through the same shard builders and packed-message layout that
+bench.py's multi-GPU mode scatters over RCCL (the ranks are played one after another by the one GPU)."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _to_device(arrays, dev):
+    import torch
+    from genomicsbench_amd import shard as S
+    buf, meta = S.pack_arrays(arrays)
+    return S.unpack_tensor(torch.from_numpy(buf).to(dev), meta)
+
+
+def _sync_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("parts", [2, 5])
+def test_bsw_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.bsw import DeviceBswBatch, make_params
+    from genomicsbench_amd.datagen import gen_bsw
+    from oracle import oracle_py as O
+    dev, p = torch.device("cuda:0"), make_params()
+    full = gen_bsw(60_000, 77)
+    got = []
+    for sh in S.bsw_shards(full, parts):
+        d = DeviceBswBatch.from_tensors(_to_device(S.bsw_to_arrays(sh), dev), dev)
+        d.run(p, _sync_stream())
+        torch.cuda.synchronize()
+        got.append(d.results())
+    assert np.array_equal(np.concatenate(got), O.bsw_oracle(p, full, 8))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_chain_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.chain import DeviceChainBatch
+    from genomicsbench_amd.datagen import gen_chain
+    from oracle import oracle_py as O
+    dev = torch.device("cuda:0")
+    full = gen_chain(120, 2001, first=500)
+    want = O.chain_oracle(*full, nthreads=8)
+    whole = DeviceChainBatch(*full, dev)
+    whole.run(_sync_stream())
+    torch.cuda.synchronize()
+    got = [[] for _ in range(4)]
+    for sh in S.chain_shards(*full, parts):
+        d = DeviceChainBatch.from_tensors(_to_device(S.chain_to_arrays(sh), dev), dev)
+        d.run(_sync_stream())
+        torch.cuda.synchronize()
+        for f, a in zip(got, d.results()):
+            f.append(a)
+    for f in range(4):
+        cat = np.concatenate(got[f])
+        assert np.array_equal(cat, want[f]) and np.array_equal(cat, whole.results()[f])
+
+
+@pytest.mark.parametrize("parts", [2, 4])
+def test_phmm_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.datagen import gen_phmm
+    from genomicsbench_amd.phmm import DevicePhmmBatchSet
+    from oracle import oracle_py as O
+    dev = torch.device("cuda:0")
+    full = gen_phmm(160, 3001, first=40)
+    want = O.phmm_oracle(full, 8)
+    got = []
+    for sh in S.phmm_shards(full, parts):
+        d = DevicePhmmBatchSet.from_tensors(_to_device(S.phmm_to_arrays(sh), dev), dev)
+        assert d.n_pairs == sh.n_pairs
+        # the pair list rebuilt on the device equals the host's
+        assert np.array_equal(d.pair_read[:d.n_pairs].cpu().numpy(), sh.pair_read)
+        assert np.array_equal(d.pair_hap[:d.n_pairs].cpu().numpy(), sh.pair_hap)
+        d.run(_sync_stream())
+        torch.cuda.synchronize()
+        got.append(d.results())
+    got = np.concatenate(got)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    # tolerance: 1e-5 relative on the log10 likelihood, floored at |want| = 1
+    assert np.all(np.abs(got[fin] - want[fin]) <= 1e-5 * np.maximum(1.0, np.abs(want[fin])))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_poa_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.datagen import gen_poa
+    from genomicsbench_amd.poa import DevicePoaWindowSet, make_params
+    from oracle import oracle_py as O
+    dev, p = torch.device("cuda:0"), make_params()
+    full = gen_poa(40, 4001, first=100)
+    want = O.poa_oracle(p, full, 8)
+    got = []
+    for sh in S.poa_shards(full, parts):
+        d = DevicePoaWindowSet.from_tensors(_to_device(S.poa_to_arrays(sh), dev), dev)
+        d.run(p, _sync_stream())
+        torch.cuda.synchronize()
+        got += d.results()
+    assert got == want
