@@ -22,6 +22,7 @@
 // tests): cells right of the live window are either never written (first-row
 // initial values, E=0) or hold zeros; cells left of it are never read again.
 #include "gbx_internal.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace gbx {
@@ -542,7 +543,7 @@ __global__ void __launch_bounds__(64) bsw_lds_kernel(BswDev prm, BswPairs P, Bsw
 // wavefront amortise it 4x better than 4 pairs; the width is bounded by the registers CPL columns need.
 struct RowShape { int lpp, cpl; };
 typedef void (*RowsFn)(BswDev, BswPairs, BswWork, int);
-struct RowKernel { int lpp, cpl; RowsFn fn[2]; int bpc[2]; const char *name; };
+struct RowKernel { int lpp, cpl; RowsFn fn[2]; std::atomic<int> bpc[2]; const char *name; };   // bpc: resident blocks per CU, cached (same on every MI355X of a node)
 #define GBX_ROW_KERNEL(L, C) { L, C, { bsw_rows_kernel<L, C, false>, bsw_rows_kernel<L, C, true> }, { 0, 0 }, "bsw_rows_" #L "x" #C }
 RowKernel row_kernels[] = {
     // the default table (class_shapes) ...
@@ -725,16 +726,18 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         hipStream_t sc = serial || lane_k == 0 ? s : ss->side[lane_k - 1];
         RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
         if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
-        if (!k->bpc[sym]) {
+        int bpc = k->bpc[sym].load(std::memory_order_relaxed);
+        if (!bpc) {
             int q = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k->fn[sym], 256, 0) != hipSuccess || q < 1) {
                 (void)hipGetLastError();
                 q = 2;
             }
-            k->bpc[sym] = q > 8 ? 8 : q;
+            bpc = q > 8 ? 8 : q;
+            k->bpc[sym].store(bpc, std::memory_order_relaxed);
         }
         Stage st(k->name, sc);
-        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, k->bpc[sym])), dim3(256), 0, sc, dev, P, W, c);
+        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
     }
     // join_events == nullptr: the caller's stream waits for the side streams (everything of this call is then
     // ordered on `s`).  Otherwise nothing waits: one event per stream is recorded (join_events[0] on `s`,
@@ -744,10 +747,14 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     if (!serial && !join_events && (rc = ss->join(s))) return rc;
     {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) {
+        // per device (a process may drive several GPUs through gbx_set_device), set at most once each
+        static std::atomic<uint64_t> attr_set[2];
+        int cur = 0;
+        GBX_HIP(hipGetDevice(&cur));
+        const uint64_t bit = (uint64_t)1 << (cur & 63);
+        if (cur >= 128 || !(attr_set[cur >> 6].load(std::memory_order_acquire) & bit)) {
             GBX_HIP(hipFuncSetAttribute((const void *)bsw_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set = true;
+            if (cur < 128) attr_set[cur >> 6].fetch_or(bit, std::memory_order_release);
         }
         int blocks = (int)(n < (int64_t)cus * 2 ? n : (int64_t)cus * 2);
         Stage st("bsw_lds", s);

@@ -612,6 +612,9 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         return GBX_ERR_ARG;
     }
     int max_h = 1;
+    // exact size of the haplotype streams (sum over the pairs of haplen+1): one long haplotype must not size the
+    // workspace of every pair
+    int64_t stream_syms = 0;
     for (int64_t k = 0; k < n_reads; ++k)
         if (read_len[k] < 0 || read_off[k] < 0 || read_off[k] + read_len[k] > read_bytes) {
             set_error("gbx_phmm_forward_host: read %lld lies outside the arena", (long long)k);
@@ -631,11 +634,16 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     {
         // the pair list is the long one (10.9 M entries in the 'large' job): a few threads, lowest bad index reported
         const int T = host_workers();
-        std::vector<int64_t> bad((size_t)T, -1);
+        std::vector<int64_t> bad((size_t)T, -1), syms((size_t)T, 0);
         parallel_ranges(n_pairs, T, [&](int t, int64_t lo, int64_t hi) {
-            for (int64_t k = lo; k < hi; ++k)
+            int64_t sum = 0;
+            for (int64_t k = lo; k < hi; ++k) {
                 if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) { bad[(size_t)t] = k; return; }
+                sum += (int64_t)hap_len[pair_hap[k]] + 1;
+            }
+            syms[(size_t)t] = sum;
         });
+        for (int t = 0; t < T; ++t) stream_syms += syms[(size_t)t];
         for (int t = 0; t < T; ++t)
             if (bad[(size_t)t] >= 0) {
                 set_error("gbx_phmm_forward_host: pair %lld names a read/haplotype out of range", (long long)bad[(size_t)t]);
@@ -648,7 +656,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     if ((rc = lane.acquire())) return rc;
     Lane *L = lane.l;
     DevBuf dpr(L), dph(L), dro(L), drl(L), drs(L), dq(L), di(L), dd(L), dc(L), dho(L), dhl(L), dh(L), dout(L), dw(L);
-    const size_t wb = phmm_workspace_bytes(n_pairs, n_reads, max_h);
+    const size_t wb = phmm_workspace_bytes(n_pairs, n_reads, max_h, stream_syms);
     if ((rc = dpr.alloc(n_pairs * 4)) || (rc = dph.alloc(n_pairs * 4)) || (rc = dro.alloc(n_reads * 8)) ||
         (rc = drl.alloc(n_reads * 4)) || (rc = drs.alloc(read_bytes)) || (rc = dq.alloc(read_bytes)) ||
         (rc = di.alloc(read_bytes)) || (rc = dd.alloc(read_bytes)) || (rc = dc.alloc(read_bytes)) ||
@@ -668,7 +676,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), n_reads, dro.as<int64_t>(), drl.as<int32_t>(),
                      drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
                      dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb,
-                     lane.l->compute);
+                     lane.l->compute, stream_syms);
     if (rc) return pipe.finish(rc);
     pipe.fetch(0, out, dout.p, n_pairs * 8);
     if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
@@ -818,12 +826,81 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         if ((rc = pipe.finish())) return rc;
         mark("results fetched");
     }
+    // Windows whose graph outgrew the first pass's node capacity (deep or noisy windows; the plan sizes it for the
+    // typical case so that the 'large' job's slots stay small) run again with room for the worst case of exactly
+    // those windows: every base its own node, bounded by what int16 scores admit.  spoa has no such limit
+    // (msa_spoa_omp.cpp:237-252), so only a window that cannot be represented at all fails the call.
+    std::vector<int64_t> redo;
     for (int64_t w = 0; w < n_windows; ++w)
-        if (status[w]) {
-            set_error("gbx_poa_consensus_host: window %lld exceeded a device capacity (status bits 0x%x, see GBX_POA_ST_*)",
-                      (long long)w, status[w]);
-            return GBX_ERR_UNSUPPORTED;
+        if (status[w] == GBX_POA_ST_NODES) redo.push_back(w);
+    if (!redo.empty()) {
+        std::vector<int64_t> wf(redo.size() + 1, 0), off;
+        std::vector<int32_t> len;
+        int64_t bmax = 1;
+        int lmax = 1, smax = 1;
+        for (size_t k = 0; k < redo.size(); ++k) {
+            const int64_t a = win_first_seq[redo[k]], b = win_first_seq[redo[k] + 1];
+            int64_t bases = 0;
+            for (int64_t sidx = a; sidx < b; ++sidx) {
+                off.push_back(seq_off[sidx]); len.push_back(seq_len[sidx]);
+                bases += seq_len[sidx];
+                if (seq_len[sidx] > lmax) lmax = seq_len[sidx];
+            }
+            if (b - a > smax) smax = (int)(b - a);
+            if (bases > bmax) bmax = bases;
+            wf[k + 1] = (int64_t)off.size();
         }
+        int64_t cap = bmax + 8;
+        while (cap > plan.node_cap && !poa_scores_fit_int16(p, cap, lmax)) cap -= (cap - plan.node_cap + 1) / 2;
+        if (cap > plan.node_cap) {
+            gbx_poa_plan big = plan;
+            big.max_seq_len = lmax;
+            big.max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);
+            big.node_cap = (int32_t)cap;
+            const size_t slot = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len);
+            int64_t slots = (int64_t)(((size_t)16 << 30) / (slot ? slot : 1));
+            if (slots < 1) slots = 1;
+            if (slots > (int64_t)redo.size()) slots = (int64_t)redo.size();
+            if (slots > plan.n_slots && plan.n_slots > 0) slots = plan.n_slots;
+            big.n_slots = (int32_t)slots;
+            const size_t wb2 = gbx_poa_workspace_bytes(&big);
+            const int64_t nr = (int64_t)redo.size(), ns = (int64_t)off.size();
+            DevBuf dwf2(L), doff2(L), dlen2(L), dcons2(L), dcl2(L), dst2(L), dw2(L);
+            if ((rc = dwf2.alloc((nr + 1) * 8)) || (rc = doff2.alloc(ns * 8)) || (rc = dlen2.alloc(ns * 4)) ||
+                (rc = dcons2.alloc(nr * cons_stride)) || (rc = dcl2.alloc(nr * 4)) || (rc = dst2.alloc(nr * 4)) ||
+                (rc = dw2.alloc(wb2)))
+                return rc;
+            hipStream_t st = lane.l->compute;
+            GBX_HIP(hipMemcpyAsync(dwf2.p, wf.data(), (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, st));
+            GBX_HIP(hipMemcpyAsync(doff2.p, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st));
+            GBX_HIP(hipMemcpyAsync(dlen2.p, len.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+            if ((rc = poa_launch(p, nr, dwf2.as<int64_t>(), doff2.as<int64_t>(), dlen2.as<int32_t>(), dar.as<uint8_t>(),
+                                 big.max_seq_len, big.max_seqs_per_window, big.node_cap, big.n_slots, dcons2.as<uint8_t>(),
+                                 dcl2.as<int32_t>(), dst2.as<int32_t>(), cons_stride, dw2.p, wb2, st)))
+                return rc;
+            std::vector<char> c2((size_t)nr * (size_t)cons_stride);
+            std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);
+            GBX_HIP(hipMemcpyAsync(c2.data(), dcons2.p, c2.size(), hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipMemcpyAsync(l2.data(), dcl2.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipMemcpyAsync(s2.data(), dst2.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipStreamSynchronize(st));
+            for (int64_t k = 0; k < nr; ++k) {
+                status[(size_t)redo[(size_t)k]] = s2[(size_t)k];
+                if (s2[(size_t)k]) continue;
+                cons_len[redo[(size_t)k]] = l2[(size_t)k];
+                memcpy(cons + redo[(size_t)k] * cons_stride, c2.data() + (size_t)k * (size_t)cons_stride, (size_t)cons_stride);
+            }
+            mark("oversized windows redone");
+        }
+    }
+    int64_t n_bad = 0, first_bad = -1;
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (status[w]) { if (first_bad < 0) first_bad = w; ++n_bad; }
+    if (n_bad) {
+        set_error("gbx_poa_consensus_host: %lld window(s) exceeded a device capacity, first is window %lld (status bits 0x%x, "
+                  "see GBX_POA_ST_*); the others' results are valid", (long long)n_bad, (long long)first_bad, status[(size_t)first_bad]);
+        return GBX_ERR_UNSUPPORTED;
+    }
     return GBX_OK;
 }
 

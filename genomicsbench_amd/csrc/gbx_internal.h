@@ -67,18 +67,19 @@ int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s);
 int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s);
 
 // ---- phmm (phmm_kernels.hip)
-size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len);
+size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len, int64_t stream_syms = -1);
 int phmm_init_tables();
 const float *phmm_host_mm_table_f(int *n);
 int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
                 int64_t n_reads, const int64_t *read_off, const int32_t *read_len,
                 const uint8_t *rs, const uint8_t *q, const uint8_t *qi, const uint8_t *qd, const uint8_t *qc,
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
-                double *out, void *d_work, size_t work_bytes, hipStream_t s);
+                double *out, void *d_work, size_t work_bytes, hipStream_t s, int64_t stream_syms = -1);
 
 // ---- poa (poa_kernels.hip)
 size_t poa_slot_bytes(int ncap, int deg, int lmax);
 int poa_waves_per_cu(int ncap);
+bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax);
 int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,

@@ -728,7 +728,10 @@ namespace {
 struct WorkLayout {
     size_t order, dlist, scratch, rcount, rslen, rcur, ucount, rfirst, rsbase, porder, soff, yin, tmp, part, ubase, ulist, stream, total;
 };
-WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len)
+// stream_syms: sum over the pairs of haplen+1 when the caller knows it (the host entry counts it while it validates
+// the pair list), < 0 for the bound n_pairs*(max_hap_len+1) that needs no pass over the pairs.  The stream is the last
+// piece of the layout, so every other offset is the same for both.
+WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len, int64_t stream_syms = -1)
 {
     if (n_pairs < 0) n_pairs = 0;
     if (n_reads < 0) n_reads = 0;
@@ -753,15 +756,16 @@ WorkLayout work_layout(int64_t n_pairs, int64_t n_reads, int max_hap_len)
     L.ubase = take((size_t)(UBINS + 1) * 4);
     L.ulist = take((size_t)n_pairs * 4);
     // every pair contributes haplen+1 symbols, every read with pairs < 48 bytes of closing boundary + padding
-    L.stream = take((size_t)n_pairs * ((size_t)max_hap_len + 1) + (size_t)(n_pairs < n_reads ? n_pairs : n_reads) * 48 + 64);
+    if (stream_syms < 0) stream_syms = n_pairs * ((int64_t)max_hap_len + 1);
+    L.stream = take((size_t)stream_syms + (size_t)(n_pairs < n_reads ? n_pairs : n_reads) * 48 + 64);
     L.total = off;
     return L;
 }
 }  // namespace
 
-size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len)
+size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len, int64_t stream_syms)
 {
-    return work_layout(n_pairs, n_reads, max_hap_len).total;
+    return work_layout(n_pairs, n_reads, max_hap_len, stream_syms).total;
 }
 
 int phmm_init_tables() { DevTables t; return upload_tables(&t); }
@@ -772,14 +776,14 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
                 int64_t n_reads, const int64_t *read_off, const int32_t *read_len,
                 const uint8_t *rs, const uint8_t *q, const uint8_t *qi, const uint8_t *qd, const uint8_t *qc,
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
-                double *out, void *d_work, size_t work_bytes, hipStream_t s)
+                double *out, void *d_work, size_t work_bytes, hipStream_t s, int64_t stream_syms)
 {
     if (n_pairs == 0) return GBX_OK;
     if (n_pairs > 0x7fffffffLL - 1024 || n_reads > 0x7fffffffLL - 1024) {
         set_error("phmm: more than 2^31 pairs or reads in one call");
         return GBX_ERR_UNSUPPORTED;
     }
-    const WorkLayout L = work_layout(n_pairs, n_reads, max_hap_len);
+    const WorkLayout L = work_layout(n_pairs, n_reads, max_hap_len, stream_syms);
     if (work_bytes < L.total) { set_error("phmm: workspace too small"); return GBX_ERR_ARG; }
     DevTables tabs;
     int rc = upload_tables(&tabs);

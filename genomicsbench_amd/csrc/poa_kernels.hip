@@ -1237,6 +1237,15 @@ int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipSt
     return GBX_OK;
 }
 
+bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax)
+{
+    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c};
+    if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
+    const int64_t worst = -(int64_t)(S.q < S.g ? -S.q : -S.g) * 2 - (int64_t)(S.c > S.e ? -S.c : -S.e) * (ncap + lmax);
+    const int64_t worst_mis = (int64_t)S.n * lmax, hi = (int64_t)S.m * lmax;
+    return !(worst < -30000 || worst_mis < -30000 || hi > 30000);
+}
+
 int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
@@ -1261,14 +1270,9 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         for (int k = 1; k < 4; ++k) A.Tc[v][k] = mp_mul(A.Tc[v][k - 1], A.Tc[v][k - 1]);
     }
     // int16 cells: every real score must stay above -30000 (poa_graph.h); worst case = one long gap
-    {
-        const int worst = -(S.q < S.g ? -S.q : -S.g) * 2 - (S.c > S.e ? -S.c : -S.e) * (ncap + lmax) - (-S.n) * 0;
-        const int worst_mis = S.n * lmax;
-        const int hi = S.m * lmax;
-        if (worst < -30000 || worst_mis < -30000 || hi > 30000) {
-            set_error("poa: scores may leave the int16 range for these capacities (nodes %d, length %d)", ncap, lmax);
-            return GBX_ERR_UNSUPPORTED;
-        }
+    if (!poa_scores_fit_int16(p, ncap, lmax)) {
+        set_error("poa: scores may leave the int16 range for these capacities (nodes %d, length %d)", ncap, lmax);
+        return GBX_ERR_UNSUPPORTED;
     }
     const int grid = (int)std::min<int64_t>(n_windows, n_slots);
     int lds_stack = 0;

@@ -13,11 +13,15 @@
 // The driver calls computelikelihoodsboth once per batch from many OpenMP threads; calls are independent
 // and each one is a complete gbx_phmm_forward_host call (upload, kernels, download) — correct, but a
 // driver that wants throughput hands all batches over at once.  Reads and haplotypes are
-// recognised by pointer, so every distinct sequence of a batch is uploaded once.
+// recognised by every field the testcase record gives them (a read: its bases, its four quality tracks and its
+// length; a haplotype: bases and length), so every distinct sequence of a batch is uploaded once and a caller
+// that reuses a bases pointer with other qualities or another length gets two distinct entries.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
-#include <unordered_map>
+#include <map>
+#include <tuple>
+#include <utility>
 #include <vector>
 #include "../../../include/gbx.h"
 
@@ -43,13 +47,14 @@ void initPairHMM()
 void computelikelihoodsboth(testcase *tc, double *out, int n)
 {
     if (n <= 0) return;
-    std::unordered_map<const char *, int> rid, hid;
+    std::map<std::tuple<const char *, const char *, const char *, const char *, const char *, int>, int> rid;
+    std::map<std::pair<const char *, int>, int> hid;
     std::vector<int64_t> roff, hoff;
     std::vector<int32_t> rlen, hlen, pr((size_t)n), ph((size_t)n);
     std::vector<uint8_t> rs, q, qi, qd, qc, hap;
     for (int k = 0; k < n; ++k) {
         const testcase &t = tc[k];
-        auto r = rid.emplace(t.rs, (int)rlen.size());
+        auto r = rid.emplace(std::make_tuple(t.rs, t.q, t.i, t.d, t.c, t.rslen), (int)rlen.size());
         if (r.second) {
             roff.push_back((int64_t)rs.size());
             rlen.push_back(t.rslen);
@@ -59,7 +64,7 @@ void computelikelihoodsboth(testcase *tc, double *out, int n)
             qd.insert(qd.end(), t.d, t.d + t.rslen);
             qc.insert(qc.end(), t.c, t.c + t.rslen);
         }
-        auto h = hid.emplace(t.hap, (int)hlen.size());
+        auto h = hid.emplace(std::make_pair(t.hap, t.haplen), (int)hlen.size());
         if (h.second) {
             hoff.push_back((int64_t)hap.size());
             hlen.push_back(t.haplen);

@@ -138,3 +138,17 @@ def test_host_entry_staged_transfers(monkeypatch):
     assert_close(forward_host(bs), want)
     monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
     assert_close(forward_host(bs), want)
+
+
+def test_one_long_haplotype_does_not_size_every_pair():
+    """A 30 000-base haplotype among ordinary ones: the host entry sizes the haplotype streams by the exact sum over
+    the pairs of haplen+1 (here ~50 MB) instead of n_pairs x (longest+1) (~3.5 GB); results as the oracle's."""
+    rng = np.random.default_rng(17)
+    haps = [rand_seq(rng, int(rng.integers(150, 320))) for _ in range(7)] + [rand_seq(rng, 30000)]
+    reads = [haps[int(rng.integers(0, 7))][:int(rng.integers(40, 140))] for _ in range(900)]
+    reads.append(haps[7][1000:1151])
+    bs = make_set(reads, haps, seed=3)
+    from genomicsbench_amd import _native as N
+    exact = int((bs.hap_len[bs.pair_hap].astype(np.int64) + 1).sum())
+    assert exact < bs.n_pairs * 30001 // 20
+    assert_close(forward_host(bs), O.phmm_oracle(bs, 8))

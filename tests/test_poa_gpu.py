@@ -94,3 +94,18 @@ def test_long_insertion_chain_deeper_than_the_lds_stack():
                                   [long_read, base, base]])
     p = make_params()
     diff(consensus_host(p, ws), O.poa_oracle(p, ws))
+
+
+def test_deep_unrelated_window_is_redone_with_a_larger_graph():
+    """The plan's node capacity is 6 x the longest read + 256 (typical windows need about 3x).  A window of 120
+    unrelated 200-base reads grows far past it; the host entry re-runs exactly the overflowing windows with room
+    for their worst case (spoa itself has no limit, msa_spoa_omp.cpp:237-252) and the other windows keep their
+    first-pass results."""
+    rng = np.random.default_rng(5)
+    deep = ["".join(rng.choice(list("ACGT"), 200)) for _ in range(120)]
+    base = "".join(rng.choice(list("ACGT"), 180))
+    ws = PoaWindowSet.from_lists([[base] * 4, deep, [base[:170], base, base[5:]]])
+    p = make_params()
+    want = O.poa_oracle(p, ws, 4)
+    assert len(want[1]) > 0
+    diff(consensus_host(p, ws), want)
