@@ -15,6 +15,7 @@
 #   oracle/_ref/bsw_refdriver_gbx    main_banded.cpp + csrc/shims/bsw_class_shim.cpp        (no bandedSWA.cpp)
 #   oracle/_ref/chain_refdriver_gbx  main.cpp host_data_io.cpp common.cpp + chain_hostkernel_shim.cpp (no host_kernel.cpp)
 #   oracle/_ref/phmm_refdriver_gbx   PairHMMUnitTest.cpp + our libgkl_pairhmm_c.so (csrc/shims/gkl_pairhmm_shim.cpp)
+#   oracle/_ref/poa_refdriver_gbx    msa_spoa_omp.cpp + the product's spoa facade include/spoa/*.hpp (our code over the C-ABI)
 # They need genomicsbench_amd/libgbx.so (make -C genomicsbench_amd/csrc first) and a GPU at run time.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -62,5 +63,8 @@ if [ -f "$PKG/libgbx.so" ] && [ -f "$PKG/libgkl_pairhmm_c.so" ]; then
     PH="$REF/benchmarks/phmm"
     $CXX -O2 -std=c++11 -fopenmp -msse4.1 -w -DPRINT_OUTPUT -I"$PH" "$PH/PairHMMUnitTest.cpp" \
         -L"$PKG" -lgkl_pairhmm_c -lgbx "$RP" -o "$OUT/phmm_refdriver_gbx"
+    PO="$REF/benchmarks/poa"
+    $CXX -O2 -std=c++11 -fopenmp -w -DPRINT_OUTPUT -I"$INC" "$PO/msa_spoa_omp.cpp" \
+        -L"$PKG" -lgbx "$RP" -o "$OUT/poa_refdriver_gbx"
 fi
 echo "built: $(ls "$OUT")"

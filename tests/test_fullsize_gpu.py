@@ -1,0 +1,86 @@
+"""Full-size parity: every kernel's BASELINE.json 'large' configuration, the whole job on the device entry, compared
+with the CPU side unit for unit (bsw: oracle, all six fields of all 2 M pairs; chain: the compiled reference's
+chain_dp on all 10 000 calls, oracle if the reference build did not travel; phmm: oracle on the first >= 1 M pairs
+of the 20 000 batches; poa: oracle on all 6 000 windows).  The CPU side runs on the GPU box's host cores (OpenMP):
+about a minute and a half in total there."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+CORES = os.cpu_count() or 1
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_bsw_large_all_fields():
+    import torch
+    from genomicsbench_amd.bsw import DeviceBswBatch, make_params
+    from genomicsbench_amd.datagen import gen_bsw
+    from oracle import oracle_py as O
+    b, p = gen_bsw(2_000_000, 1002), make_params()
+    d = DeviceBswBatch(b, torch.device("cuda:0"))
+    d.run(p, _stream())
+    torch.cuda.synchronize()
+    got, want = d.results(), O.bsw_oracle(p, b, CORES)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert not len(bad), "%d of %d pairs differ, first %d: got %s want %s" % (len(bad), b.n, bad[0], got[bad[0]], want[bad[0]])
+    # a checksum of checksums per field, for the log
+    print("bsw large: field sums", got.astype(np.int64).sum(axis=0).tolist())
+
+
+def test_chain_large_all_calls():
+    import torch
+    from genomicsbench_amd.chain import DeviceChainBatch
+    from genomicsbench_amd.datagen import gen_chain
+    from oracle import oracle_py as O
+    case = gen_chain(10_000, 2001)
+    d = DeviceChainBatch(*case, torch.device("cuda:0"))
+    d.run(_stream())
+    torch.cuda.synchronize()
+    want = O.chain_ref(*case, nthreads=CORES) if O.ref_lib("chain") is not None else O.chain_oracle(*case, nthreads=CORES)
+    for name, g, w in zip(("score", "parent", "target", "peak"), d.results(), want):
+        bad = np.nonzero(g != w)[0]
+        assert not len(bad), "chain %s: %d of %d anchors differ, first at %d" % (name, len(bad), len(w), bad[0])
+
+
+def test_phmm_large_first_million_pairs():
+    import torch
+    from genomicsbench_amd.datagen import gen_phmm
+    from genomicsbench_amd.phmm import DevicePhmmBatchSet
+    from oracle import oracle_py as O
+    bs = gen_phmm(20_000, 3001)
+    d = DevicePhmmBatchSet(bs, torch.device("cuda:0"))
+    d.run(_stream())
+    torch.cuda.synchronize()
+    nb = int(np.searchsorted(bs.batch_pair_off, 1_000_000)) + 1          # whole batches covering >= 1 M pairs
+    sub = bs.take_batches(0, nb)
+    assert sub.n_pairs >= 1_000_000
+    got, want = d.results()[:sub.n_pairs], O.phmm_oracle(sub, CORES)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    err = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)      # 1e-5 relative, |want| floored at 1
+    assert err.max() <= 1e-5, "max rel err %.3g at pair %d" % (err.max(), int(np.argmax(err)))
+    # the rest of the job: finite, negative log-likelihoods everywhere
+    rest = d.results()[sub.n_pairs:]
+    assert np.isfinite(rest).all() and (rest < 0).all()
+
+
+def test_poa_large_all_windows():
+    import torch
+    from genomicsbench_amd.datagen import gen_poa
+    from genomicsbench_amd.poa import DevicePoaWindowSet, make_params
+    from oracle import oracle_py as O
+    ws, p = gen_poa(6_000, 4001), make_params()
+    d = DevicePoaWindowSet(ws, torch.device("cuda:0"))
+    d.run(p, _stream())
+    torch.cuda.synchronize()
+    got, want = d.results(), O.poa_oracle(p, ws, CORES)
+    bad = [w for w in range(ws.n_windows) if got[w] != want[w]]
+    assert not bad, "%d of %d windows differ, first %d" % (len(bad), ws.n_windows, bad[0])

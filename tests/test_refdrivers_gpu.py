@@ -1,8 +1,8 @@
 """Drop-in boundary, end to end: the reference's own, UNMODIFIED drivers (bsw main_banded.cpp, chain main.cpp,
-phmm PairHMMUnitTest.cpp), compiled from /root/reference by oracle/build_ref.sh against our libraries instead
-of the reference kernels (csrc/shims/*.cpp are the bindings), run on the GPU and must reproduce the oracle.
-The binaries live in oracle/_ref (built where the reference exists, shipped to the GPU box); the poa driver
-cannot be built (it includes spoa's headers, an empty submodule)."""
+phmm PairHMMUnitTest.cpp, poa msa_spoa_omp.cpp), compiled from /root/reference by oracle/build_ref.sh against our
+libraries instead of the reference kernels (csrc/shims/*.cpp and the product's include/spoa/*.hpp are the
+bindings), run on the GPU and must reproduce the oracle.  The binaries live in oracle/_ref (built where the
+reference exists, shipped to the GPU box)."""
 import os
 import subprocess
 
@@ -11,7 +11,7 @@ import pytest
 
 from genomicsbench_amd import io as gio
 from genomicsbench_amd.bsw import make_params
-from genomicsbench_amd.datagen import gen_bsw, gen_chain, gen_phmm
+from genomicsbench_amd.datagen import gen_bsw, gen_chain, gen_phmm, gen_poa
 from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
@@ -76,3 +76,27 @@ def test_reference_phmm_driver_on_our_gkl_library(tmp_path):
     want = O.phmm_oracle(bs, 4)
     assert len(got) == bs.n_pairs
     assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want)) + 1e-6)      # printed with 6 decimals
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reference_poa_driver_on_the_spoa_facade(tmp_path, threads):
+    """msa_spoa_omp.cpp (-DPRINT_OUTPUT) over include/spoa/spoa.hpp: createAlignmentEngine / createGraph / align /
+    add_alignment / generate_consensus (:189-190,237-252) bind to gbx_poa_consensus_host, one window per call."""
+    from genomicsbench_amd.poa import make_params
+    ws = gen_poa(10, 24)
+    inp = str(tmp_path / "poa.fa")
+    gio.write_poa_windows(inp, ws)
+    r = run([driver("poa_refdriver_gbx"), "-s", inp, "-t", str(threads)])
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
+    lines = r.stdout.splitlines()
+    got = [lines[k + 1] for k in range(len(lines) - 1) if lines[k] == ">Consensus_sequence"]
+    assert got == O.poa_oracle(make_params(), ws, 4)
+
+
+def test_reference_poa_driver_rejects_positive_gap_penalties(tmp_path):
+    """createAlignmentEngine throws std::invalid_argument, the driver prints it and returns 1 (:191-194)."""
+    ws = gen_poa(1, 24)
+    inp = str(tmp_path / "poa.fa")
+    gio.write_poa_windows(inp, ws)
+    r = run([driver("poa_refdriver_gbx"), "-s", inp, "-o", "-9,24"])         # -o negates: o1 = +9 -> g = o1+e1 > 0
+    assert r.returncode == 1 and "non-positive" in r.stderr
