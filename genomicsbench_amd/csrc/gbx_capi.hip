@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 #include "gbx_internal.h"
+#include <dlfcn.h>
 
 namespace gbx {
 
@@ -46,7 +47,29 @@ struct StageRec { const char *name; hipEvent_t a, b; };
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<StageRec> g_prof;
 
-Stage::Stage(const char *name, hipStream_t s) : slot_(-1), s_(s)
+// ---- roctx ranges (optional, GBX_ROCTX=1) -------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("GBX_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { fprintf(stderr, "[gbx] GBX_ROCTX set but no roctx library could be loaded: %s\n", dlerror()); return; }
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr;
+    }
+};
+const Roctx &roctx() { static Roctx r; return r; }
+}  // namespace
+RoctxRange::RoctxRange(const char *name) : on_(roctx().push != nullptr) { if (on_) (void)roctx().push(name); }
+RoctxRange::~RoctxRange() { if (on_) (void)roctx().pop(); }
+
+Stage::Stage(const char *name, hipStream_t s) : slot_(-1), s_(s), range_(name)
 {
     if (!g_prof_on) return;
     StageRec r{name, nullptr, nullptr};
@@ -294,6 +317,7 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
                         const int32_t *len1, const int32_t *len2,
                         const int32_t *h0, gbx_bsw_result *out)
 {
+    RoctxRange range_("gbx_bsw_extend_host");
     if (!p || n < 0 || ref_bytes < 0 || qer_bytes < 0) { set_error("gbx_bsw_extend_host: bad argument"); return GBX_ERR_ARG; }
     if (n == 0) return GBX_OK;
     if (!ref || !qer || !idr || !idq || !len1 || !len2 || !h0 || !out) {
@@ -434,6 +458,7 @@ int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t
                             const uint8_t *ref, int64_t ref_bytes,
                             const uint8_t *qer, int64_t qer_bytes)
 {
+    RoctxRange range_("gbx_bsw_extend_seqpairs");
     if (!p || n < 0) { set_error("gbx_bsw_extend_seqpairs: bad argument"); return GBX_ERR_ARG; }
     if (n == 0) return GBX_OK;
     if (!pairs) { set_error("gbx_bsw_extend_seqpairs: null pointer"); return GBX_ERR_ARG; }
@@ -516,6 +541,7 @@ int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor
 int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *ax, const uint64_t *ay,
                    const gbx_chain_call *hdr, int32_t *score, int32_t *parent, int32_t *target, int32_t *peak)
 {
+    RoctxRange range_("gbx_chain_host");
     if (n_calls < 0) { set_error("gbx_chain_host: bad argument"); return GBX_ERR_ARG; }
     if (n_calls == 0) return GBX_OK;
     if (!anchor_off || !hdr || !score || !parent) { set_error("gbx_chain_host: null pointer"); return GBX_ERR_ARG; }
@@ -601,6 +627,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
                           int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
                           const uint8_t *hap, double *out)
 {
+    RoctxRange range_("gbx_phmm_forward_host");
     if (n_pairs < 0 || n_reads < 0 || n_haps < 0 || read_bytes < 0 || hap_bytes < 0) {
         set_error("gbx_phmm_forward_host: bad argument");
         return GBX_ERR_ARG;
@@ -769,6 +796,7 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
                            const char *arena, int64_t arena_bytes,
                            char *cons, int32_t *cons_len, int64_t cons_stride)
 {
+    RoctxRange range_("gbx_poa_consensus_host");
     if (!p || n_windows < 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0) {
         set_error("gbx_poa_consensus_host: bad argument");
         return GBX_ERR_ARG;

@@ -21,11 +21,23 @@ int  hip_fail(hipError_t e, const char *what);
 
 // Optional per-kernel timing with HIP events on the launch stream (gbx_profile_*).
 // A Stage brackets one kernel launch; it is a no-op unless profiling is on.
+// roctx ranges (the reference's analogue: ITT pause/resume and task markers around its timed regions,
+// bsw/main_banded.cpp:203-205,274-276,293-295).  GBX_ROCTX=1 loads librocprofiler-sdk-roctx.so (libroctx64.so as
+// a fallback) on first use and brackets host-entry calls, H2D / D2H transfers and kernel launches with
+// roctxRangePush/Pop on the calling thread, so that `rocprofv3 --marker-trace` shows them beside the kernels;
+// unset, the constructor is one predictable branch.
+struct RoctxRange {
+    explicit RoctxRange(const char *name);
+    ~RoctxRange();
+    bool on_;
+};
+
 struct Stage {
     Stage(const char *name, hipStream_t s);
     ~Stage();
     int slot_;
     hipStream_t s_;
+    RoctxRange range_;
 };
 
 // Side streams for independent kernels of one call (the per-class kernels have long single-wave tails that

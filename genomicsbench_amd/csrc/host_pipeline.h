@@ -253,6 +253,7 @@ struct HostPipe {
             hipError_t e = hipSuccess;
             if (busy[slot]) e = hipEventSynchronize(L->wev[w][slot]);
             if (e == hipSuccess) {
+                RoctxRange range_("gbx:h2d piece (stage into pinned slab + DMA)");
                 memcpy(L->wslab[w][slot], p.src, p.len);
                 e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.len, hipMemcpyHostToDevice, xfer);
             }
@@ -268,6 +269,7 @@ struct HostPipe {
     // (the copy of one half to the caller's memory overlaps the DMA into the other)
     hipError_t fetch_chunk(int64_t c)
     {
+        RoctxRange range_("gbx:d2h chunk (wait for the chunk's kernels + DMA + copy out)");
         hipError_t e = hipSuccess;
         for (int k = 0; k < chunk_nev[(size_t)c]; ++k)        // the chunk's kernels are done on every stream they ran on
             if ((e = hipEventSynchronize(L->ev_chunk[(size_t)c * Lane::JOIN_EVENTS + (size_t)k])) != hipSuccess) return e;
@@ -342,6 +344,7 @@ struct HostPipe {
     int wait_stage(int64_t c)
     {
         if (!staged) {
+            RoctxRange range_("gbx:h2d (direct)");
             for (; next < pieces.size() && pieces[next].chunk <= c; ++next) {
                 const Piece &p = pieces[next];
                 const void *src = p.src;

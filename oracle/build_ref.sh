@@ -35,6 +35,11 @@ $CXX -shared -fPIC -O3 -std=c++11 -fopenmp -mavx2 -w \
     -I"$BSW" "$BSW/bandedSWA.cpp" "$HERE/ref_harness/bsw_ref_shim.cpp" \
     -o "$OUT/libbsw_ref.so"
 
+# ---- bsw: the reference's own CPU driver, unmodified (R/benchmarks/bsw/Makefile:59-75 with arch=avx2): BASELINE
+# config 0 runs it with -t 1 -b 512 exactly as R/scripts/run-cpu.sh:61 (scripts/run-cpu-bsw-small.sh)
+$CXX -O3 -std=c++11 -fopenmp -mavx2 -w -DSORT_PAIRS -DENABLE_PREFETCH -DBWA_OTHER_ELE=0 -I"$BSW" \
+    "$BSW/main_banded.cpp" "$BSW/bandedSWA.cpp" -o "$OUT/bsw_refdriver_cpu"
+
 # ---- chain: R/benchmarks/chain/src/host_kernel.cpp names three minimap2
 # headers (minimap.h, mmpriv.h, kalloc.h :8-10) from the un-vendored
 # tools/minimap2 submodule and uses nothing from them.  We do not write

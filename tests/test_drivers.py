@@ -188,3 +188,21 @@ def test_poa_driver_end_to_end(data):
     lines = [ln for ln in r.stdout.split("\n") if ln]
     assert lines[0::2] == [">Consensus_sequence"] * po.n_windows
     assert lines[1::2] == O.poa_oracle(poa_params(), po, 4)
+
+
+def test_config0_reference_cpu_driver_plumbing(tmp_path):
+    """BASELINE config 0: the reference's own bsw driver (unmodified main_banded.cpp + bandedSWA.cpp, built by
+    oracle/build_ref.sh) with -t 1 -b 512 as R/scripts/run-cpu.sh:61 runs it, on a generated input file in the
+    reference's 3-lines-per-pair format.  CPU only.  scripts/run-cpu-bsw-small.sh runs the 100 000-pair set."""
+    import subprocess
+    from genomicsbench_amd import io as gio
+    from genomicsbench_amd.datagen import gen_bsw
+    exe = os.path.join(ROOT, "oracle", "_ref", "bsw_refdriver_cpu")
+    if not os.path.exists(exe):
+        pytest.skip("reference CPU driver not built (no /root/reference at build time)")
+    pairs = str(tmp_path / "pairs.txt")
+    gio.write_bsw_pairs(pairs, gen_bsw(2000, 1001))
+    r = subprocess.run([exe, "-pairs", pairs, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1                                  # by design, main_banded.cpp:352
+    assert "Number of input pairs: 2000" in r.stdout and "Total Pairs processed: 2000" in r.stdout
+    assert "Overall SW cycles" in r.stdout
