@@ -22,12 +22,14 @@ if [ -x "$REFBIN" ]; then
 else
     echo "oracle/_ref/bsw_refdriver_cpu not built (no /root/reference at build time)" >&2
 fi
-gpu_ms=null
+gpu_ms=null; gpu_first_ms=null
 if [ -x "$ROOT/genomicsbench_amd/bin/bsw" ] && python3 -c "import sys; sys.path.insert(0, '$ROOT'); from genomicsbench_amd import _native as N; sys.exit(0 if N.device_count() > 0 else 1)" 2>/dev/null; then
-    "$ROOT/genomicsbench_amd/bin/bsw" -pairs "$F" -t 1 -b 512 > /tmp/gbx-config0-gpu.log 2>&1 || true
+    "$ROOT/genomicsbench_amd/bin/bsw" -pairs "$F" -t 1 -b 512 --repeat 3 > /tmp/gbx-config0-gpu.log 2>&1 || true
     cat /tmp/gbx-config0-gpu.log >&2
     gpu_s=$(sed -n 's/^Overall SW time (H2D + kernels + D2H) = \([0-9.]*\) s/\1/p' /tmp/gbx-config0-gpu.log | head -1)
     [ -n "$gpu_s" ] && gpu_ms=$(python3 -c "print(1e3 * $gpu_s)")
+    first_s=$(sed -n 's/^call 0: \([0-9.]*\) s/\1/p' /tmp/gbx-config0-gpu.log | head -1)
+    [ -n "$first_s" ] && gpu_first_ms=$(python3 -c "print(1e3 * $first_s)")
 fi
 cells=$(python3 - "$F" <<'PY'
 import sys
@@ -42,4 +44,4 @@ with open(sys.argv[1]) as f:
 print(n)
 PY
 )
-echo "{\"config\": \"bsw small, reference CPU driver -t 1 -b 512 (run-cpu.sh:61)\", \"pairs_file\": \"$F\", \"nominal_cells\": $cells, \"reference_cpu_seconds\": ${cpu_s:-null}, \"reference_cpu_threads\": $cpu_cores, \"gpu_driver_h2d_kernels_d2h_ms\": $gpu_ms}"
+echo "{\"config\": \"bsw small, reference CPU driver -t 1 -b 512 (run-cpu.sh:61)\", \"pairs_file\": \"$F\", \"nominal_cells\": $cells, \"reference_cpu_seconds\": ${cpu_s:-null}, \"reference_cpu_threads\": $cpu_cores, \"gpu_driver_h2d_kernels_d2h_ms\": $gpu_ms, \"gpu_driver_first_call_ms\": $gpu_first_ms}"

@@ -142,7 +142,8 @@ def test_host_entry_staged_transfers(monkeypatch):
 
 def test_one_long_haplotype_does_not_size_every_pair():
     """A 30 000-base haplotype among ordinary ones: the host entry sizes the haplotype streams by the exact sum over
-    the pairs of haplen+1 (here ~50 MB) instead of n_pairs x (longest+1) (~3.5 GB); results as the oracle's."""
+    the pairs of haplen+1 (here 28 MB: every read meets the long haplotype once) instead of n_pairs x (longest+1)
+    (216 MB); results as the oracle's."""
     rng = np.random.default_rng(17)
     haps = [rand_seq(rng, int(rng.integers(150, 320))) for _ in range(7)] + [rand_seq(rng, 30000)]
     reads = [haps[int(rng.integers(0, 7))][:int(rng.integers(40, 140))] for _ in range(900)]
@@ -150,5 +151,5 @@ def test_one_long_haplotype_does_not_size_every_pair():
     bs = make_set(reads, haps, seed=3)
     from genomicsbench_amd import _native as N
     exact = int((bs.hap_len[bs.pair_hap].astype(np.int64) + 1).sum())
-    assert exact < bs.n_pairs * 30001 // 20
+    assert exact < bs.n_pairs * 30001 // 5
     assert_close(forward_host(bs), O.phmm_oracle(bs, 8))
