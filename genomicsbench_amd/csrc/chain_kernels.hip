@@ -68,6 +68,9 @@ struct ChainWork {
     int32_t *next;      // work cursor
     int32_t *order;     // [n_calls] calls, longest bucket first
     unsigned long long *evaluated;   // predecessor pairs visited (the benchmark's "cell")
+    int32_t *st;        // [n_anchors] first predecessor of every anchor (chain_st_kernel)
+    int32_t *unsorted;  // [n_calls] bit 0: the call's x are not sorted (the DP kernel walks st itself); bit 1: several
+                        // segment ids or upper x words in the call (the DP kernel's general 64-bit path)
 };
 
 __device__ inline int bucket_of(int64_t n)
@@ -88,12 +91,28 @@ __global__ void __launch_bounds__(256) chain_order_kernel(int64_t n_calls, const
     W.order[base + atomicAdd(&W.cursors[b], 1)] = (int)c;
 }
 
-constexpr int RING = 256;                 // most recent anchors kept in LDS (covers the usual look-back)
+// -DGBX_CHAIN_STAMPS: s_memtime stamps around the parts of an anchor, accumulated by the block that runs the longest
+// call (slot 0) and read back with gbx_debug_chain_stamps (scripts/dbg_chain_stamps.py).  A stamp is read through
+// lgkmcnt, so it also drains the LDS reads issued before it: a part is charged its own LDS latency.
+#ifdef GBX_CHAIN_STAMPS
+__device__ unsigned long long g_chain_stamps[16];
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] += now_ - last_; last_ = now_; } while (0)
+#define STAMP_RESET() do { last_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMP_RESET() do { } while (0)
+#endif
+
+// Ring of the most recent anchors in LDS, five slabs of 64 (anchor a lives in slot a mod 320).  While the block of
+// anchors [ib, ib+64) is being computed, the anchors a >= ib - RING_LIVE are addressed in the ring (four complete
+// blocks + the one being filled); older ones are read from / written to global memory.
+constexpr int RING_LIVE = 256;
+constexpr int RING_PHYS = 320;
 
 // Loaded values that are produced on a rare path and consumed after the paths merge make the compiler put
 // `s_waitcnt vmcnt(0)` at the merge point - which, on the common path, waits for this wavefront's
-// outstanding global *stores* (gfx9 counts them in vmcnt), a microsecond per anchor.  settle() consumes the
-// value inside the rare path, so the wait stays there.
+// outstanding global *stores* (gfx9 counts them in vmcnt).  settle() consumes the value inside the rare path,
+// so the wait stays there.
 __device__ inline int settle(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ inline uint64_t settle(uint64_t v)
 {
@@ -109,17 +128,64 @@ __device__ inline uint64_t readlane64(uint64_t v, int k)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Pre-pass, one thread per anchor, a block per call slice: the first predecessor of every anchor (host_kernel.cpp:56-57)
+//     st(i) = max(first s in [0,i] with x[i] <= x[s] + max_dist_x,  i - max_iter)
+// which is what the reference's running `st` equals at anchor i when the anchors are sorted by x (both terms are
+// non-decreasing in i).  It depends on the anchor words only, so it is computed here at full-chip throughput instead
+// of on the serial path of the call's wavefront (it was a ninth of an anchor's latency there).  A call whose x are
+// not sorted gets its flag set and the DP kernel walks `st` for it as the reference does.
+__global__ void __launch_bounds__(256) chain_st_kernel(int n_calls, const int64_t *__restrict__ off, const uint64_t *__restrict__ ax,
+                                                       const uint64_t *__restrict__ ay,
+                                                       const gbx_chain_call *__restrict__ hdr, int32_t *__restrict__ st_out,
+                                                       int32_t *__restrict__ unsorted)
+{
+    const int call = blockIdx.x;
+    if (call >= n_calls) return;
+    const int64_t o = off[call];
+    const int n = (int)(off[call + 1] - o);
+    const uint64_t *x = ax + o, *y = ay + o;
+    const uint64_t mdx = (uint64_t)(int64_t)hdr[call].max_dist_x;
+    bool bad = false, wide = false;
+    const uint64_t x0 = n ? x[0] : 0, y0 = n ? y[0] : 0;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+        const uint64_t ri = x[i];
+        if (i > 0 && x[i - 1] > ri) bad = true;
+        // the DP kernel's narrow path needs one segment id (y bits 48-55) and one upper x word (strand + reference id,
+        // host_data.h) in the whole call: true of every minimap2 call on one reference sequence
+        if ((ri ^ x0) >> 32 || ((y[i] ^ y0) >> 48 & 0xff)) wide = true;
+        // gallop backwards from i, then bisect: lo = last known far index (or -1), hi = known not-far index
+        int hi = i, lo = -1, step = 32;
+        const int floor_ = i - GBX_CHAIN_MAX_ITER > 0 ? i - GBX_CHAIN_MAX_ITER : 0;
+        while (hi > floor_) {
+            int probe = hi - step;
+            if (probe < floor_) probe = floor_;
+            if (ri > x[probe] + mdx) { lo = probe; break; }
+            hi = probe;
+            step <<= 1;
+        }
+        if (lo < 0) lo = floor_ - 1;                      // everything down to the floor is near
+        while (hi - lo > 1) {
+            const int mid = (hi + lo) >> 1;
+            if (ri > x[mid] + mdx) lo = mid; else hi = mid;
+        }
+        st_out[o + i] = hi;                               // first not-far index >= floor (hi == i when all are far)
+    }
+    const int any_bad = __syncthreads_or(bad), any_wide = __syncthreads_or(wide);
+    const int fl = any_bad ? 3 : (any_wide ? 2 : 0);                                // unsorted calls take the wide path too
+    if (fl && threadIdx.x == 0) atomicOr(&unsorted[call], fl);
+}
+
 __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *__restrict__ off,
                                                    const uint64_t *__restrict__ ax, const uint64_t *__restrict__ ay,
                                                    const gbx_chain_call *__restrict__ hdr,
                                                    int32_t *score, int32_t *parent, int32_t *target, int32_t *peak,
                                                    ChainWork W)
 {
-    // ring of the last RING anchors (slot = index & (RING-1)): anchor words and the DP state of the reference's
-    // scores / parents / targets / peak_scores vectors.  The same values also go to global memory (the outputs),
-    // which serves the rare look-backs deeper than the ring.
-    __shared__ uint64_t rx[RING], ry[RING];
-    __shared__ int rf[RING], rp[RING], rt[RING], rk[RING];
+    // ring entries: the anchor words {x, y} and the DP state {score, parent, target, peak} of the reference's four
+    // vectors, 16 bytes each, so that a look-back chunk is two ds_read_b128 per lane.  Scores / parents / peaks go
+    // to global memory once per block of 64 anchors (coalesced), targets when their block leaves the ring.
+    __shared__ uint4 rxy[RING_PHYS];
+    __shared__ int4 rst[RING_PHYS];
     __shared__ int mark[64];
     const int lane = threadIdx.x;
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
@@ -132,151 +198,255 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         const int n = (int)(off[call + 1] - o);
         const uint64_t *x = ax + o, *y = ay + o;
         int32_t *f = score + o, *p = parent + o, *t = target + o, *pk = peak + o;
-        const gbx_chain_call h = hdr[call];
-        const int max_dist_x = h.max_dist_x, max_dist_y = h.max_dist_y, bw = h.bw, n_segs = h.n_segs;
-        const double avg_qspan = (double)h.avg_qspan;
-        const uint64_t mdx = (uint64_t)(int64_t)max_dist_x;
-
-        for (int i = lane; i < n; i += 64) t[i] = 0;          // vectors are zero-filled, host_kernel.cpp:44-47
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-
-        int st = 0;
-        int sb = 0;                                           // block of 64 x-values cached for the st scan
-        uint64_t xs = n ? x[min(lane, n - 1)] : 0;
+        const int32_t *stp = W.st + o;
+        const int flags = W.unsorted[call];
+        const bool sorted = (flags & 1) == 0;
         unsigned long long visited = 0;
-        for (int ib = 0; ib < n; ib += 64) {
-            // this block's anchors, one per lane
-            const uint64_t xa = settle(x[min(ib + lane, n - 1)]), ya = settle(y[min(ib + lane, n - 1)]);
-            const int kmax = min(64, n - ib);
-            for (int k = 0; k < kmax; ++k) {
-                const int i = ib + k;
-                const uint64_t ri = readlane64(xa, k), yi = readlane64(ya, k);
-                const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
-                const int sidi = (int)(yi >> 48 & 0xff);
-                // advance st (:56): first st with ri <= x[st] + max_dist_x, scanning the cached block
-                for (;;) {
-                    if (st >= i) break;
-                    if (st >= sb + 64 || st < sb) { sb = st; xs = settle(x[min(sb + lane, n - 1)]); }
-                    const int idx = sb + lane;
-                    const bool far = idx >= st && idx < i && ri > xs + mdx;
-                    const bool stop = idx >= st && !far;                  // first lane at/after st that is not far
-                    const unsigned long long m = __ballot(stop);
-                    if (m) { st = sb + __builtin_ctzll(m); break; }
-                    st = sb + 64;                                         // the whole rest of the block is far
-                }
-                if (st > i) st = i;
-                if (i - st > max_iter) st = i - max_iter;                 // :57
+        // NARROW: one segment id and one upper x word in the whole call (and sorted x): `same` is always true and the
+        // reference-position differences fit 32 unsigned bits, which takes a fifth of the instructions out of a chunk
+        auto run_call = [&](auto narrow_tag) {
+            constexpr bool NARROW = decltype(narrow_tag)::value;
+            const gbx_chain_call h = hdr[call];
+            const int max_dist_x = h.max_dist_x, max_dist_y = h.max_dist_y, bw = h.bw, n_segs = h.n_segs;
+            const double avg_qspan = (double)h.avg_qspan;
+            const uint64_t mdx = (uint64_t)(int64_t)max_dist_x;
 
-                int max_f = q_span, max_j = -1, n_skip = 0;
-                // One 64-wide chunk of the look-back, lane 0 = anchor jhi.  Returns true when the max_skip break fired.
-                // The anchor words and DP state of the chunk arrive as arguments, so that the ring path below is
-                // made of LDS reads only: a flat / global load here would have to wait (vmcnt) for the global
-                // stores of the previous anchors, which is most of a chunk's latency.
-                auto chunk = [&](int jhi, bool valid, uint64_t xj, uint64_t yj, int fj, int pj, int tj) -> bool {
-                    // ---- phase 1: candidate score / `continue` mask (:59-80)
-                    const int64_t dr = (int64_t)(ri - xj);
-                    const int dq = qi - (int)yj;
-                    const int sidj = (int)(yj >> 48 & 0xff);
-                    const bool same = sidi == sidj;
-                    bool skip = !valid || (same && dr == 0) || dq <= 0;
-                    skip = skip || (same && dq > max_dist_y) || dq > max_dist_x;
-                    const int dd = (int)(dr > dq ? dr - dq : dq - dr);
-                    skip = skip || (same && dd > bw);
-                    skip = skip || (n_segs > 1 && same && dr > max_dist_y);
-                    const int min_d = dq < dr ? dq : (int)dr;
-                    int sc = min_d > q_span ? q_span : min_d;
-                    const int log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
-                    const int c_lin = (int)((double)dd * .01 * avg_qspan);
-                    int gap_cost = 0;
-                    if (!same) {
-                        if (dr == 0) ++sc;
-                        else gap_cost = c_lin < log_dd ? c_lin : log_dd;
+    #ifdef GBX_CHAIN_STAMPS
+            unsigned long long acc_[12] = {0}, last_ = 0, n_chunks_ = 0;
+    #endif
+            int st = 0;
+            int sb = 0;                                           // unsorted calls: block of 64 x-values cached for the st scan
+            uint64_t xs = n ? x[min(lane, n - 1)] : 0;
+            int sib = 0;                                          // ib mod RING_PHYS (blocks are slab-aligned: 320 = 5 x 64)
+            for (int ib = 0; ib < n; ib += 64, sib = sib + 64 == RING_PHYS ? 0 : sib + 64) {
+                // this block's anchors, one per lane
+                const int ia = min(ib + lane, n - 1);
+                const uint64_t xa = settle(x[ia]), ya = settle(y[ia]);
+                const int stv = settle(stp[ia]);
+                const int kmax = min(64, n - ib);
+                const int live0 = ib - RING_LIVE;                 // anchors >= live0 are addressed in the ring during this block
+                // the slab this block fills holds the anchors [ib-320, ib-256): their targets are final (no anchor of this
+                // or a later block marks them through the ring), so they go to the output now, one coalesced store
+                if (ib >= RING_PHYS) t[ib - RING_PHYS + lane] = rst[sib + lane].z;
+                rxy[sib + lane] = make_uint4((unsigned)xa, (unsigned)(xa >> 32), (unsigned)ya, (unsigned)(ya >> 32));
+                int of_ = 0, op_ = 0, ok_ = 0;                    // outputs of the block's anchors, anchor ib+k in lane k
+                for (int k = 0; k < kmax; ++k) {
+                    const int i = ib + k, si = sib + k;           // si = i mod RING_PHYS
+                    STAMP_RESET();
+                    const uint64_t ri = readlane64(xa, k), yi = readlane64(ya, k);
+                    const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
+                    const int sidi = (int)(yi >> 48 & 0xff);
+                    if (sorted) {
+                        st = __builtin_amdgcn_readlane(stv, k);
                     } else {
-                        gap_cost = c_lin + (log_dd >> 1);
+                        // advance st (:56): first st with ri <= x[st] + max_dist_x, scanning the cached block
+                        for (;;) {
+                            if (st >= i) break;
+                            if (st >= sb + 64 || st < sb) { sb = st; xs = settle(x[min(sb + lane, n - 1)]); }
+                            const int idx = sb + lane;
+                            const bool far = idx >= st && idx < i && ri > xs + mdx;
+                            const bool stop = idx >= st && !far;                  // first lane at/after st that is not far
+                            const unsigned long long m = __ballot(stop);
+                            if (m) { st = sb + __builtin_ctzll(m); break; }
+                            st = sb + 64;                                         // the whole rest of the block is far
+                        }
+                        if (st > i) st = i;
+                        if (i - st > max_iter) st = i - max_iter;                 // :57
                     }
-                    // (int)((double)gap_cost * gap_scale + .499) with gap_scale = 1.0f is gap_cost itself: gap_cost >= 0
-                    // for every lane that is not skipped (dd >= 0), and skipped lanes never use sc
-                    sc -= gap_cost;
-                    sc += fj;
-                    // ---- phase 2: was this j already marked as a parent during this i? (:84)
-                    mark[lane] = 0;
-                    const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
-                    if (!skip && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
-                    const bool hit = (tj == i) || mark[lane] != 0;
-                    // ---- phase 3: ordered max_f / n_skip / break (:81-88)
-                    const unsigned cand = skip ? 0u : (unsigned)sc + UBIAS;      // biased: 0 = "no candidate"
-                    bool improving, bump;
-                    int nl;                                                       // n_skip after this lane
-                    if (__ballot(cand > (unsigned)max_f + UBIAS) == 0) {
-                        // no lane beats max_f (the usual case beyond the first chunk): nobody improves, n_skip only
-                        // counts the marked lanes - a prefix popcount instead of three wave scans
-                        improving = false;
-                        bump = !skip && hit;
-                        const unsigned long long bm = __ballot(bump);
-                        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
-                        nl = n_skip + below + (bump ? 1 : 0);
-                    } else {
-                        const unsigned pm = wave_scan_umax(cand);                 // inclusive prefix max of candidates
-                        unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);         // exclusive (wave_shr:1)
-                        pmx = lane == 0 ? 0u : pmx;
-                        improving = !skip && cand > max((unsigned)max_f + UBIAS, pmx);
-                        bump = !skip && !improving && hit;
-                        const int d = improving ? -1 : (bump ? 1 : 0);
-                        const int S = n_skip + wave_scan_add(d);
-                        // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
-                        const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
-                        const int mn = -(int)(mx - UBIAS);
-                        nl = S - min(0, mn);
-                    }
-                    const unsigned long long brk = __ballot(bump && nl > max_skip);
-                    const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
-                    const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
-                    visited += __builtin_popcountll(__ballot(valid) & (bl >= 63 ? ~0ull : ((2ull << bl) - 1)));
-                    const unsigned long long imp = __ballot(improving) & before;
-                    if (imp) {
-                        const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
-                        max_j = jhi - li;
-                        max_f = __builtin_amdgcn_readlane(sc, li);
-                    }
-                    // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89)
-                    if (!skip && pj >= 0 && lane < bl) {
-                        t[pj] = i;
-                        if (i - pj <= RING) rt[pj & (RING - 1)] = i;
-                    }
-                    n_skip = __builtin_amdgcn_readlane(nl, 63);
-                    return bl < 64;
-                };
-                int jhi = i - 1;
-                bool broke = false;
-                // chunks that lie inside the ring: LDS only
-                for (; jhi >= st && i - (jhi - 63) <= RING; jhi -= 64) {
-                    const int j = jhi - lane;
-                    const bool valid = j >= st;
-                    const int rs = (valid ? j : st) & (RING - 1);
-                    if ((broke = chunk(jhi, valid, rx[rs], ry[rs], rf[rs], rp[rs], rt[rs]))) break;
-                }
-                // deeper chunks: the global arrays (this wavefront's own earlier stores are visible in order)
-                if (!broke)
-                    for (; jhi >= st; jhi -= 64) {
+                    // ring slot of anchor a, i - 320 < a <= i
+                    auto slot_of = [&](int a) -> int { const int v = si - (i - a); return v < 0 ? v + RING_PHYS : v; };
+
+                    STAMP(0);
+                    int max_f = q_span, max_j = -1, n_skip = 0, last_bl = 64;
+                    // One 64-wide chunk of the look-back, lane 0 = anchor jhi.  Returns true when the max_skip break fired.
+                    // The anchor words and DP state of the chunk arrive as arguments, so that the ring path below is
+                    // made of LDS reads only.
+                    auto chunk = [&](int jhi, bool valid, uint64_t xj, uint64_t yj, int fj, int pj, int tj) -> bool {
+                        // ---- phase 1: candidate score / `continue` mask (:59-80)
+    #ifdef GBX_CHAIN_STAMPS
+                        { unsigned lo_ = (unsigned)xj, a_ = (unsigned)fj, b_ = (unsigned)pj, c_ = (unsigned)tj, d_ = (unsigned)yj;
+                          asm volatile("" :: "v"(lo_), "v"(a_), "v"(b_), "v"(c_), "v"(d_)); ++n_chunks_; }
+    #endif
+                        STAMP(1);
+                        int dq, dd, min_d, log_dd, c_lin, sc, gap_cost = 0;
+                        bool skip;
+                        if constexpr (NARROW) {
+                            // dr in [0, 2^32) as unsigned (sorted x, equal upper words); every use below either compares
+                            // it with a positive int (lanes with dq <= 0 are skipped) or truncates it to 32 bits as the
+                            // reference's int32 assignments do
+                            const unsigned dr = (unsigned)ri - (unsigned)xj;
+                            dq = qi - (int)yj;
+                            skip = !valid || dr == 0 || dq <= 0 || dq > max_dist_y || dq > max_dist_x;
+                            const bool gt = dr > (unsigned)dq;
+                            dd = gt ? (int)(dr - (unsigned)dq) : (int)((unsigned)dq - dr);
+                            skip = skip || dd > bw;
+                            skip = skip || (n_segs > 1 && (max_dist_y < 0 || dr > (unsigned)max_dist_y));
+                            min_d = gt ? dq : (int)dr;
+                            sc = min_d > q_span ? q_span : min_d;
+                            log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
+                            c_lin = (int)((double)dd * .01 * avg_qspan);
+                            gap_cost = c_lin + (log_dd >> 1);
+                        } else {
+                            const int64_t dr = (int64_t)(ri - xj);
+                            dq = qi - (int)yj;
+                            const int sidj = (int)(yj >> 48 & 0xff);
+                            const bool same = sidi == sidj;
+                            skip = !valid || (same && dr == 0) || dq <= 0;
+                            skip = skip || (same && dq > max_dist_y) || dq > max_dist_x;
+                            dd = (int)(dr > dq ? dr - dq : dq - dr);
+                            skip = skip || (same && dd > bw);
+                            skip = skip || (n_segs > 1 && same && dr > max_dist_y);
+                            min_d = dq < dr ? dq : (int)dr;
+                            sc = min_d > q_span ? q_span : min_d;
+                            log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
+                            c_lin = (int)((double)dd * .01 * avg_qspan);
+                            if (!same) {
+                                if (dr == 0) ++sc;
+                                else gap_cost = c_lin < log_dd ? c_lin : log_dd;
+                            } else {
+                                gap_cost = c_lin + (log_dd >> 1);
+                            }
+                        }
+                        // (int)((double)gap_cost * gap_scale + .499) with gap_scale = 1.0f is gap_cost itself: gap_cost >= 0
+                        // for every lane that is not skipped (dd >= 0), and skipped lanes never use sc
+                        sc -= gap_cost;
+                        sc += fj;
+    #ifdef GBX_CHAIN_STAMPS
+                        { unsigned a_ = (unsigned)sc, b_ = skip; asm volatile("" :: "v"(a_), "v"(b_)); }
+    #endif
+                        STAMP(2);
+                        // ---- phase 2: was this j already marked as a parent during this i? (:84)
+                        mark[lane] = 0;
+                        const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
+                        if (!skip && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
+                        // The marks travel from lane to lane through LDS inside one wavefront (LDS operations of a wavefront
+                        // are performed in order): the read is volatile so that the compiler does not forward this lane's own
+                        // store of 0 to it.  No short circuit with tj == i: one LDS read, no branch.
+                        const bool hit = (((volatile int *)mark)[lane] != 0) | (tj == i);
+    #ifdef GBX_CHAIN_STAMPS
+                        { unsigned b_ = hit; asm volatile("" :: "v"(b_)); }
+    #endif
+                        STAMP(3);
+                        // ---- phase 3: ordered max_f / n_skip / break (:81-88)
+                        const unsigned cand = skip ? 0u : (unsigned)sc + UBIAS;      // biased: 0 = "no candidate"
+                        bool improving, bump;
+                        int nl;                                                       // n_skip after this lane
+                        if (__ballot(cand > (unsigned)max_f + UBIAS) == 0) {
+                            // no lane beats max_f (the usual case beyond the first chunk): nobody improves, n_skip only
+                            // counts the marked lanes - a prefix popcount instead of three wave scans
+                            improving = false;
+                            bump = !skip && hit;
+                            const unsigned long long bm = __ballot(bump);
+                            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+                            nl = n_skip + below + (bump ? 1 : 0);
+                        } else {
+                            const unsigned pm = wave_scan_umax(cand);                 // inclusive prefix max of candidates
+                            unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);         // exclusive (wave_shr:1)
+                            pmx = lane == 0 ? 0u : pmx;
+                            improving = !skip && cand > max((unsigned)max_f + UBIAS, pmx);
+                            bump = !skip && !improving && hit;
+                            // S = n_skip + (bumps up to and including this lane) - (improving lanes likewise): two ballots and
+                            // prefix popcounts instead of a third wave scan
+                            const unsigned long long bmask = __ballot(bump), imask = __ballot(improving);
+                            const int bcnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bmask, 0u));
+                            const int icnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(imask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)imask, 0u));
+                            const int S = n_skip + bcnt - icnt + (bump ? 1 : 0) - (improving ? 1 : 0);
+                            // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
+                            const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
+                            const int mn = -(int)(mx - UBIAS);
+                            nl = S - min(0, mn);
+                        }
+    #ifdef GBX_CHAIN_STAMPS
+                        { unsigned a_ = (unsigned)nl; asm volatile("" :: "v"(a_)); }
+    #endif
+                        STAMP(4);
+                        const unsigned long long brk = __ballot(bump && nl > max_skip);
+                        const int bl = brk ? __builtin_ctzll(brk) : 64;   // first breaking lane
+                        const unsigned long long before = bl >= 64 ? ~0ull : ((1ull << bl) - 1);
+                        last_bl = bl;
+                        const unsigned long long imp = __ballot(improving) & before;
+                        if (imp) {
+                            const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
+                            max_j = jhi - li;
+                            max_f = __builtin_amdgcn_readlane(sc, li);
+                        }
+                        STAMP(5);
+                        // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89): in the ring while
+                        // the parent's block is live, straight to the output (already flushed there) when it is older
+                        if (!skip && pj >= 0 && lane < bl) {
+                            if (pj >= live0) rst[slot_of(pj)].z = i;
+                            else t[pj] = i;
+                        }
+                        n_skip = __builtin_amdgcn_readlane(nl, 63);
+                        STAMP(6);
+                        return bl < 64;
+                    };
+                    int jhi = i - 1;
+                    bool broke = false;
+                    // chunks that lie inside the ring: LDS only
+                    for (; jhi >= st && jhi - 63 >= live0; jhi -= 64) {
                         const int j = jhi - lane;
                         const bool valid = j >= st;
-                        const int jj = valid ? j : st;
-                        if (chunk(jhi, valid, settle(x[jj]), settle(y[jj]), settle(f[jj]), settle(p[jj]), settle(t[jj]))) break;
+                        const int rs = slot_of(valid ? j : st);
+                        const uint4 wxy = rxy[rs];
+                        const int4 wst = rst[rs];
+                        if ((broke = chunk(jhi, valid, ((uint64_t)wxy.y << 32) | wxy.x, ((uint64_t)wxy.w << 32) | wxy.z, wst.x, wst.y, wst.z))) break;
                     }
-                // :91-92, to the outputs and to the ring
-                int pkj = 0;
-                if (max_j >= 0) {
-                    if (i - max_j <= RING) pkj = rk[max_j & (RING - 1)];
-                    else pkj = settle(pk[max_j]);
+                    // deeper chunks: the global arrays (blocks that left the ring are complete there; a chunk that straddles
+                    // the ring's edge reads its newer lanes from the ring)
+                    if (!broke)
+                        for (; jhi >= st; jhi -= 64) {
+                            const int j = jhi - lane;
+                            const bool valid = j >= st;
+                            const int jj = valid ? j : st;
+                            uint64_t xj, yj; int fj, pj, tj;
+                            if (jj >= live0) {
+                                const int rs = slot_of(jj);
+                                const uint4 wxy = rxy[rs];
+                                const int4 wst = rst[rs];
+                                xj = ((uint64_t)wxy.y << 32) | wxy.x; yj = ((uint64_t)wxy.w << 32) | wxy.z; fj = wst.x; pj = wst.y; tj = wst.z;
+                            } else {
+                                xj = settle(x[jj]); yj = settle(y[jj]); fj = settle(f[jj]); pj = settle(p[jj]); tj = settle(t[jj]);
+                            }
+                            if (chunk(jhi, valid, xj, yj, fj, pj, tj)) break;
+                        }
+                    // predecessors visited (the benchmark's cell count): everything down to st, or down to the breaking lane
+                    visited += (unsigned long long)(last_bl < 64 ? (i - 1 - jhi) + last_bl + 1 : i - st);
+                    STAMP(7);
+                    // :91-92: into the block's output registers and the ring
+                    int pkj = 0;
+                    if (max_j >= 0) {
+                        if (max_j >= live0) pkj = rst[slot_of(max_j)].w;
+                        else pkj = settle(pk[max_j]);
+                    }
+                    const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
+                    const bool mine = lane == k;                  // one compare, three selects: no exec-mask change, no LDS
+                    of_ = mine ? max_f : of_;
+                    op_ = mine ? max_j : op_;
+                    ok_ = mine ? pki : ok_;
+                    if (lane == 0) rst[si] = make_int4(max_f, max_j, 0, pki);
+                    STAMP(8);
                 }
-                const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
-                if (lane == 0) {
-                    f[i] = max_f; p[i] = max_j; pk[i] = pki;
-                    const int rs = i & (RING - 1);
-                    rx[rs] = ri; ry[rs] = yi; rf[rs] = max_f; rp[rs] = max_j; rt[rs] = 0; rk[rs] = pki;
+                if (lane < kmax) { f[ib + lane] = of_; p[ib + lane] = op_; pk[ib + lane] = ok_; }
+            }
+            // targets still in the ring: the anchors of the last five blocks
+            if (n > 0) {
+                const int ibl = (n - 1) & ~63;                    // start of the last block, whose slab is sib - 64 (mod 320)
+                const int sibl = sib == 0 ? RING_PHYS - 64 : sib - 64;
+                for (int a = max(0, ibl - RING_LIVE) + lane; a < n; a += 64) {
+                    int v = sibl + (a - ibl);
+                    v = v < 0 ? v + RING_PHYS : v;
+                    t[a] = rst[v].z;
                 }
             }
-        }
+    #ifdef GBX_CHAIN_STAMPS
+            if (lane == 0 && (unsigned long long)n >= g_chain_stamps[13]) {      // the longest call finishes last
+                for (int k = 0; k < 9; ++k) g_chain_stamps[k] = acc_[k];
+                g_chain_stamps[12] = n_chunks_; g_chain_stamps[13] = (unsigned long long)n;
+            }
+    #endif
+        };
+        if (flags == 0) run_call(std::true_type{}); else run_call(std::false_type{});
         if (lane == 0) atomicAdd(W.evaluated, visited);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
@@ -286,9 +456,17 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
 
 size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors)
 {
-    // counters (3*NBUCKET ints) + order[n_calls] + optional target/peak planes
-    return (size_t)(3 * NBUCKET + (n_calls > 0 ? n_calls : 0) + 2 * (n_anchors > 0 ? n_anchors : 0) + 16) * sizeof(int32_t);
+    // counters (3*NBUCKET ints) + order[n_calls] + optional target/peak planes + st[n_anchors] + unsorted[n_calls]
+    return (size_t)(3 * NBUCKET + 2 * (n_calls > 0 ? n_calls : 0) + 3 * (n_anchors > 0 ? n_anchors : 0) + 24) * sizeof(int32_t);
 }
+
+#ifdef GBX_CHAIN_STAMPS
+extern "C" int gbx_debug_chain_stamps(unsigned long long *out16)
+{
+    GBX_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chain_stamps), sizeof(unsigned long long) * 16));
+    return GBX_OK;
+}
+#endif
 
 int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s)
 {
@@ -309,16 +487,25 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     if (work_bytes < chain_workspace_bytes(n_calls, n_anchors)) { set_error("chain: workspace too small"); return GBX_ERR_ARG; }
     int32_t *wi = (int32_t *)d_work;
     // [counts | cursors | next, evaluated(u64 at +2) | order[n_calls] | spare planes]
-    ChainWork W = {wi, wi + NBUCKET, wi + 2 * NBUCKET, wi + 3 * NBUCKET, (unsigned long long *)(wi + 2 * NBUCKET + 2)};
     int32_t *spare = wi + 3 * NBUCKET + n_calls + 8;
+    ChainWork W = {wi, wi + NBUCKET, wi + 2 * NBUCKET, wi + 3 * NBUCKET, (unsigned long long *)(wi + 2 * NBUCKET + 2),
+                   spare + 2 * n_anchors, spare + 3 * n_anchors + 8};
     if (!d_target) d_target = spare;
     if (!d_peak) d_peak = spare + n_anchors;
     GBX_HIP(hipMemsetAsync(d_work, 0, 3 * NBUCKET * sizeof(int32_t), s));
+    // GBX_CHAIN_WIDE=1 (test aid): every call takes the general 64-bit / multi-segment path (flag bit 1 preset)
+    const char *wide_env = getenv("GBX_CHAIN_WIDE");
+    GBX_HIP(hipMemsetAsync(W.unsorted, wide_env && atoi(wide_env) ? 2 : 0, (size_t)n_calls * sizeof(int32_t), s));
     const int ob = (int)((n_calls + 255) / 256);
     {
         Stage st("chain_order", s);
         hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, n_calls, d_off, W, 0);
         hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, n_calls, d_off, W, 1);
+    }
+    {
+        // up to 8 slices of a call side by side: long calls are not left to one block (the longest has 60 000 anchors)
+        Stage st("chain_st", s);
+        hipLaunchKernelGGL(chain_st_kernel, dim3((unsigned)n_calls, 8), dim3(256), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr, W.st, W.unsorted);
     }
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);
