@@ -223,7 +223,8 @@ class ChainWork:
         self.extra["evaluated_pairs_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        return 32 * self.d.n_anchors, self.units             # 16 B anchor in + 4 x 4 B outputs (16 in + 8 out + 8)
+        # 16 B anchor in + 4 x 4 B outputs (16 in + 8 out + 8 with targets / peaks exported)
+        return 32 * self.d.n_anchors, self.units
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgbx.so")
+LIB_PATH = os.environ.get("GBX_LIB") or os.path.join(_HERE, "libgbx.so")      # GBX_LIB: a tuning build of the same library
 
 GBX_OK = 0
 GBX_ERR_ARG = -1

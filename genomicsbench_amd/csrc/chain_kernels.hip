@@ -103,11 +103,18 @@ __device__ unsigned long long g_chain_stamps[16];
 #define STAMP_RESET() do { } while (0)
 #endif
 
-// Ring of the most recent anchors in LDS, five slabs of 64 (anchor a lives in slot a mod 320).  While the block of
-// anchors [ib, ib+64) is being computed, the anchors a >= ib - RING_LIVE are addressed in the ring (four complete
+// Ring of the most recent anchors in LDS, slabs of 64 (anchor a lives in slot a mod RING_PHYS).  While the block of
+// anchors [ib, ib+64) is being computed, the anchors a >= ib - RING_LIVE are addressed in the ring (complete
 // blocks + the one being filled); older ones are read from / written to global memory.
-constexpr int RING_LIVE = 256;
-constexpr int RING_PHYS = 320;
+// Ring size (GBX_CHAIN_RING_LIVE to tune): measured on 'large', whose longest call is the critical path and whose
+// look-backs reach past 256 anchors in a tenth of its chunks: 256 anchors (10.5 KB, 15 calls per CU) 76.7-78.0 ms,
+// 512 (18.7 KB, 8 per CU) 74.1-75.0, 768 (26.9 KB, 6 per CU) 72.2-73.3.  512 keeps eight calls per CU for jobs made of
+// many short calls.
+#ifndef GBX_CHAIN_RING_LIVE
+#define GBX_CHAIN_RING_LIVE 512
+#endif
+constexpr int RING_LIVE = GBX_CHAIN_RING_LIVE;
+constexpr int RING_PHYS = RING_LIVE + 64;
 
 // Loaded values that are produced on a rare path and consumed after the paths merge make the compiler put
 // `s_waitcnt vmcnt(0)` at the merge point - which, on the common path, waits for this wavefront's
@@ -268,8 +275,19 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                           asm volatile("" :: "v"(lo_), "v"(a_), "v"(b_), "v"(c_), "v"(d_)); ++n_chunks_; }
     #endif
                         STAMP(1);
-                        int dq, dd, min_d, log_dd, c_lin, sc, gap_cost = 0;
+                        int dq, dd, min_d, log_dd, c_lin, sc, gap_cost = 0, marked = 0;
                         bool skip;
+                        // ---- phase 2, issued as soon as the `continue` mask is known: was this j already marked as a parent
+                        // during this i (:84)?  True iff an earlier visited, non-skipped lane's parent is this lane's anchor (or
+                        // tj == i from an earlier chunk).  The marks travel from lane to lane through LDS inside one wavefront
+                        // (its LDS operations are performed in order); the read is volatile so that the compiler does not
+                        // forward this lane's own store of 0 to it.
+                        auto exchange_marks = [&](bool skip_) -> int {
+                            mark[lane] = 0;
+                            const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
+                            if (!skip_ && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
+                            return ((volatile int *)mark)[lane];
+                        };
                         if constexpr (NARROW) {
                             // dr in [0, 2^32) as unsigned (sorted x, equal upper words); every use below either compares
                             // it with a positive int (lanes with dq <= 0 are skipped) or truncates it to 32 bits as the
@@ -281,6 +299,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             dd = gt ? (int)(dr - (unsigned)dq) : (int)((unsigned)dq - dr);
                             skip = skip || dd > bw;
                             skip = skip || (n_segs > 1 && (max_dist_y < 0 || dr > (unsigned)max_dist_y));
+                            marked = exchange_marks(skip);            // the LDS round trip runs under the arithmetic below
                             min_d = gt ? dq : (int)dr;
                             sc = min_d > q_span ? q_span : min_d;
                             log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
@@ -296,6 +315,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             dd = (int)(dr > dq ? dr - dq : dq - dr);
                             skip = skip || (same && dd > bw);
                             skip = skip || (n_segs > 1 && same && dr > max_dist_y);
+                            marked = exchange_marks(skip);            // the LDS round trip runs under the arithmetic below
                             min_d = dq < dr ? dq : (int)dr;
                             sc = min_d > q_span ? q_span : min_d;
                             log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
@@ -315,15 +335,8 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         { unsigned a_ = (unsigned)sc, b_ = skip; asm volatile("" :: "v"(a_), "v"(b_)); }
     #endif
                         STAMP(2);
-                        // ---- phase 2: was this j already marked as a parent during this i? (:84)
-                        mark[lane] = 0;
-                        const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
-                        if (!skip && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
-                        // The marks travel from lane to lane through LDS inside one wavefront (LDS operations of a wavefront
-                        // are performed in order): the read is volatile so that the compiler does not forward this lane's own
-                        // store of 0 to it.  No short circuit with tj == i: one LDS read, no branch.
-                        const bool hit = (((volatile int *)mark)[lane] != 0) | (tj == i);
-    #ifdef GBX_CHAIN_STAMPS
+                        const bool hit = (marked != 0) | (tj == i);
+#ifdef GBX_CHAIN_STAMPS
                         { unsigned b_ = hit; asm volatile("" :: "v"(b_)); }
     #endif
                         STAMP(3);

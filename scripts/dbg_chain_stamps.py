@@ -18,6 +18,7 @@ N.lib().gbx_debug_chain_stamps(out)
 v = list(out)
 names = ["st advance", "ring/global loads (wait)", "phase1 math", "phase2 marks", "phase3 scans", "ballots/readlane", "phase4 stores", "loop overhead/exit", "outputs+ring update"]
 tot = sum(v[:9]); na = v[13]; nch = v[12]
+print("chunks past the ring (global loads)", v[14])
 print("anchors", na, "chunks", nch, "chunks/anchor %.2f" % (nch / max(na, 1)), "cycles/anchor %.0f" % (tot / max(na, 1)))
 for k, nm in enumerate(names):
     per = v[k] / max(nch if 1 <= k <= 6 else na, 1)
