@@ -101,7 +101,12 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
-    L.mat = take((int64_t)(ncap + 1) * poa_cap_stride(lmax) * 5 * (int64_t)sizeof(poa_cell_t) + 64);
+    #ifndef GBX_POA_PLANES
+#define GBX_POA_PLANES 2
+#endif
+    // pipelined DP (sequences up to 512 columns): the H plane + one plane of (H-F, H-O) byte pairs; the column-block
+    // DP of longer sequences keeps spoa's five int16 planes
+    L.mat = take((int64_t)(ncap + 1) * poa_cap_stride(lmax) * (lmax <= 512 ? GBX_POA_PLANES : 5) * (int64_t)sizeof(poa_cell_t) + 64);
     L.total = align_up(o, 256);
     return L;
 }
@@ -303,7 +308,6 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
 // stores; a predecessor that is row r itself is handed over in registers.  Vector memory operations of one
 // wavefront are performed in order, so a row stored in an earlier iteration is visible to these loads
 // without a fence.
-struct PoaPredIn { v8s h, f, o; int h0, o0, f0; };
 
 // ---- packed int16 arithmetic of the pipelined DP --------------------------------------------------
 // Cells are int16 in memory; the row arithmetic stays in packed int16 (two columns, or the (E,Q) pair,
@@ -312,6 +316,18 @@ struct PoaPredIn { v8s h, f, o; int h0, o0, f0; };
 // max-plus scan (saturating adds keep it there); real scores stay above -30000 (host plan), so the
 // results are the integers of the int32 formulation.
 typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+// F and O live in memory as gap deficits: dF = H - F, dO = H - O, one byte each.  They are small by construction:
+// H(i,j) <= max_p H(p,j) + (m - g) over the row's predecessors p (diagonal, vertical and horizontal moves alike, by
+// induction over the columns), and F(i,j) >= max_p H(p,j) + g, O(i,j) >= max_p H(p,j) + q, hence 0 <= H - F <= m - 2g
+// and 0 <= H - O <= m - g - q (14 and 33 with the driver's scores; the host plan checks they fit a byte).  Row 0 is
+// the exception (F = O = -infinity there): its deficits are stored as 255, which is as good as -infinity in every
+// use: a successor's F = max(H + g, F + e) never takes the second term once H - F >= e - g, and no equality test of
+// the traceback against a value that low can hold (each is bounded below by H + g or H + q of the same cell).
+// 4 instead of 6 bytes per cell written, and read, per predecessor row.
+struct PoaPredIn { v8s h; v4u fo; int h0, o0, f0; };      // fo = the lane's 8 bytes of H - F (x, y) and 8 of H - O (z, w), as stored
+constexpr int POA_C0_F = -3, POA_C0_O = -2;       // column-0 F and O of a row sit in H-plane pad cells before column 0: {F0, O0, -, H0} is one aligned 8-byte group
 constexpr short PK_NEG = -32768;
 __device__ inline v2s pk2(int lo, int hi) { v2s r; r.x = (short)lo; r.y = (short)hi; return r; }
 __device__ inline v2s pk_sat(int lo, int hi) { return pk2(max(lo, -32768), max(hi, -32768)); }      // clamp of -inf entries
@@ -339,7 +355,7 @@ struct PkMat { v2s ac, bd; };
 __device__ inline PkMat pk_mat(const Mat2 &m) { PkMat r; r.ac = pk_sat(m.a, m.c); r.bd = pk_sat(m.b, m.d); return r; }
 __device__ inline v2s pk_apply(const PkMat &m, v2s eq) { return pk_max(pk_add(m.ac, pk_lo(eq)), pk_add(m.bd, pk_hi(eq))); }
 
-__device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
+__device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
                                  int &max_i, int &max_j)
 {
     constexpr int CPL = 8;
@@ -358,9 +374,11 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 
     for (int j = lane; j <= len; j += 64) {                    // row 0 (`initialize`)
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
-        M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
         M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
     }
+    uint8_t *const FO = (uint8_t *)M.F;                        // the second plane: per lane 8 bytes of H-F, then 8 of H-O
+    for (int j = lane; j < POA_PIPE_STRIDE * 2; j += 64) FO[j] = 255;          // row 0: F = O = -infinity
+    if (lane == 0) { M.H[POA_COL0 + POA_C0_F] = 0; M.H[POA_COL0 + POA_C0_O] = 0; }
     int32_t *d_pred = g.score, *d_info = g.pred;
     const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;
     {
@@ -383,8 +401,10 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 
     auto fetch = [&](int prow, PoaPredIn &x) {
         const int64_t b = (int64_t)prow * Wp + POA_COL0;
-        x.h = *(const v8s *)(M.H + b + j0); x.f = *(const v8s *)(M.F + b + j0); x.o = *(const v8s *)(M.O + b + j0);
-        x.h0 = M.H[b]; x.o0 = M.O[b]; x.f0 = M.F[b];
+        x.h = *(const v8s *)(M.H + b + j0);
+        x.fo = *(const v4u *)(M.F + b + j0);
+        const v2u c0 = *(const v2u *)(M.H + b + POA_C0_F);      // {F0, O0 | pad, H0}
+        x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
     };
     auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
         const int rr = min(r, n - 1);
@@ -392,21 +412,25 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
     };
     auto settle_i = [](int &v) { asm volatile("" : "+v"(v)); };
     auto settle_in = [&](PoaPredIn &x) {
-        asm volatile("" : "+v"(x.h), "+v"(x.f), "+v"(x.o));
+        asm volatile("" : "+v"(x.h), "+v"(x.fo));
         settle_i(x.h0); settle_i(x.o0); settle_i(x.f0);
     };
     // F, O and diagonal-H contributions of one predecessor row to the lane's columns (packed pairs)
     auto pred_terms = [&](const PoaPredIn &x, const v2s (&sc)[4], v2s (&F)[4], v2s (&O)[4], v2s (&H)[4]) {
         const v2s hp[4] = {pk_pair<0>(x.h), pk_pair<1>(x.h), pk_pair<2>(x.h), pk_pair<3>(x.h)};
-        const v2s fp[4] = {pk_pair<0>(x.f), pk_pair<1>(x.f), pk_pair<2>(x.f), pk_pair<3>(x.f)};
-        const v2s op[4] = {pk_pair<0>(x.o), pk_pair<1>(x.o), pk_pair<2>(x.o), pk_pair<3>(x.o)};
+        // byte k of a dword -> zero-extended int16, two per register: one v_perm_b32 per pair of columns
+        const v2s dfp[4] = {pk_from(__builtin_amdgcn_perm(0u, x.fo.x, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.x, 0x0c030c02u)),
+                            pk_from(__builtin_amdgcn_perm(0u, x.fo.y, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.y, 0x0c030c02u))};
+        const v2s dqp[4] = {pk_from(__builtin_amdgcn_perm(0u, x.fo.z, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.z, 0x0c030c02u)),
+                            pk_from(__builtin_amdgcn_perm(0u, x.fo.w, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.w, 0x0c030c02u))};
         // H(pred, j0-1): high half of the previous lane's last pair, or column 0 for lane 0
         unsigned left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk_bits(hp[3]), 0x138, 0xf, 0xf, false);
         if (lane == 0) left = (unsigned)x.h0 << 16;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            F[k] = pk_max(pk_add(hp[k], G2), pk_add(fp[k], E2));
-            O[k] = pk_max(pk_add(hp[k], Q2), pk_add(op[k], C2));
+            // max(H + g, F + e) = H + max(g, e - (H - F)), likewise for O: the deficits are used as they are stored
+            F[k] = pk_add(hp[k], pk_max(G2, E2 - dfp[k]));
+            O[k] = pk_add(hp[k], pk_max(Q2, C2 - dqp[k]));
             const unsigned prev = k ? pk_bits(hp[k - 1]) : left;
             const v2s hs = pk_from(__builtin_amdgcn_alignbit(pk_bits(hp[k]), prev, 16));      // (H[j-1]) of the pair's columns
             H[k] = pk_add(hs, sc[k]);
@@ -421,7 +445,7 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
     desc(0, ap0, ap1, ap2, ainfo);
     desc(1, bp0, bp1, bp2, binfo);
     PoaPredIn in0, in1, last;
-    last.h = last.f = last.o = (v8s)0;
+    last.h = (v8s)0; last.fo = (v4u)0;
     last.h0 = last.o0 = last.f0 = 0;
     bool reg0 = false, reg1 = false;                           // predecessor k of the row at hand is the previous row
     {
@@ -495,7 +519,11 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
         // column 0: every lane stores the same values to the same cells
-        M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
+        if (lane == 0) {                                       // column 0: one 8-byte store
+            v2u c0;
+            c0.x = ((unsigned)F0 & 0xffffu) | ((unsigned)O0 << 16); c0.y = (unsigned)H0 << 16;
+            *(v2u *)(M.H + ro + POA_C0_F) = c0;
+        }
         const v2s cEQ = pk2(H0 + S.g, H0 + S.q);               // (E,Q) entering column 1
         v2s Aa[4];
 #pragma unroll
@@ -532,10 +560,15 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) Hn[k] = __builtin_shufflevector(hcol[2 * k], hcol[2 * k + 1], 0, 3);
         last.h = pk_join(Hn[0], Hn[1], Hn[2], Hn[3]);
-        last.f = pk_join(Fa[0], Fa[1], Fa[2], Fa[3]);
-        last.o = pk_join(Oa[0], Oa[1], Oa[2], Oa[3]);
+        const v2s d0 = Hn[0] - Fa[0], d1 = Hn[1] - Fa[1], d2 = Hn[2] - Fa[2], d3 = Hn[3] - Fa[3];      // deficits of this row
+        const v2s q0 = Hn[0] - Oa[0], q1 = Hn[1] - Oa[1], q2 = Hn[2] - Oa[2], q3 = Hn[3] - Oa[3];
         last.h0 = H0; last.o0 = O0; last.f0 = F0;
-        *(v8s *)(M.H + ro + j0) = last.h; *(v8s *)(M.F + ro + j0) = last.f; *(v8s *)(M.O + ro + j0) = last.o;
+        // low bytes of four int16 pairs -> one dword each (v_perm_b32: bytes 0 and 2 of either source)
+        last.fo.x = __builtin_amdgcn_perm(pk_bits(d1), pk_bits(d0), 0x06040200u);
+        last.fo.y = __builtin_amdgcn_perm(pk_bits(d3), pk_bits(d2), 0x06040200u);
+        last.fo.z = __builtin_amdgcn_perm(pk_bits(q1), pk_bits(q0), 0x06040200u);
+        last.fo.w = __builtin_amdgcn_perm(pk_bits(q3), pk_bits(q2), 0x06040200u);
+        *(v8s *)(M.H + ro + j0) = last.h; *(v4u *)(M.F + ro + j0) = last.fo;
         if (sink) {                                            // H(i, len)
             const int cl = (len - 1) % CPL;
             v2s hv = hcol[0];
@@ -556,7 +589,7 @@ __device__ void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const 
 // are rebuilt from its H by two tilted prefix-max scans, E(i,j) = max_{k<j} H(i,k) + g + (j-1-k) e (same
 // for Q with q, c) - the same integers the DP had, since H is final - one row load and ~60 instructions,
 // cached per row.  Otherwise identical to poa_traceback (poa_graph.h), which serves the stored-E/Q path.
-__device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len,
+__device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len,
                                    int max_i, int max_j)
 {
     g.n_path = 0;
@@ -614,6 +647,14 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
 
     int i = max_i, j = max_j, prev_i = 0, prev_j = 0, np = 0;
 #define PG_AT(A, a, b) ((int)(A)[(int64_t)(a) * Wp + (b) + POA_COL0])
+    // F and O of a cell from the deficit plane (PoaPredIn): column j >= 1 is byte (j-1)&7 of the 16-byte group of lane
+    // (j-1)>>3, H-F in the group's first 8 bytes and H-O in the last 8; column 0 keeps both as int16 in the row's pad cells
+    const uint8_t *const FO = (const uint8_t *)M.F;
+    auto fo_at = [&](int i_, int j_, int hv, int which) -> int {
+        if (j_ == 0) return (int)M.H[(int64_t)i_ * Wp + POA_COL0 + (which ? POA_C0_O : POA_C0_F)];
+        const int64_t byte = ((int64_t)i_ * Wp + POA_COL0 + 1) * 2 + (int64_t)((j_ - 1) >> 3) * 16 + ((j_ - 1) & 7) + (which ? 8 : 0);
+        return hv - (int)FO[byte];
+    };
     int plo = -1, phi = -1;                      // positions come out in descending order
 #define PG_PUSH(nd, ps) do { const int ps_ = (ps); if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = ps_; } \
                              if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; } while (0)
@@ -676,7 +717,7 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
             if (!found) {
                 for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
                     const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
-                    const int fv = PG_AT(M.F, pi, j), hv = PG_AT(M.H, pi, j), ov = PG_AT(M.O, pi, j);
+                    const int hv = PG_AT(M.H, pi, j), fv = fo_at(pi, j, hv, 0), ov = fo_at(pi, j, hv, 1);
                     const bool c1 = Hij == fv + S.e;
                     const bool c2 = !c1 && Hij == hv + S.g;
                     const bool c3 = !c1 && !c2 && Hij == ov + S.c;
@@ -716,14 +757,15 @@ __device__ void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaS
                 prev_i = 0;
                 const int nd = g.r2n[i - 1];
                 const int icu = (rd_info[i - 1] >> 8) & 0xff;
-                const int fij = PG_AT(M.F, i, j), oij = PG_AT(M.O, i, j);
+                const int hij = PG_AT(M.H, i, j);
+                const int fij = fo_at(i, j, hij, 0), oij = fo_at(i, j, hij, 1);
                 for (int p = 0; p < icu; ++p) {
                     const int pi = p ? g.n2r[PG_IN_SRC(g, nd, p)] + 1 : rd_pred[i - 1];
                     const int hv = PG_AT(M.H, pi, j);
                     const bool s1 = fij == hv + S.g;
-                    const bool s2 = !s1 && fij == PG_AT(M.F, pi, j) + S.e;
+                    const bool s2 = !s1 && fij == fo_at(pi, j, hv, 0) + S.e;
                     const bool s3 = !s1 && !s2 && oij == hv + S.q;
-                    const bool s4 = !s1 && !s2 && !s3 && oij == PG_AT(M.O, pi, j) + S.c;
+                    const bool s4 = !s1 && !s2 && !s3 && oij == fo_at(pi, j, hv, 1) + S.c;
                     if (s1) stop = true; else if (s2) stop = false; else stop = s3;
                     if (s1 || s2 || s3 || s4) { prev_i = pi; break; }
                 }
@@ -797,13 +839,21 @@ __device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo
 #endif
 // LDS arrays of the topological sort, persistent per wavefront for the life of a window
 constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
+// The pointers carry the LDS address space in their type.  As plain (generic) pointers they depend on the compiler
+// inferring the address space through the whole inlined window kernel; when it does not (it stopped after an unrelated
+// change of the DP: SQ_INSTS_LDS fell from 2.1e9 to 2.8e6 per launch) every access below becomes a FLAT instruction,
+// which works, and costs half as much again per visit.
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) short lds_s16;
 struct PoaTopoLds {
-    unsigned char *st8;      // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
-    short *old;              // [ncp] rank of the node in the previous sort (-1: node added since)
-    short *stk;              // [stk_cap] DFS stack
+    lds_u8 *st8;             // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
+    lds_s16 *old;            // [ncp] rank of the node in the previous sort (-1: node added since)
+    lds_s16 *stk;            // [stk_cap] DFS stack
     int stk_cap;             // entries; a deeper walk falls back to the global-memory sort
-    short *rec;              // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
+    lds_s16 *rec;            // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
     int n_sorted;            // nodes ranked by the previous sort
+    int use;                 // 0: the node capacity does not fit LDS, the global-memory sort runs instead (a null test
+                             // will not do: LDS offset 0 is a valid address, and the LDS null pointer is not 0)
 };
 
 // Graph::topological_sort, same order as poa_topo_sort (poa_graph.h).  The walk itself is serial, but one
@@ -814,9 +864,9 @@ struct PoaTopoLds {
 // order closely (one sequence changes the graph little), so the records of 64 nodes that were consecutive
 // in that order are cached in LDS and re-read when the walk has moved on (second miss in the same
 // 64-rank region); nodes added since the previous sort are read in place.
-__device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
+__device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
-    unsigned char *st8 = T.st8; short *stk = T.stk, *old = T.old, *rec = T.rec;
+    lds_u8 *st8 = T.st8; lds_s16 *stk = T.stk, *old = T.old, *rec = T.rec;
     int32_t *ord = g.stack;                                    // the order under construction goes to global memory (the
                                                                // global DFS-stack area is free here): stores only, nothing in
                                                                // the walk waits for them; r2n still holds the previous order
@@ -834,7 +884,7 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
         const PoaInt4 e = *(const PoaInt4 *)(g.in_src + (int64_t)id * 4);
         const PoaInt4 a = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE);
         const PoaInt4 b = *(const PoaInt4 *)(g.aln + (int64_t)id * POA_ALN_STRIDE + 4);
-        short *r = rec + lane * POA_REC_SHORTS;
+        lds_s16 *r = rec + lane * POA_REC_SHORTS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { r[k] = (short)e.v[k]; r[4 + k] = (short)a.v[k]; r[8 + k] = (short)b.v[k]; }
         r[12] = (short)cc;
@@ -958,8 +1008,8 @@ __device__ inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 #define TOPO_TIMED(g) POA_TOPO(g);
 #endif
 // topological sort through LDS when the kernel was launched with the LDS layout, else the global-memory one
-#define POA_TOPO(g) { if (T.st8) poa_topo_sort_lds(g, T); else poa_topo_sort(g); }
-__device__ void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, PoaTopoLds &T)
+#define POA_TOPO(g) { if (T.use) poa_topo_sort_lds(g, T); else poa_topo_sort(g); }
+__device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, PoaTopoLds &T)
 {
     if (len == 0) return;
     const int lane = threadIdx.x & 63;
@@ -1072,6 +1122,11 @@ __global__ void poa_job_stats_kernel(PoaArgs A)
     if (threadIdx.x == 0 && blockIdx.x == 0) A.cells[14] = (unsigned long long)(A.win_first_seq[A.n_windows] - A.win_first_seq[0]);
 }
 
+// The phase functions above are always_inline: the window kernel is one function on purpose.  Left to its cost model the
+// inliner stops at 1100 basic blocks (amdgpu-inline-max-bb) and the first phase it leaves out (add_alignment, after the
+// DP grew by a dozen instructions) takes `PoaGraph &` by reference: the graph's pointers then live in scratch memory,
+// lose their address space, and every access of the kernel becomes a FLAT instruction (993 of them, 397 instead of
+// 330 ms, found through SQ_INSTS_LDS dropping to nothing).
 __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
@@ -1092,9 +1147,11 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     const int ncp = (A.ncap + 15) & ~15;
     // serial DFS state on chip (LDS): state byte per node, order under construction, stack
     PoaTopoLds T;
-    T.st8 = A.lds_marks ? (unsigned char *)lds_raw : nullptr;
-    T.old = (short *)(lds_raw + ncp);
-    T.stk = (short *)(lds_raw + 3 * ncp);
+    lds_u8 *const lds0 = (lds_u8 *)lds_raw;
+    T.st8 = lds0;
+    T.use = A.lds_marks;
+    T.old = (lds_s16 *)(lds0 + ncp);
+    T.stk = (lds_s16 *)(lds0 + 3 * ncp);
     T.stk_cap = A.lds_stack;
     T.rec = T.stk + A.lds_stack;
     T.n_sorted = 0;
@@ -1145,9 +1202,15 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 PH_T0
+#ifdef GBX_POA_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
+#ifdef GBX_POA_PRIO
+                __builtin_amdgcn_s_setprio(GBX_POA_PRIO);
+#endif
                 if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                 else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
@@ -1243,6 +1306,9 @@ bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax)
     if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
     const int64_t worst = -(int64_t)(S.q < S.g ? -S.q : -S.g) * 2 - (int64_t)(S.c > S.e ? -S.c : -S.e) * (ncap + lmax);
     const int64_t worst_mis = (int64_t)S.n * lmax, hi = (int64_t)S.m * lmax;
+    // the pipelined DP keeps H - F and H - O in one byte each (PoaPredIn): H - F <= smax - max(g,q) - g, H - O likewise with q
+    const int smax = S.m > S.n ? S.m : S.n, delta = smax - (S.g > S.q ? S.g : S.q);
+    if (delta - S.g > 255 || delta - S.q > 255) return false;
     return !(worst < -30000 || worst_mis < -30000 || hi > 30000);
 }
 
