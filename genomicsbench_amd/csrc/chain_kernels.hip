@@ -27,6 +27,7 @@ namespace gbx {
 namespace {
 
 constexpr int NBUCKET = 32;
+typedef __attribute__((address_space(3))) int lds_int;
 
 template <int CTRL, int ROWMASK = 0xf>
 __device__ inline int dppi(int old, int x)
@@ -192,10 +193,11 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     // vectors, 16 bytes each, so that a look-back chunk is two ds_read_b128 per lane.  Scores / parents / peaks go
     // to global memory once per block of 64 anchors (coalesced), targets when their block leaves the ring.
     __shared__ uint4 rxy[RING_PHYS];
-    __shared__ int4 rst[RING_PHYS];
-    __shared__ int mark[64];
+    __shared__ int4 rst[RING_PHYS + 64];    // + a dump entry per lane for phase 4
+    __shared__ int mark[128];               // [0,64) the chunk's marks, [64,128) dump slots of the lanes that mark nothing
     const int lane = threadIdx.x;
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
+    const unsigned long long lane_bit = 1ull << lane;
 
     // one call per block when the grid allows it (chain_launch), else a stride over the longest-first list;
     // everything derived from `slot` stays wave-uniform
@@ -285,8 +287,10 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         auto exchange_marks = [&](bool skip_) -> int {
                             mark[lane] = 0;
                             const int tl = jhi - pj;                       // lane that holds anchor pj, if inside this chunk
-                            if (!skip_ && pj >= 0 && tl < 64) mark[tl] = 1; // tl > lane always: parents precede their children
-                            return ((volatile int *)mark)[lane];
+                            // tl > lane always: parents precede their children.  Lanes with nothing to mark write to a slot
+                            // of their own behind the 64 marks: one select instead of an exec-mask change and a branch
+                            mark[(!skip_ && pj >= 0 && tl < 64) ? tl : 64 + lane] = 1;
+                            return ((const volatile lds_int *)mark)[lane];    // typed LDS pointer: ds_read, not a FLAT load
                         };
                         if constexpr (NARROW) {
                             // dr in [0, 2^32) as unsigned (sorted x, equal upper words); every use below either compares
@@ -364,12 +368,21 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             const int bcnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bmask, 0u));
                             const int icnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(imask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)imask, 0u));
                             const int S = n_skip + bcnt - icnt + (bump ? 1 : 0) - (improving ? 1 : 0);
-                            // n_skip after this lane = walk reflected at 0: S - min(0, prefix-min S); the min via a biased max of -S
-                            const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
-                            const int mn = -(int)(mx - UBIAS);
-                            nl = S - min(0, mn);
+                            // n_skip after this lane = the walk S reflected at 0: S - min(0, prefix-min S).  The usual shape -
+                            // improving lanes only in front of the first bump - needs no scan: those improvements take n_skip
+                            // down towards 0 and from there on it only counts bumps.
+                            const unsigned long long first_b = bmask & (0 - bmask);                  // lowest bump bit (0 if none)
+                            const unsigned long long lead = first_b ? first_b - 1 : ~0ull;           // lanes before the first bump
+                            if ((imask & ~lead) == 0) {
+                                const int base = max(0, n_skip - (int)__builtin_popcountll(imask));  // after the leading improvements
+                                nl = (lane_bit & lead) ? max(0, n_skip - icnt - (improving ? 1 : 0)) : base + bcnt + (bump ? 1 : 0);
+                            } else {
+                                const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);          // min via a biased max of -S
+                                const int mn = -(int)(mx - UBIAS);
+                                nl = S - min(0, mn);
+                            }
                         }
-    #ifdef GBX_CHAIN_STAMPS
+#ifdef GBX_CHAIN_STAMPS
                         { unsigned a_ = (unsigned)nl; asm volatile("" :: "v"(a_)); }
     #endif
                         STAMP(4);
@@ -386,9 +399,11 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         STAMP(5);
                         // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89): in the ring while
                         // the parent's block is live, straight to the output (already flushed there) when it is older
-                        if (!skip && pj >= 0 && lane < bl) {
-                            if (pj >= live0) rst[slot_of(pj)].z = i;
-                            else t[pj] = i;
+                        {
+                            const bool wr = !skip && pj >= 0 && lane < bl;
+                            rst[wr && pj >= live0 ? slot_of(pj) : RING_PHYS + lane].z = i;      // non-writers: their dump entry
+                            if (__ballot(wr && pj < live0))                                     // rare: the parent left the ring
+                                if (wr && pj < live0) t[pj] = i;
                         }
                         n_skip = __builtin_amdgcn_readlane(nl, 63);
                         STAMP(6);
