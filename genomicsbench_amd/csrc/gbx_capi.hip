@@ -743,7 +743,9 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
     }
     plan->max_seq_len = lmax;
     plan->max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);     /* multiple of 4: 16-byte aligned edge rows */
-    int64_t cap = (int64_t)6 * lmax + 256;                 /* typical windows stay below ~3x the read length */
+    int nf = 6;                                            /* typical windows stay below ~3.6x the read length */
+    if (const char *e = getenv("GBX_POA_NODE_FACTOR")) { const int v = atoi(e); if (v >= 2 && v <= 16) nf = v; }   /* tuning aid */
+    int64_t cap = (int64_t)nf * lmax + 256;
     if (bmax + 8 < cap) cap = bmax + 8;
     plan->node_cap = (int32_t)cap;
     int cus = 256, dev = 0;

@@ -1202,15 +1202,13 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 int mi, mj;
                 cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
                 PH_T0
-#ifdef GBX_POA_PRIO
+                // The serial phases (one useful lane) are latency chains that lose issue slots to the other wavefronts' DP rows;
+                // the DP is throughput work that does not mind waiting.  Priority 3 for the former: 300.8 -> 294.7 ms.
                 __builtin_amdgcn_s_setprio(0);
-#endif
                 if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
-#ifdef GBX_POA_PRIO
-                __builtin_amdgcn_s_setprio(GBX_POA_PRIO);
-#endif
+                __builtin_amdgcn_s_setprio(3);
                 if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                 else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
@@ -1253,7 +1251,9 @@ static size_t poa_lds_plan(int ncap, int *stack_entries)
 {
     const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + 64 * POA_REC_SHORTS * 2;
     if (ncap >= 32768) return 0;
-    for (int waves = 12; waves >= 8; --waves) {
+    int max_waves = 12;
+    if (const char *e = getenv("GBX_POA_MAX_WAVES")) { const int v = atoi(e); if (v >= 8 && v <= 16) max_waves = v; }   // tuning aid
+    for (int waves = max_waves; waves >= 8; --waves) {
         // measured (node capacity 3364): twelve windows of 12304 B run together (336 ms); at 13024 B the twelfth is
         // resident only some of the time (362-386 ms), so the budget is 12 x 12544 B, not the nominal 160 KB
         const size_t share = ((size_t)12 * 12544 / (size_t)waves) & ~(size_t)31;
@@ -1280,7 +1280,9 @@ int poa_waves_per_cu(int ncap)
     // measured on MI355X (6000 windows, cursor schedule): 8 per CU 410 ms, 9: 393, 10: 378, 11: 361, 12: 329 - twelve is what
     // 168 VGPRs admit; poa_lds_plan sizes the LDS stack so that twelve fit
     const int hw = q;
-    if (q > 12) q = 12;
+    int max_waves = 12;
+    if (const char *e = getenv("GBX_POA_MAX_WAVES")) { const int v = atoi(e); if (v >= 8 && v <= 16) max_waves = v; }
+    if (q > max_waves) q = max_waves;
     if (const char *e = getenv("GBX_POA_WAVES_PER_CU")) {      // tuning aid: another number of windows in flight (up to what the hardware admits)
         const int v = atoi(e);
         if (v >= 1 && v <= hw) q = v;
