@@ -638,6 +638,34 @@ size_t bsw_workspace_bytes(int64_t n)
     return (size_t)(WS_HDR + 2 * (n > 0 ? n : 0)) * sizeof(int32_t);
 }
 
+// Expands the packed image of a byte arena (two base codes per byte, host_pipeline.h: pack4) over [lo, hi) of the
+// arena, lo even: 8 packed bytes -> 16 codes per thread.
+__global__ void __launch_bounds__(256) bsw_unpack4_kernel(const uint8_t *__restrict__ packed, uint8_t *__restrict__ out, int64_t lo, int64_t hi)
+{
+    const int64_t o = lo + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (o >= hi) return;
+    if (((uintptr_t)(packed + (o >> 1)) & 7) == 0 && ((uintptr_t)(out + o) & 15) == 0 && o + 16 <= hi) {
+        const uint2 v = *(const uint2 *)(packed + (o >> 1));
+        uint4 r;
+        // byte b = lo | hi << 4  ->  two bytes (lo, hi); four packed bytes give two dwords
+        auto spread = [](unsigned h) -> unsigned { return (h & 0xfu) | ((h & 0xf0u) << 4) | ((h & 0xf00u) << 8) | ((h & 0xf000u) << 12); };
+        r.x = spread(v.x & 0xffffu); r.y = spread(v.x >> 16); r.z = spread(v.y & 0xffffu); r.w = spread(v.y >> 16);
+        *(uint4 *)(out + o) = r;
+        return;
+    }
+    for (int64_t k = o; k < o + 16 && k < hi; ++k) out[k] = (uint8_t)((packed[k >> 1] >> ((k & 1) * 4)) & 0xf);
+}
+
+int bsw_unpack4(const uint8_t *d_packed, uint8_t *d_out, int64_t lo, int64_t hi, hipStream_t s)
+{
+    if (hi <= lo) return GBX_OK;
+    const int64_t threads = (hi - lo + 15) / 16;
+    Stage st("bsw_unpack4", s);
+    hipLaunchKernelGGL(bsw_unpack4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_packed, d_out, lo, hi);
+    GBX_HIP(hipGetLastError());
+    return GBX_OK;
+}
+
 // Small jobs whose queries all fit one register class (1..256 columns, no empty sequence, scores below the
 // packed-key limit; the caller has checked): one launch of the 8x16 or 16x16 kernel over the pairs in input order, without
 // the binning passes, the stream fork and the join - the dependent launch chain is what a 512-pair call costs.

@@ -353,7 +353,7 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
         slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0;
     };
     {
-        const int vt = n_slices >= 8 ? 4 : 1;
+        const int vt = n_slices >= 16 ? 8 : n_slices >= 8 ? 4 : 1;      // 0.9 ms with 4 threads at 2 M pairs, on the call's critical path
         std::vector<std::thread> th;
         for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = t; sl < n_slices; sl += vt) check_slice(sl); });
         for (int64_t sl = 0; sl < n_slices; sl += vt) check_slice(sl);
@@ -403,13 +403,29 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     mark("allocated", 0);
     HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28, n_chunks > 1);
     if ((rc = pipe.prepare(n_chunks))) return rc;
+    // Staged (large) calls send the bases two per byte: the upload workers pack them on their way into the pinned slabs
+    // (host_pipeline.h: pack4), the device expands them into the byte arenas the kernels read (bsw_unpack4) - the
+    // arenas are most of the upload (2 M pairs: 590 of 640 MB), and PCIe is the longest leg of the call.
+    const bool pack_bases = pipe.staged && !(getenv("GBX_BSW_PACK") && atoi(getenv("GBX_BSW_PACK")) == 0);
+    DevBuf dref_p(L), dqer_p(L);
+    if (pack_bases && ((rc = dref_p.alloc((size_t)ref_bytes / 2 + 16)) || (rc = dqer_p.alloc((size_t)qer_bytes / 2 + 16)))) return rc;
+    std::vector<int64_t> lo_r((size_t)n_chunks), hi_r((size_t)n_chunks), lo_q((size_t)n_chunks), hi_q((size_t)n_chunks);
     int64_t up_r = 0, up_q = 0;
     for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
         const int64_t b = a + chunk < n ? a + chunk : n, m = b - a;
-        const int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
-        const int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
-        pipe.stage(c, dref.as<uint8_t>() + up_r, ref + up_r, (size_t)(nr - up_r));
-        pipe.stage(c, dqer.as<uint8_t>() + up_q, qer + up_q, (size_t)(nq - up_q));
+        int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
+        int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
+        if (pack_bases) {
+            // packed ranges start at even offsets: round the ends up to even while the arena allows it
+            if ((nr & 1) && nr < ref_bytes) ++nr;
+            if ((nq & 1) && nq < qer_bytes) ++nq;
+            pipe.stage_pack4(c, dref_p.as<uint8_t>() + up_r / 2, ref + up_r, (size_t)(nr - up_r));
+            pipe.stage_pack4(c, dqer_p.as<uint8_t>() + up_q / 2, qer + up_q, (size_t)(nq - up_q));
+            lo_r[(size_t)c] = up_r; hi_r[(size_t)c] = nr; lo_q[(size_t)c] = up_q; hi_q[(size_t)c] = nq;
+        } else {
+            pipe.stage(c, dref.as<uint8_t>() + up_r, ref + up_r, (size_t)(nr - up_r));
+            pipe.stage(c, dqer.as<uint8_t>() + up_q, qer + up_q, (size_t)(nq - up_q));
+        }
         pipe.stage(c, didr.as<int64_t>() + a, idr + a, m * 8);
         pipe.stage(c, didq.as<int64_t>() + a, idq + a, m * 8);
         pipe.stage(c, dl1.as<int32_t>() + a, len1 + a, m * 4);
@@ -428,6 +444,10 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
     }
     if (direct) {
         if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        if (pack_bases &&
+            ((rc = bsw_unpack4(dref_p.as<uint8_t>(), dref.as<uint8_t>(), lo_r[0], hi_r[0], L->compute)) ||
+             (rc = bsw_unpack4(dqer_p.as<uint8_t>(), dqer.as<uint8_t>(), lo_q[0], hi_q[0], L->compute))))
+            return pipe.finish(rc);
         rc = bsw_launch_direct(p, n, direct_q, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>(), didq.as<int64_t>(),
                                dl1.as<int32_t>(), dl2.as<int32_t>(), dh0.as<int32_t>(), dout.as<gbx_bsw_result>(), L->compute);
         if (!rc) { pipe.fetch(0, out, dout.p, n * sizeof(gbx_bsw_result)); rc = pipe.chunk_launched(0, 0); }
@@ -437,6 +457,10 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
         const int64_t m = (a + chunk < n ? a + chunk : n) - a;
         if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
         mark("uploads queued, chunk", c);
+        if (pack_bases &&
+            ((rc = bsw_unpack4(dref_p.as<uint8_t>(), dref.as<uint8_t>(), lo_r[(size_t)c], hi_r[(size_t)c], L->compute)) ||
+             (rc = bsw_unpack4(dqer_p.as<uint8_t>(), dqer.as<uint8_t>(), lo_q[(size_t)c], hi_q[(size_t)c], L->compute))))
+            return pipe.finish(rc);
         // pipelined calls: no barrier between the chunks, the launch records one event per kernel stream
         hipEvent_t *je = n_chunks > 1 ? pipe.join_events(c) : nullptr;
         rc = bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,

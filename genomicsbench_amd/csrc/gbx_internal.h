@@ -64,6 +64,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s,
                hipEvent_t *join_events = nullptr);
 
+int bsw_unpack4(const uint8_t *d_packed, uint8_t *d_out, int64_t lo, int64_t hi, hipStream_t s);
 int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,
                       const uint8_t *d_ref, const uint8_t *d_qer, const int64_t *d_idr, const int64_t *d_idq,
                       const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0, gbx_bsw_result *d_out, hipStream_t s);

@@ -14,6 +14,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <thread>
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace gbx {
 
@@ -32,6 +35,42 @@ template <class F> static void parallel_ranges(int64_t n, int threads, F fn)
     for (int t = 1; t < threads; ++t) th.emplace_back([=] { fn(t, n * t / threads, n * (t + 1) / threads); });
     fn(0, (int64_t)0, n / threads);
     for (auto &x : th) x.join();
+}
+
+// Two base codes per byte for the PCIe leg of gbx_bsw_extend_host (codes 0..4; anything larger is clamped to 15, which
+// the kernels treat like 4, the ambiguous base): byte k of the output = code 2k | code 2k+1 << 4.  The upload workers
+// do this instead of their memcpy into the pinned slab, so the DMA moves half the bytes; bsw_unpack4 expands them on
+// the device.  n may be odd (the last byte then holds one code).
+static void pack4_scalar(uint8_t *d, const uint8_t *s, size_t n)
+{
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) {
+        const unsigned a = s[i] < 15 ? s[i] : 15, b = s[i + 1] < 15 ? s[i + 1] : 15;
+        d[i >> 1] = (uint8_t)(a | (b << 4));
+    }
+    if (i < n) d[i >> 1] = (uint8_t)(s[i] < 15 ? s[i] : 15);
+}
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+__attribute__((target("avx2"))) static void pack4_avx2(uint8_t *d, const uint8_t *s, size_t n)
+{
+    const __m256i m15 = _mm256_set1_epi8(15), mul = _mm256_set1_epi16(0x1001);   // bytes (1, 16): lo + 16 * hi per pair
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m256i a = _mm256_min_epu8(_mm256_loadu_si256((const __m256i *)(s + i)), m15);
+        const __m256i b = _mm256_min_epu8(_mm256_loadu_si256((const __m256i *)(s + i + 32)), m15);
+        const __m256i r = _mm256_packus_epi16(_mm256_maddubs_epi16(a, mul), _mm256_maddubs_epi16(b, mul));
+        _mm256_storeu_si256((__m256i *)(d + (i >> 1)), _mm256_permute4x64_epi64(r, 0xD8));
+    }
+    pack4_scalar(d + (i >> 1), s + i, n - i);
+}
+#endif
+static void pack4(uint8_t *d, const uint8_t *s, size_t n)
+{
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { pack4_avx2(d, s, n); return; }
+#endif
+    pack4_scalar(d, s, n);
 }
 
 struct DevBlock { void *p; size_t cap; };
@@ -174,7 +213,7 @@ struct DevBuf {
 //          the chunk is done
 //   P.finish()  -> joins the threads, returns the first error
 struct HostPipe {
-    struct Piece { char *dst; const char *src; size_t len; int chunk; };
+    struct Piece { char *dst; const char *src; size_t len; int chunk; bool pack; };     // pack: len source bytes -> (len+1)/2 at dst
     struct Fetch { void *dst; const void *src; size_t len; int chunk; };
     Lane *L;
     bool staged;
@@ -228,9 +267,22 @@ struct HostPipe {
         const size_t cap = staged ? Lane::PIECE : bytes;
         while (bytes) {
             const size_t len = bytes < cap ? bytes : cap;
-            pieces.push_back(Piece{d, s, len, (int)chunk});
+            pieces.push_back(Piece{d, s, len, (int)chunk, false});
             ++remaining[(size_t)chunk];
             d += len; s += len; bytes -= len;
+        }
+    }
+    // like stage(), for base codes that travel two per byte (staged calls only; src_off = offset of src in its arena,
+    // even): byte k of the arena's packed image on the device holds codes 2k and 2k+1
+    void stage_pack4(int64_t chunk, void *dst_packed, const void *src, size_t bytes)
+    {
+        char *d = (char *)dst_packed;
+        const char *s = (const char *)src;
+        while (bytes) {
+            const size_t len = bytes < Lane::PIECE ? bytes : Lane::PIECE;      // PIECE is even: only the last piece can be odd
+            pieces.push_back(Piece{d, s, len, (int)chunk, true});
+            ++remaining[(size_t)chunk];
+            d += len / 2; s += len; bytes -= len;
         }
     }
     void fail_hip(hipError_t e)
@@ -254,8 +306,9 @@ struct HostPipe {
             if (busy[slot]) e = hipEventSynchronize(L->wev[w][slot]);
             if (e == hipSuccess) {
                 RoctxRange range_("gbx:h2d piece (stage into pinned slab + DMA)");
-                memcpy(L->wslab[w][slot], p.src, p.len);
-                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.len, hipMemcpyHostToDevice, xfer);
+                if (p.pack) pack4((uint8_t *)L->wslab[w][slot], (const uint8_t *)p.src, p.len);
+                else memcpy(L->wslab[w][slot], p.src, p.len);
+                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.pack ? (p.len + 1) / 2 : p.len, hipMemcpyHostToDevice, xfer);
             }
             if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], xfer);
             if (e != hipSuccess) { fail_hip(e); return; }
