@@ -413,7 +413,10 @@ class PoaWork:
 
 
 WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork}
-_PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy")}
+_PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy"),
+                  "valu_insts": ("profiles/valu_insts.json", "valu_insts")}
+VALU_PEAK_FP32 = 7.86e13     # lane-ops/s the guide's vector FP32 rate implies (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)
+VALU_PEAK_INT32 = 3.93e13    # one wave64 integer instruction per SIMD every 4 cycles (16 lanes per cycle)
 
 
 def _committed(kind, kernel_name, default_size):
@@ -517,7 +520,25 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     default_size = not args.size and per_gpu_units is None and world == 1
     traffic, tsrc = _committed("traffic", name, default_size)
-    valu, vsrc = _committed("valu_busy", name, default_size)
+    valu_b, vsrc = _committed("valu_busy", name, default_size)
+    valu = None
+    vi, visrc = _committed("valu_insts", name, default_size)
+    if vi and k_units:
+        # VALU issue of the dominant kernel: committed SQ_INSTS_VALU per launch x 64 lanes over the units it processes and
+        # over its live duration in this run; bsw / phmm / chain are bound by this, not by HBM
+        lane_ops = vi * 64.0
+        valu = {"lane_ops_per_unit": lane_ops / k_units, "lane_ops_per_s": lane_ops / (k_ms * 1e-3),
+                "frac_of_7.86e13": lane_ops / (k_ms * 1e-3) / VALU_PEAK_FP32,
+                "frac_of_int32_issue_3.93e13": lane_ops / (k_ms * 1e-3) / VALU_PEAK_INT32, "insts_source": visrc}
+        if kind == "bsw":
+            allk = json.load(open(os.path.join(ROOT, "profiles/valu_insts.json")))["valu_insts"]
+            tot = 64.0 * sum(v for kk, v in allk.items() if kk.startswith("bsw_"))
+            valu["job_lane_ops_per_nominal_cell"] = tot / work.units
+            # the class kernels overlap on four streams, so the job-level rate is the meaningful one: every bsw kernel's
+            # lane operations over the step time
+            valu["job_lane_ops_per_s"] = tot / (dt_max / steps)
+            valu["job_frac_of_7.86e13"] = valu["job_lane_ops_per_s"] / VALU_PEAK_FP32
+            valu["job_frac_of_int32_issue_3.93e13"] = valu["job_lane_ops_per_s"] / VALU_PEAK_INT32
     cfg = {"workload": label or work.workload, "mode": args.mode if world > 1 else "single",
            "parallelism": ("units sharded over %d rank(s) in contiguous cost-balanced ranges, no data-path collective; "
                            % world) + ("rank 0 scatters packed shards / gathers outputs over RCCL p2p"
@@ -530,7 +551,7 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         "vs_baseline": None, "dtype": work.dtype, "data": "synthetic", "config": cfg,
         "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                     "valu_busy": valu, "valu_busy_source": vsrc, "kernel_ms": k_ms,
+                     "valu_busy": valu_b, "valu_busy_source": vsrc, "valu": valu, "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
         "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},

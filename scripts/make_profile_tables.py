@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turns the per-kernel counter means of scripts/pmc_summary.py (gpurun_out/<tag>_<k>_pmc.json, collected with
+scripts/pmc.sh: one rocprofv3 --pmc pass per counter group, default 'large' sizes) into the tables bench.py reads:
+
+  profiles/hbm_traffic.json   bytes per launch = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 where the kernel's reads
+                              are wide coalesced vector loads (poa, phmm stream, chain ring refills), x 1 otherwise:
+                              /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are KB; on gfx950
+                              FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads, WRITE_SIZE is exact.
+                              Both the raw and the corrected figures are kept.
+  profiles/valu_busy.json     SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+  profiles/valu_insts.json    SQ_INSTS_VALU per launch (wave instructions; x 64 = lane operations)
+
+usage: make_profile_tables.py <tag>      e.g. r02e
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+WIDE_READS = ("poa_window", "phmm_stream", "phmm_f32", "phmm_f64")      # kernels whose reads are 16-byte-per-lane vectors
+
+
+def stage_name(kname):
+    """kernel symbol -> the Stage name gbx_profile_end reports (csrc/*.hip)."""
+    m = re.match(r"bsw_rows_kernel<(\d+), (\d+), \w+>", kname)
+    if m:
+        return "bsw_rows_%sx%s" % (m.group(1), m.group(2))
+    m = re.match(r"phmm_stream_kernel<(\d+)>", kname)
+    if m:
+        return "phmm_stream_rpl" + m.group(1)
+    m = re.match(r"phmm_f32_kernel<(\d+)>", kname)
+    if m:
+        return "phmm_f32_rpl" + m.group(1)
+    return {"poa_kernel": "poa_window", "chain_kernel": "chain_dp", "chain_st_kernel": "chain_st", "bsw_lds_kernel": "bsw_lds",
+            "bsw_classify_kernel": "bsw_classify", "phmm_f64_kernel<4>": "phmm_f64_redo", "bsw_unpack4_kernel": "bsw_unpack4"}.get(kname, kname)
+
+
+traffic, busy, insts = {}, {}, {}
+for k in ("bsw", "chain", "phmm", "poa"):
+    path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
+    if not os.path.exists(path):
+        continue
+    for kname, v in json.load(open(path)).items():
+        if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_")):
+            continue
+        name = stage_name(kname)
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            f, w = v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
+            wide = name.startswith(WIDE_READS)
+            traffic[name] = {"fetch_raw": int(f), "write": int(w), "fetch_factor": 2 if wide else 1, "bytes": int(f * (2 if wide else 1) + w)}
+        if "valu_busy" in v:
+            busy[name] = v["valu_busy"]
+        if "SQ_INSTS_VALU" in v:
+            insts[name] = int(v["SQ_INSTS_VALU"])
+note = ("rocprofv3 --pmc, separate passes per counter group (scripts/pmc.sh), default 'large' sizes, tag %s; units and the gfx950 "
+        "FETCH_SIZE correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (see scripts/make_profile_tables.py)" % tag)
+json.dump({"note": note, "bytes_per_launch": {k: v["bytes"] for k, v in traffic.items()}, "detail": traffic},
+          open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+json.dump({"note": "fraction of SIMD cycles in which the VALU issues; " + note, "valu_busy": busy},
+          open(os.path.join(ROOT, "profiles", "valu_busy.json"), "w"), indent=1)
+json.dump({"note": "SQ_INSTS_VALU per launch (wave-level instructions, x 64 lanes = lane operations); " + note, "valu_insts": insts},
+          open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
+print("kernels: traffic %d, valu_busy %d, valu_insts %d" % (len(traffic), len(busy), len(insts)))
