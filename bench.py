@@ -395,7 +395,9 @@ class PoaWork:
         self.extra["dp_cells_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        return int(self.units * 13), self.units             # 3 x 2 B written (H, F, O) + 3 x 2 B x ~1.2 predecessor rows read per cell
+        # per cell: 4 B written (H int16 + one byte each of H-F and H-O) + 4 B x ~1.2 predecessor rows read = 8.8 B
+        # (measured, profiles/hbm_traffic.json: 747 GB per 6000-window launch = 8.4 B/cell)
+        return int(self.units * 8.8), self.units
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
