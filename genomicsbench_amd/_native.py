@@ -111,6 +111,13 @@ def _declare(L):
         L.gbx_phmm_workspace_bytes.restype = sz
         L.gbx_phmm_forward_host.argtypes = [i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, vp, vp]
         L.gbx_phmm_forward_device.argtypes = [i64, vp, vp, i64] + [vp] * 10 + [C.c_int32, vp, vp, sz, vp]
+    if hasattr(L, "gbx_abea_align_host"):
+        L.gbx_abea_plan_host.argtypes = [i64, vp, vp, vp, vp, vp]
+        L.gbx_abea_workspace_bytes.argtypes = [i64, i64, i64]
+        L.gbx_abea_workspace_bytes.restype = sz
+        L.gbx_abea_align_host.argtypes = [i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+        L.gbx_abea_align_device.argtypes = [i64] + [vp] * 11 + [i64, i64, vp, vp, vp, sz, vp]
+        L.gbx_abea_cells.argtypes = [vp, C.POINTER(C.c_int64), vp]
     if hasattr(L, "gbx_chain_host"):
         L.gbx_chain_workspace_bytes.argtypes = [i64, i64]
         L.gbx_chain_workspace_bytes.restype = sz

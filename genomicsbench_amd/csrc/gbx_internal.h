@@ -89,6 +89,15 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
                 double *out, void *d_work, size_t work_bytes, hipStream_t s, int64_t stream_syms = -1);
 
+// ---- abea (abea_kernels.hip)
+size_t abea_workspace_bytes(int64_t n_reads, int64_t n_kmers_total, int64_t n_bands_total);
+int abea_read_cells(const void *d_work, int64_t *cells, hipStream_t s);
+int abea_launch(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_len, const char *d_seq,
+                const int64_t *d_event_off, const float *d_event_mean, const gbx_abea_model *d_models,
+                const float *d_scale, const float *d_shift, const int64_t *d_band_off, const int32_t *d_order,
+                const double *d_lp, int64_t n_kmers_total, int64_t n_bands_total,
+                gbx_abea_pair *d_out, int32_t *d_n_pairs, void *d_work, size_t work_bytes, hipStream_t s);
+
 // ---- poa (poa_kernels.hip)
 size_t poa_slot_bytes(int ncap, int deg, int lmax);
 int poa_waves_per_cu(int ncap);

@@ -35,6 +35,11 @@ def _L():
         _lib.gbx_gen_phmm_fill_many.argtypes = [u64, i64, i64] + [vp] * 10
         _lib.gbx_gen_poa_counts_many.argtypes = [u64, i64, i64, vp]
         _lib.gbx_gen_poa_many.argtypes = [u64, i64, i64, C.c_int, vp, vp, vp, vp]
+        _lib.gbx_gen_abea_model.argtypes = [u64, vp, vp]
+        _lib.gbx_gen_abea_counts_many.argtypes = [u64, i64, i64, vp, vp]
+        _lib.gbx_gen_abea_fill_many.argtypes = [u64, i64, i64] + [vp] * 8
+        for f in ("abea_model", "abea_counts_many", "abea_fill_many"):
+            getattr(_lib, "gbx_gen_" + f).restype = None
         for f in ("chain_counts_many", "chain_fill_many", "phmm_counts_many", "phmm_lengths_many", "phmm_fill_many",
                   "poa_counts_many", "poa_many"):
             getattr(_lib, "gbx_gen_" + f).restype = None
@@ -121,3 +126,21 @@ def gen_poa(n_windows, seed, first=0):
     arena = np.zeros(int(off[-1]) + 8, dtype=np.uint8)
     L.gbx_gen_poa_many(seed, first, n_windows, 2, _p(wf), _p(lens), _p(off), _p(arena))
     return PoaWindowSet(wf, off[:-1].copy(), lens, arena)
+
+
+def gen_abea(n_reads, seed, first=0):
+    """abea 'large' = (4096 reads, seed 5001).  Returns an AbeaReadSet (synthetic pore model, reads, events, scalings)."""
+    from ..abea import AbeaReadSet, make_model
+    L = _L()
+    lm, ls = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
+    L.gbx_gen_abea_model(seed, _p(lm), _p(ls))
+    seq_len = np.zeros(n_reads, dtype=np.int32)
+    n_ev = np.zeros(n_reads, dtype=np.int64)
+    L.gbx_gen_abea_counts_many(seed, first, n_reads, _p(seq_len), _p(n_ev))
+    seq_off = np.zeros(n_reads + 1, dtype=np.int64); np.cumsum(seq_len, out=seq_off[1:])
+    event_off = np.zeros(n_reads + 1, dtype=np.int64); np.cumsum(n_ev, out=event_off[1:])
+    seq = np.zeros(int(seq_off[-1]) + 8, dtype=np.uint8)
+    ev = np.zeros(int(event_off[-1]) + 4, dtype=np.float32)
+    scale, shift = np.zeros(n_reads, np.float32), np.zeros(n_reads, np.float32)
+    L.gbx_gen_abea_fill_many(seed, first, n_reads, _p(lm), _p(ls), _p(seq_off), _p(event_off), _p(seq), _p(ev), _p(scale), _p(shift))
+    return AbeaReadSet(seq_off[:-1].copy(), seq_len, seq, event_off, ev[:int(event_off[-1])], scale, shift, make_model(lm, ls))

@@ -302,3 +302,71 @@ void gbx_gen_chain_counts_many(uint64_t seed, int64_t first, int64_t n_calls, in
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < n_calls; ++c) counts[c] = gbx_gen_chain_count(seed, first + c);
 }
+
+/* ------------------------------------------------------------------ abea
+ * Synthetic pore model and reads with events, in the shapes f5c's align() consumes (R/benchmarks/abea/src/f5c.h:
+ * model_t :122, event_t :104, scalings_t :139).  The real r9.4 6-mer model is a table in the reference's source tree
+ * and real signal needs fast5 files; neither is used: the algorithm only asks for 4096 (mean, stdv) levels.
+ * model state s: level_mean ~ U[65,125] pA, level_stdv ~ U[1.2,3.2].
+ * read r: length ~ LogNormal(median 6000, sigma 0.6) clipped to [400, 40000] bases ~U{ACGT}; per k-mer the number of
+ * events is 0 (skip, 3 %), else 1 + Geometric(0.45) (stays); event mean = scale*level_mean + shift + N(0, level_stdv);
+ * scalings: shift ~ N(0, 4), scale ~ U[0.94, 1.06] (what estimate_scalings would have found: the generator hands
+ * them over exact).  mode 0: (seq_len, n_events); mode 1: fill.
+ */
+void gbx_gen_abea_model(uint64_t seed, float *level_mean, float *level_stdv)
+{
+    rng_t r;
+    rng_seed(&r, seed, 0xabeaULL);
+    for (int s = 0; s < 4096; ++s) {
+        level_mean[s] = (float)(65.0 + 60.0 * rng_unif(&r));
+        level_stdv[s] = (float)(1.2 + 2.0 * rng_unif(&r));
+    }
+}
+
+static void abea_read(uint64_t seed, int64_t read, int mode, const float *level_mean, const float *level_stdv,
+                      int32_t *seq_len, int64_t *n_events, char *seq, float *ev, float *scale, float *shift)
+{
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)read * 2 + 1);
+    double v = 6000.0 * exp(0.6 * rng_norm(&r));
+    if (v < 400) v = 400;
+    if (v > 40000) v = 40000;
+    const int len = (int)v;
+    const float sc = (float)(0.94 + 0.12 * rng_unif(&r)), sh = (float)(4.0 * rng_norm(&r));
+    *seq_len = len;
+    if (mode == 1) { *scale = sc; *shift = sh; }
+    /* the sequence and the event counts come from one stream so that both modes agree */
+    uint32_t rank = 0;
+    int64_t ne = 0;
+    for (int i = 0; i < len; ++i) {
+        const uint32_t b = rng_below(&r, 4);
+        if (mode == 1) seq[i] = "ACGT"[b];
+        rank = ((rank << 2) | b) & 4095u;                 /* k-mer ending at base i: first base is the most significant */
+        if (i < 5) continue;
+        int cnt = 0;
+        if (rng_below(&r, 100) >= 3) { cnt = 1; while (rng_unif(&r) < 0.45 && cnt < 12) ++cnt; }
+        for (int c = 0; c < cnt; ++c) {
+            const double noise = rng_norm(&r);
+            if (mode == 1) ev[ne] = (float)((double)sc * level_mean[rank] + (double)sh + noise * level_stdv[rank]);
+            ++ne;
+        }
+    }
+    if (ne == 0) { if (mode == 1) ev[0] = sc * level_mean[rank] + sh; ne = 1; }
+    *n_events = ne;
+}
+
+void gbx_gen_abea_counts_many(uint64_t seed, int64_t first, int64_t n_reads, int32_t *seq_len, int64_t *n_events)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t k = 0; k < n_reads; ++k) abea_read(seed, first + k, 0, 0, 0, seq_len + k, n_events + k, 0, 0, 0, 0);
+}
+
+void gbx_gen_abea_fill_many(uint64_t seed, int64_t first, int64_t n_reads, const float *level_mean, const float *level_stdv,
+                            const int64_t *seq_off, const int64_t *event_off, char *seq, float *ev, float *scale, float *shift)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t k = 0; k < n_reads; ++k) {
+        int32_t l; int64_t ne;
+        abea_read(seed, first + k, 1, level_mean, level_stdv, &l, &ne, seq + seq_off[k], ev + event_off[k], scale + k, shift + k);
+    }
+}

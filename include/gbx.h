@@ -272,6 +272,58 @@ int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, 
                              const char *d_arena, char *d_cons, int32_t *d_cons_len, int32_t *d_status,
                              int64_t cons_stride, void *d_work, size_t work_bytes, void *stream);
 
+/* -------------------------------------------------------------------- abea
+ * Adaptive banded event alignment of nanopore events to the k-mers of a read's basecalled sequence (f5c /
+ * nanopolish; SURVEY §8f rank 4: the suite's other banded DP).
+ * Replaces  int32_t align(AlignedPair *out, char *sequence, int32_t sequence_len, event_table events,
+ *                         model_t *models, scalings_t scaling, float sample_rate)
+ *           R/benchmarks/abea/src/align.c:169-548, called per read by align_single, f5c.c:1344-1349
+ *           (the suite's CUDA path for the same step: align.cu:140-560 - not a template for this code).
+ * Semantics are those of the CPU function, bit for bit: float band scores and emissions, double transition
+ * penalties (every candidate is a double sum rounded to float), Suzuki's adaptive band placement, the traceback,
+ * the double emission sum and the three QC rules that empty an alignment.  `sample_rate` is unused by align()
+ * (:108-126) and has no counterpart here.  Of an event only its mean is read (:125).
+ */
+#define GBX_ABEA_BANDWIDTH 100     /* ALN_BANDWIDTH, f5c.h:28 */
+#define GBX_ABEA_KMER      6       /* KMER_SIZE, f5c.h:24 */
+#define GBX_ABEA_NMODEL    4096    /* 4^KMER_SIZE model states */
+
+typedef struct gbx_abea_model {   /* model_t with CACHED_LOG, f5c.h:122-136 */
+    float level_mean, level_stdv, level_log_stdv;     /* level_log_stdv = log(level_stdv), model.c:53 */
+} gbx_abea_model;
+typedef struct gbx_abea_event {   /* event_t, f5c.h:104-111 (24 bytes) */
+    uint64_t start;
+    float length, mean, stdv;
+} gbx_abea_event;
+typedef struct gbx_abea_pair {    /* AlignedPair, f5c.h:163-166 */
+    int32_t ref_pos, read_pos;    /* k-mer index, event index */
+} gbx_abea_pair;
+
+/* Read r: bases seq_arena[seq_off[r] .. +seq_len[r]) (A/C/G/T; anything else ranks as A, align.c:10-24), events
+ * [event_off[r], event_off[r+1]) of the concatenated event array, scalings scale[r], shift[r] (scalings_t, f5c.h:139-155).
+ * Output: pairs of read r at out + 2*event_off[r] (the reference sizes the array 2 x n_events, f5c.c), n_pairs[r] of
+ * them in ascending order, 0 when a QC rule failed (align.c:530-541).  seq_len >= KMER and >= 1 event per read. */
+int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *seq_len, const char *seq_arena,
+                        int64_t seq_bytes, const int64_t *event_off, const gbx_abea_event *events,
+                        const gbx_abea_model *models, const float *scale, const float *shift,
+                        gbx_abea_pair *out, int32_t *n_pairs);
+
+/* Device path.  gbx_abea_plan_host computes from host metadata the per-read offsets into the band workspace
+ * (band_off[n_reads+1], in bands), the processing order (longest first) and the two read-dependent transition
+ * penalties, which are double logarithms (align.c:195-204) and are taken with the host C library so that they are the
+ * reference's bits; the device entry takes the compact float array of event means.  n_kmers_total = sum of
+ * seq_len - KMER + 1, n_bands_total = band_off[n_reads]. */
+int gbx_abea_plan_host(int64_t n_reads, const int32_t *seq_len, const int64_t *event_off,
+                       int64_t *band_off, int32_t *order, double *lp /* [n_reads][2]: lp_stay, lp_step, align.c:195-204 */);
+size_t gbx_abea_workspace_bytes(int64_t n_reads, int64_t n_kmers_total, int64_t n_bands_total);
+int gbx_abea_align_device(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_len, const char *d_seq_arena,
+                          const int64_t *d_event_off, const float *d_event_mean, const gbx_abea_model *d_models,
+                          const float *d_scale, const float *d_shift, const int64_t *d_band_off, const int32_t *d_order,
+                          const double *d_lp, int64_t n_kmers_total, int64_t n_bands_total,
+                          gbx_abea_pair *d_out, int32_t *d_n_pairs, void *d_work, size_t work_bytes, void *stream);
+/* DP cells filled by the last gbx_abea_align_device call on this workspace (the reference's `fills`, align.c:280,401). */
+int gbx_abea_cells(const void *d_work, int64_t *cells, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,15 @@ void oracle_poa_consensus(const gbx_poa_params *P, int64_t n_windows, const int6
                           const int64_t *seq_off, const int32_t *seq_len, const char *arena,
                           char *cons, int32_t *cons_len, int64_t cons_stride, int nthreads, int64_t *cells);
 
+/* abea: adaptive banded event alignment, R/benchmarks/abea/src/align.c:169-548 (parity UNPINNED by a compiled
+ * reference: f5c.h needs htslib / HDF5 headers; the restated source is in the tree, see abea_oracle.c) */
+int32_t oracle_abea_align_one(const char *sequence, int32_t sequence_len, const float *event_mean, int64_t n_events,
+                              const gbx_abea_model *models, float scale, float shift, gbx_abea_pair *out, int64_t *cells);
+void oracle_abea_align(int64_t n_reads, const int64_t *seq_off, const int32_t *seq_len, const char *seq_arena,
+                       const int64_t *event_off, const float *event_mean, const gbx_abea_model *models,
+                       const float *scale, const float *shift, gbx_abea_pair *out, int32_t *n_pairs,
+                       int nthreads, int64_t *cells);
+
 #ifdef __cplusplus
 }
 #endif
