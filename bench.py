@@ -414,7 +414,92 @@ class PoaWork:
                             % (sub.n_windows, "identical to" if same else "DIFFER from")}
 
 
-WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork}
+class AbeaWork:
+    """SURVEY 8f rank 4, widened in round 2: adaptive banded event alignment (R/benchmarks/abea/src/align.c:169-548)."""
+    metric, unit, dtype = "abea_large_gcups", "GCUPS", "f32+f64"
+    large, seed = 4096, 5001
+
+    def __init__(self, args):
+        self.n = args.size or self.large
+        self.workload = ("abea large: %d synthetic nanopore reads per GPU (seed 5001: synthetic 6-mer pore model, read lengths "
+                         "LogNormal(median 6000), 1.76 events per k-mer), inputs resident in HBM, cell = filled band cell" % self.n)
+
+    def generate(self, first, n_units):
+        from genomicsbench_amd.datagen import gen_abea
+        return gen_abea(n_units, self.seed, first=first)
+
+    def shards(self, full, parts):
+        return S.abea_shards(full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.abea_to_arrays(sh))
+    n_units = staticmethod(lambda sh: sh.n_reads)
+
+    def attach(self, tensors, dev, host_shard):
+        from genomicsbench_amd.abea import DeviceAbeaReadSet
+        self.d = DeviceAbeaReadSet.from_tensors(tensors, dev)
+        self.rs = host_shard
+        self.units = None                                   # filled band cells: device counter
+        self.extra = {"reads_this_gpu": self.d.n_reads, "events_this_gpu": self.d.n_events_total, "bands_this_gpu": self.d.n_bands_total,
+                      "workspace_gb": round(self.d.work_bytes / 1e9, 2)}
+
+    def run(self, stream):
+        self.d.run(stream)
+
+    def finish(self, stream):
+        self.units = float(self.d.cells(stream))
+        self.extra["filled_cells_this_gpu"] = int(self.units)
+
+    def output_tensor(self):
+        """Fixed-stride records are not possible (pairs per read vary): the flat pair array followed by the counts."""
+        import torch
+        d = self.d
+        return torch.cat([d.out.reshape(-1), d.n_pairs[:d.n_reads]])
+
+    def check_gathered(self, full, ranges, parts, sample):
+        from oracle import oracle_py as O
+        bad = checked = 0
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                sub_all = full.take(lo, hi)
+                g = got.cpu().numpy()
+                n_ev = int(sub_all.event_off[-1])
+                pairs = g[:4 * max(n_ev, 1)].reshape(-1, 2)
+                npairs = g[4 * max(n_ev, 1):]
+                sub = sub_all.take(0, m)
+                wo, wn = O.abea_oracle(sub, min(os.cpu_count() or 1, 32))
+                ok = np.array_equal(npairs[:m], wn)
+                for r in range(m):
+                    a = 2 * int(sub.event_off[r])
+                    ok = ok and np.array_equal(pairs[a:a + int(wn[r])], np.stack([wo["ref_pos"][a:a + int(wn[r])], wo["read_pos"][a:a + int(wn[r])]], axis=1))
+                bad += int(not ok)
+                checked += m
+        return "%d reads (front of every shard) vs oracle, aligned pairs and QC verdicts: %s" % (checked, "identical" if not bad else "DIFFER")
+
+    def roofline_bytes(self, kernel):
+        # per band: 100 cells; algorithmic traffic per band = 64 B of back-pointers + 4 B corner written, read once more by the
+        # traceback along its path; per read the bases, 4 B per event and 8 B per aligned pair: ~0.75 B per cell
+        d = self.d
+        return int(d.n_bands_total * 68 + d.n_events_total * 4 + d.n_kmers_total + d.n_events_total * 12), self.units
+
+    def cpu_baseline(self, max_units):
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        sub = self.rs.take(0, min(self.rs.n_reads, max_units or 256))
+        t0 = time.perf_counter()
+        wo, wn, cells = O.abea_oracle(sub, cores, True)
+        dt = time.perf_counter() - t0
+        go, gn = self.d.results()
+        same = np.array_equal(gn[:sub.n_reads], wn) and all(
+            np.array_equal(go[2 * int(sub.event_off[r]):2 * int(sub.event_off[r]) + int(wn[r])],
+                           wo[2 * int(sub.event_off[r]):2 * int(sub.event_off[r]) + int(wn[r])]) for r in range(sub.n_reads))
+        return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+                "sample": "first %d reads (%d filled cells), oracle/abea_oracle.c restating the CPU align(), OpenMP, %.2f s "
+                          "(the reference translation unit needs htslib / HDF5 headers: no reference build)" % (sub.n_reads, cells, dt),
+                "verified": "device pairs and QC verdicts of these %d reads %s the CPU run's" % (sub.n_reads, "identical to" if same else "DIFFER from")}
+
+
+WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork, "abea": AbeaWork}
 _PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy"),
                   "valu_insts": ("profiles/valu_insts.json", "valu_insts")}
 VALU_PEAK_FP32 = 7.86e13     # lane-ops/s the guide's vector FP32 rate implies (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)
@@ -562,7 +647,7 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     if args.mode != "local":
         line["dataset_gen_s"] = gen_s
         line["gather_verified"] = work.check_gathered(full, ranges, parts, args.verify_units or
-                                                      {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8}[kind])
+                                                      {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8}[kind])
         line["shard_units"] = [hi - lo for lo, hi in ranges]
     if not args.no_cpu:
         line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
@@ -621,7 +706,7 @@ def main():
     else:
         line = run_kernel("bsw", args, ctx, args.steps, args.warmup)
         others = {}
-        for kind in ("chain", "phmm", "poa"):
+        for kind in ("chain", "phmm", "poa", "abea"):
             torch.cuda.empty_cache()
             sub = argparse.Namespace(**vars(args))
             sub.size, sub.cpu_units = 0, 0                   # --size / --cpu-units speak about the headline kernel

@@ -289,3 +289,35 @@ def poa_to_arrays(ws):
 def poa_from_arrays(d):
     from .poa import PoaWindowSet
     return PoaWindowSet(*(np.asarray(d[k]) for k in ("win_first_seq", "seq_off", "seq_len", "arena")))
+
+
+def abea_cost(rs):
+    """Bands of a read = events + k-mers + 2; every band is 100 cells (R/benchmarks/abea/src/align.c:209-211)."""
+    return rs.n_bands
+
+
+def abea_shards(rs, parts, ranges=None):
+    """`parts` AbeaReadSet objects over contiguous read ranges balanced by bands (reads are independent, f5c.c:1350-1370)."""
+    from .abea import AbeaReadSet
+    out = []
+    for lo, hi in (ranges or split_by_cost(abea_cost(rs), parts)):
+        a, b = int(rs.event_off[lo]), int(rs.event_off[hi])
+        arena, off = _cut_arena(rs.seq_arena, rs.seq_off[lo:hi], rs.seq_len[lo:hi])
+        out.append(AbeaReadSet(off, rs.seq_len[lo:hi], arena, rs.event_off[lo:hi + 1] - a, rs.event_mean[a:b],
+                               rs.scale[lo:hi], rs.shift[lo:hi], rs.model))
+    return out
+
+
+def abea_to_arrays(rs):
+    return dict(seq_off=rs.seq_off, seq_len=rs.seq_len, seq_arena=rs.seq_arena, event_off=rs.event_off,
+                event_mean=np.concatenate([rs.event_mean, np.zeros(4, np.float32)]), scale=rs.scale, shift=rs.shift,
+                model=np.ascontiguousarray(rs.model).view(np.uint8))
+
+
+def abea_from_arrays(d):
+    from .abea import MODEL_DTYPE, AbeaReadSet
+    eo = np.asarray(d["event_off"])
+    return AbeaReadSet(np.asarray(d["seq_off"]), np.asarray(d["seq_len"]), np.asarray(d["seq_arena"]), eo,
+                       np.asarray(d["event_mean"])[:int(eo[-1] - eo[0])] if len(eo) else np.zeros(0, np.float32),
+                       np.asarray(d["scale"]), np.asarray(d["shift"]),
+                       np.ascontiguousarray(d["model"]).view(np.uint8).view(MODEL_DTYPE))

@@ -84,3 +84,20 @@ def test_poa_large_all_windows():
     got, want = d.results(), O.poa_oracle(p, ws, CORES)
     bad = [w for w in range(ws.n_windows) if got[w] != want[w]]
     assert not bad, "%d of %d windows differ, first %d" % (len(bad), ws.n_windows, bad[0])
+
+
+def test_abea_large_all_reads():
+    import torch
+    from genomicsbench_amd.abea import DeviceAbeaReadSet
+    from genomicsbench_amd.datagen import gen_abea
+    from oracle import oracle_py as O
+    rs = gen_abea(4096, 5001)
+    d = DeviceAbeaReadSet(rs, torch.device("cuda:0"))
+    d.run(_stream())
+    torch.cuda.synchronize()
+    (go, gn), (wo, wn, cells) = d.results(), O.abea_oracle(rs, CORES, True)
+    assert np.array_equal(gn, wn), "QC verdicts / pair counts differ for %d reads" % int((gn != wn).sum())
+    assert d.cells(_stream()) == cells
+    for r in range(rs.n_reads):
+        a = 2 * int(rs.event_off[r])
+        assert np.array_equal(go[a:a + int(wn[r])], wo[a:a + int(wn[r])]), "read %d" % r

@@ -189,6 +189,27 @@ def _worker(rank, world, port, tmp, kernel):
         units = len(bs.n_reads)
         if rank == 0:
             ok = np.array_equal(torch.cat(parts).numpy(), O.phmm_oracle(full, 2))
+    elif kernel == "abea":
+        from genomicsbench_amd.datagen import gen_abea
+        if rank == 0:
+            full = gen_abea(8, 5001)
+            per_rank = [S.abea_to_arrays(s) for s in S.abea_shards(full, world)]
+        mine, _ = S.scatter_arrays(per_rank)
+        rs = S.abea_from_arrays(np_of(mine))
+        out, n = O.abea_oracle(rs, 2)
+        flat = np.concatenate([out["ref_pos"], out["read_pos"], n]).astype(np.int32)      # pairs then counts, one message
+        parts = S.gather_array(torch.from_numpy(flat))
+        units = rs.n_reads
+        if rank == 0:
+            wo, wn = O.abea_oracle(full, 2)
+            want_pairs = full.split_pairs(wo, wn)
+            got_pairs, k = [], 0
+            for p, sh in zip(parts, S.abea_shards(full, world)):
+                p = p.numpy()
+                ne = 2 * max(int(sh.event_off[-1]), 1)
+                o = np.zeros(ne, dtype=wo.dtype); o["ref_pos"] = p[:ne]; o["read_pos"] = p[ne:2 * ne]
+                got_pairs += sh.split_pairs(o, p[2 * ne:])
+            ok = len(got_pairs) == len(want_pairs) and all(np.array_equal(g, w) for g, w in zip(got_pairs, want_pairs))
     else:
         from genomicsbench_amd.datagen import gen_poa
         from genomicsbench_amd.poa import make_params
@@ -218,10 +239,10 @@ def _worker(rank, world, port, tmp, kernel):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,total", [("bsw", 3000), ("chain", 24), ("phmm", 24), ("poa", 10)])
+@pytest.mark.parametrize("kernel,total", [("bsw", 3000), ("chain", 24), ("phmm", 24), ("poa", 10), ("abea", 8)])
 def test_scatter_compute_gather_world2(tmp_path, kernel, total):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000) + {"bsw": 0, "chain": 1, "phmm": 2, "poa": 3}[kernel]
+    port = 29500 + (os.getpid() % 2000) + {"bsw": 0, "chain": 1, "phmm": 2, "poa": 3, "abea": 4}[kernel]
     mp.spawn(_worker, args=(2, port, str(tmp_path), kernel), nprocs=2, join=True)
     ok = np.load(str(tmp_path / "ok.npy"))
     assert ok[0] == 1 and ok[1] == 2 and 0 < ok[2] < total

@@ -108,3 +108,22 @@ def test_poa_split_compute_concat(parts):
         torch.cuda.synchronize()
         got += d.results()
     assert got == want
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_abea_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.abea import DeviceAbeaReadSet
+    from genomicsbench_amd.datagen import gen_abea
+    from oracle import oracle_py as O
+    dev = torch.device("cuda:0")
+    full = gen_abea(36, 5001, first=50)
+    want = full.split_pairs(*O.abea_oracle(full, 8))
+    got = []
+    for sh in S.abea_shards(full, parts):
+        d = DeviceAbeaReadSet.from_tensors(_to_device(S.abea_to_arrays(sh), dev), dev)
+        d.run(_sync_stream())
+        torch.cuda.synchronize()
+        got += sh.split_pairs(*d.results())
+    assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
