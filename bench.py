@@ -417,7 +417,7 @@ class PoaWork:
 class AbeaWork:
     """SURVEY 8f rank 4, widened in round 2: adaptive banded event alignment (R/benchmarks/abea/src/align.c:169-548)."""
     metric, unit, dtype = "abea_large_gcups", "GCUPS", "f32+f64"
-    large, seed = 4096, 5001
+    large, seed = 10000, 5001                           # the reference's large input is 10000 reads (R/scripts/run-gpu.sh:45)
 
     def __init__(self, args):
         self.n = args.size or self.large
@@ -477,10 +477,11 @@ class AbeaWork:
         return "%d reads (front of every shard) vs oracle, aligned pairs and QC verdicts: %s" % (checked, "identical" if not bad else "DIFFER")
 
     def roofline_bytes(self, kernel):
-        # per band: 100 cells; algorithmic traffic per band = 64 B of back-pointers + 4 B corner written, read once more by the
-        # traceback along its path; per read the bases, 4 B per event and 8 B per aligned pair: ~0.75 B per cell
+        # per band (100 cells): 64 B of back-pointers written and read once more by the traceback, + 1 B of move records
+        # written and read; per k-mer the base and 16 B of scaled model parameters written and read; per event 4 B read
+        # twice (range check, band loop); 8 B per aligned pair (~1 per event): ~1.6 B per cell
         d = self.d
-        return int(d.n_bands_total * 68 + d.n_events_total * 4 + d.n_kmers_total + d.n_events_total * 12), self.units
+        return int(d.n_bands_total * 130 + d.n_kmers_total * 33 + d.n_events_total * 16), self.units
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O

@@ -129,7 +129,7 @@ def gen_poa(n_windows, seed, first=0):
 
 
 def gen_abea(n_reads, seed, first=0):
-    """abea 'large' = (4096 reads, seed 5001).  Returns an AbeaReadSet (synthetic pore model, reads, events, scalings)."""
+    """abea 'large' = (10000 reads, seed 5001), the read count of the reference's large input.  Returns an AbeaReadSet (synthetic pore model, reads, events, scalings)."""
     from ..abea import AbeaReadSet, make_model
     L = _L()
     lm, ls = np.zeros(4096, np.float32), np.zeros(4096, np.float32)

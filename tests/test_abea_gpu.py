@@ -83,3 +83,17 @@ def test_shard_equivalence():
     got = [x for p, sub in zip(parts, (rs.take(0, 11), rs.take(11, 30))) for x in sub.split_pairs(*p)]
     for g, w in zip(got, rs.split_pairs(*whole)):
         assert np.array_equal(g, w)
+
+
+def test_reads_outside_the_fast_division_range():
+    """A read whose events / model leave [2^-40, 2^40] (or hold a zero stdv-free extreme) takes the kernel's plain
+    IEEE-division path; reads next to it keep the hoisted-reciprocal path.  Both must equal the oracle bit for bit."""
+    rs = gen_abea(12, 77)
+    ev = rs.event_mean.copy()
+    ev[int(rs.event_off[3]) + 10] = np.float32(1e-30)       # tiny but non-zero: v_div_scale territory for a / stdv
+    ev[int(rs.event_off[5]) + 200] = np.float32(3e13)       # beyond 2^40
+    ev[int(rs.event_off[8]) + 7] = np.float32(0.0)          # zero is inside the fast range
+    scale = np.asarray(rs.scale, dtype=np.float32).copy()
+    scale[10] = np.float32(1e-14)                           # scaled means of read 10 become ~1e-12 < 2^-40
+    rs2 = AbeaReadSet(rs.seq_off, rs.seq_len, rs.seq_arena, rs.event_off, ev, scale, rs.shift, rs.model)
+    assert_same(rs2, align_host(rs2), O.abea_oracle(rs2, 8))
