@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats over a short bench run; prints per-kernel calls / mean / share.
-# Usage (GPU box): bash scripts/kstats.sh <bsw|chain|phmm|poa> [extra bench.py args]   -> gpurun_out/kstats_<kernel>.csv
+# Usage (GPU box): bash scripts/kstats.sh <bsw|chain|phmm|poa|abea> [extra bench.py args]   -> gpurun_out/kstats_<kernel>.csv
 k=$1; shift
 export TMPDIR=/tmp
 root=$PWD

@@ -10,7 +10,7 @@ scripts/pmc.sh: one rocprofv3 --pmc pass per counter group, default 'large' size
   profiles/valu_busy.json     SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
   profiles/valu_insts.json    SQ_INSTS_VALU per launch (wave instructions; x 64 = lane operations)
 
-usage: make_profile_tables.py <tag>      e.g. r02e
+usage: make_profile_tables.py <tag>      e.g. r02e      (kernels without a gpurun_out/<tag>_<k>_pmc.json keep their committed entries)
 """
 import json
 import os
@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-WIDE_READS = ("poa_window", "phmm_stream", "phmm_f32", "phmm_f64")      # kernels whose reads are 16-byte-per-lane vectors
+WIDE_READS = ("poa_window", "phmm_stream", "phmm_f32", "phmm_f64", "abea_align")      # kernels whose reads are 16-byte-per-lane vectors
 
 
 def stage_name(kname):
@@ -34,16 +34,24 @@ def stage_name(kname):
     if m:
         return "phmm_f32_rpl" + m.group(1)
     return {"poa_kernel": "poa_window", "chain_kernel": "chain_dp", "chain_st_kernel": "chain_st", "bsw_lds_kernel": "bsw_lds",
-            "bsw_classify_kernel": "bsw_classify", "phmm_f64_kernel<4>": "phmm_f64_redo", "bsw_unpack4_kernel": "bsw_unpack4"}.get(kname, kname)
+            "bsw_classify_kernel": "bsw_classify", "phmm_f64_kernel<4>": "phmm_f64_redo", "bsw_unpack4_kernel": "bsw_unpack4",
+            "abea_kernel": "abea_align"}.get(kname, kname)
 
 
-traffic, busy, insts = {}, {}, {}
-for k in ("bsw", "chain", "phmm", "poa"):
+def committed(name, key):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(key, {})
+    except (OSError, ValueError):
+        return {}
+
+
+traffic, busy, insts = committed("hbm_traffic.json", "detail"), committed("valu_busy.json", "valu_busy"), committed("valu_insts.json", "valu_insts")
+for k in ("bsw", "chain", "phmm", "poa", "abea"):
     path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
     if not os.path.exists(path):
         continue
     for kname, v in json.load(open(path)).items():
-        if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_")):
+        if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_")):
             continue
         name = stage_name(kname)
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:

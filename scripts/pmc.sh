@@ -1,6 +1,6 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass per argument group over a short bench run; prints per-kernel counter sums / launches.
-# Usage (GPU box): bash scripts/pmc.sh <bench kernel: bsw|chain|phmm|poa> "<CTR1 CTR2>" ["<CTR3 CTR4>" ...]
+# Usage (GPU box): bash scripts/pmc.sh <bench kernel: bsw|chain|phmm|poa|abea> "<CTR1 CTR2>" ["<CTR3 CTR4>" ...]
 # Counters go in their own passes (no tracing domains combined with --pmc).  Output: gpurun_out/pmc_<kernel>.json
 k=$1; shift
 export TMPDIR=/tmp
