@@ -1,10 +1,11 @@
 // san_main.cpp — CPU-only sanitizer run of the host-side code that has no GPU dependency:
-//   * oracle/*.c               (the four restatements, single- and multi-threaded entry points),
+//   * oracle/*.c               (the five restatements, single- and multi-threaded entry points),
 //   * tests/hostcheck/poa_hostcheck.cpp (the product's serial graph code, csrc/poa_graph.h, host build),
 //   * genomicsbench_amd/datagen/datagen.c (the generators that feed them).
 // Built by tests/sanitize/Makefile with -fsanitize=address,undefined and run by tests/test_sanitize_cpu.py;
 // exits 0 when every run completes and the oracle and the product's graph code agree.  TEST INFRASTRUCTURE.
 // GPU code is never sanitized this way (no GPU ASAN on this pool).
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,10 @@ void gbx_gen_phmm_fill_many(uint64_t seed, int64_t first, int64_t n_batches, con
 void gbx_gen_poa_counts_many(uint64_t seed, int64_t first, int64_t n_windows, int32_t *n_reads);
 void gbx_gen_poa_many(uint64_t seed, int64_t first, int64_t n_windows, int mode, const int64_t *wf, int32_t *seq_len,
                       const int64_t *seq_off, char *arena);
+void gbx_gen_abea_model(uint64_t seed, float *level_mean, float *level_stdv);
+void gbx_gen_abea_counts_many(uint64_t seed, int64_t first, int64_t n_reads, int32_t *seq_len, int64_t *n_events);
+void gbx_gen_abea_fill_many(uint64_t seed, int64_t first, int64_t n_reads, const float *level_mean, const float *level_stdv,
+                            const int64_t *seq_off, const int64_t *event_off, char *seq, float *ev, float *scale, float *shift);
 int hostcheck_poa_window(const gbx_poa_params *P, int n_seqs, const char *const *seqs, const int32_t *lens,
                          char *cons, int cons_cap, int ncap, int deg, int64_t *stats);
 }
@@ -147,12 +152,43 @@ static void run_poa()
     printf("poa: %lld windows, %lld cells\n", (long long)nw, (long long)cells);
 }
 
+static void run_abea()
+{
+    const int64_t n = 6;
+    std::vector<float> lm(4096), ls(4096);
+    gbx_gen_abea_model(5001, lm.data(), ls.data());
+    std::vector<gbx_abea_model> model(4096);
+    for (int k = 0; k < 4096; ++k) { model[k].level_mean = lm[k]; model[k].level_stdv = ls[k]; model[k].level_log_stdv = logf(ls[k]); }
+    std::vector<int32_t> sl(n);
+    std::vector<int64_t> ne(n), so(n + 1, 0), eo(n + 1, 0);
+    gbx_gen_abea_counts_many(5001, 0, n, sl.data(), ne.data());
+    for (int64_t r = 0; r < n; ++r) { so[r + 1] = so[r] + sl[r]; eo[r + 1] = eo[r] + ne[r]; }
+    std::vector<char> seq((size_t)so[n] + 8);
+    std::vector<float> ev((size_t)eo[n] + 4), sc(n), sh(n);
+    gbx_gen_abea_fill_many(5001, 0, n, lm.data(), ls.data(), so.data(), eo.data(), seq.data(), ev.data(), sc.data(), sh.data());
+    std::vector<gbx_abea_pair> o1((size_t)(2 * eo[n])), o2(o1.size());
+    std::vector<int32_t> n1(n), n2(n);
+    int64_t c1 = 0, c2 = 0;
+    oracle_abea_align(n, so.data(), sl.data(), seq.data(), eo.data(), ev.data(), model.data(), sc.data(), sh.data(), o1.data(), n1.data(), 1, &c1);
+    oracle_abea_align(n, so.data(), sl.data(), seq.data(), eo.data(), ev.data(), model.data(), sc.data(), sh.data(), o2.data(), n2.data(), 4, &c2);
+    bool same = n1 == n2 && c1 == c2;
+    int64_t aligned = 0;
+    for (int64_t r = 0; r < n && same; ++r) {
+        same = !memcmp(&o1[(size_t)(2 * eo[r])], &o2[(size_t)(2 * eo[r])], (size_t)n1[r] * sizeof(gbx_abea_pair));
+        aligned += n1[r];
+    }
+    CHECK(same, "abea: 1 thread != 4 threads");
+    CHECK(aligned > 0, "abea: no read aligned");
+    printf("abea: %lld reads, %lld pairs, %lld cells\n", (long long)n, (long long)aligned, (long long)c1);
+}
+
 int main()
 {
     run_bsw();
     run_chain();
     run_phmm();
     run_poa();
+    run_abea();
     if (fails) { fprintf(stderr, "san_main: %d check(s) failed\n", fails); return 1; }
     printf("san_main: ok\n");
     return 0;
