@@ -835,10 +835,11 @@ constexpr int POA_LDS_STACK16 = 256;       // largest DFS stack kept in LDS (swe
                                            // 376: 362); the launch may choose less (PoaTopoLds::stk_cap)
 
 #ifdef GBX_POA_PHASE_STATS
-__device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo_blocks, g_topo_dfs_cycles;
+__device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo_blocks, g_topo_dfs_cycles, g_topo_roots, g_topo_trivial;
 #endif
 // LDS arrays of the topological sort, persistent per wavefront for the life of a window
 constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
+constexpr int POA_OBUF_SHORTS = 80;         // staging of the order under construction: 64 entries + one emission (1 + 8 aligned)
 // The pointers carry the LDS address space in their type.  As plain (generic) pointers they depend on the compiler
 // inferring the address space through the whole inlined window kernel; when it does not (it stopped after an unrelated
 // change of the DP: SQ_INSTS_LDS fell from 2.1e9 to 2.8e6 per launch) every access below becomes a FLAT instruction,
@@ -851,6 +852,7 @@ struct PoaTopoLds {
     lds_s16 *stk;            // [stk_cap] DFS stack
     int stk_cap;             // entries; a deeper walk falls back to the global-memory sort
     lds_s16 *rec;            // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
+    lds_s16 *obuf;           // [POA_OBUF_SHORTS] the newest entries of the order, flushed to global memory 64 at a time
     int n_sorted;            // nodes ranked by the previous sort
     int use;                 // 0: the node capacity does not fit LDS, the global-memory sort runs instead (a null test
                              // will not do: LDS offset 0 is a valid address, and the LDS null pointer is not 0)
@@ -866,10 +868,15 @@ struct PoaTopoLds {
 // 64-rank region); nodes added since the previous sort are read in place.
 __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
-    lds_u8 *st8 = T.st8; lds_s16 *stk = T.stk, *old = T.old, *rec = T.rec;
-    int32_t *ord = g.stack;                                    // the order under construction goes to global memory (the
-                                                               // global DFS-stack area is free here): stores only, nothing in
-                                                               // the walk waits for them; r2n still holds the previous order
+    lds_u8 *st8 = T.st8; lds_s16 *stk = T.stk, *old = T.old, *rec = T.rec, *obuf = T.obuf;
+    // The order under construction goes to global memory (the global DFS-stack area is free here; r2n still holds the
+    // previous order) - 64 entries at a time through an LDS staging buffer.  One store per emitted node looked free
+    // ("stores only, nothing waits for them") and was not: the compiler keeps an `s_waitcnt vmcnt(0)` at the head of
+    // the loop over the roots (a rarely taken path of the body loads from global memory into a register the head
+    // redefines), gfx9 counts stores in that counter, and nearly every node of a partial-order graph is a root whose
+    // walk ends with an emission - so every node waited a full store round trip (2 900 clocks per node).
+    int32_t *ord = g.stack;
+    int nflush = 0;                                            // entries of the order already in global memory
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
     const int n_old = T.n_sorted;
@@ -893,7 +900,7 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
     };
     int sp = 0, nr = 0;
 #ifdef GBX_POA_PHASE_STATS
-    unsigned long long tv0_ = __builtin_readcyclecounter(), nvis_ = 0, nblk_ = 0;
+    unsigned long long tv0_ = __builtin_readcyclecounter(), nvis_ = 0, nblk_ = 0, nroot_ = 0, ntriv_ = 0;
 #endif
     // The node on top of the stack and its state byte are carried in registers whenever they are known: after a
     // push the new top is the last candidate pushed and its state was just read for the push decision, and the
@@ -908,6 +915,9 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
         stk[sp++] = (short)i;
         int top = i, top_st = st_i;
         bool top_known = true;
+#ifdef GBX_POA_PHASE_STATS
+        ++nroot_; const unsigned long long v0_ = nvis_;
+#endif
         while (sp) {
 #ifdef GBX_POA_PHASE_STATS
             ++nvis_;
@@ -971,13 +981,24 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
             if (valid) {
                 if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 2);
                 if (chk) {
-                    if (lane == 0) ord[nr] = id;
-                    if (lane >= 4 && lane < 4 + ac) ord[nr + 1 + lane - 4] = cand;
+                    const int ob = nr - nflush;                  // < 64
+                    if (lane == 0) obuf[ob] = (short)id;
+                    if (lane >= 4 && lane < 4 + ac) obuf[ob + 1 + lane - 4] = (short)cand;
                     nr += 1 + ac;
+                    if (nr - nflush >= 64) {
+                        ord[nflush + lane] = ((const volatile lds_s16 *)obuf)[lane];
+                        const int rem = nr - nflush - 64;        // <= 8 entries of the last emission
+                        const short mv = ((const volatile lds_s16 *)obuf)[64 + min(lane, 15)];
+                        if (lane < rem) obuf[lane] = mv;
+                        nflush += 64;
+                    }
                 }
                 --sp;
             } else if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 1);
         }
+#ifdef GBX_POA_PHASE_STATS
+        if (nvis_ - v0_ == 1) ++ntriv_;
+#endif
     }
     if (overflow) {
         // deeper than the LDS stack (a long fresh chain walked back node by node): redo this sort with the
@@ -992,8 +1013,9 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
         return;
     }
 #ifdef GBX_POA_PHASE_STATS
-    if (lane == 0) { atomicAdd(&g_topo_dfs_cycles, __builtin_readcyclecounter() - tv0_); atomicAdd(&g_topo_visits, nvis_); atomicAdd(&g_topo_blocks, nblk_); }
+    if (lane == 0) { atomicAdd(&g_topo_dfs_cycles, __builtin_readcyclecounter() - tv0_); atomicAdd(&g_topo_visits, nvis_); atomicAdd(&g_topo_blocks, nblk_); atomicAdd(&g_topo_roots, nroot_); atomicAdd(&g_topo_trivial, ntriv_); }
 #endif
+    if (lane < nr - nflush) ord[nflush + lane] = ((const volatile lds_s16 *)obuf)[lane];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; old[id] = (short)r; }
@@ -1154,6 +1176,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     T.stk = (lds_s16 *)(lds0 + 3 * ncp);
     T.stk_cap = A.lds_stack;
     T.rec = T.stk + A.lds_stack;
+    T.obuf = T.rec + 64 * POA_REC_SHORTS;
     T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
@@ -1234,7 +1257,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     if ((threadIdx.x & 63) == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); }
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-        A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles;
+        A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;
     }
 #endif
 }
@@ -1249,7 +1272,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 // global-memory sort).  Returns the bytes, or 0 when the node capacity does not fit LDS at all.
 static size_t poa_lds_plan(int ncap, int *stack_entries)
 {
-    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + 64 * POA_REC_SHORTS * 2;
+    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + 64 * POA_REC_SHORTS * 2 + POA_OBUF_SHORTS * 2;
     if (ncap >= 32768) return 0;
     int max_waves = 12;
     if (const char *e = getenv("GBX_POA_MAX_WAVES")) { const int v = atoi(e); if (v >= 8 && v <= 16) max_waves = v; }   // tuning aid

@@ -1,16 +1,24 @@
-import sys, time, ctypes as C
-sys.path.insert(0, ".")
+"""Development aid: where poa_kernel's wavefronts spend their clocks (DP / traceback / add_alignment incl. the
+topological sort / consensus), summed over wavefronts.  Needs a library built with -DGBX_POA_PHASE_STATS:
+  hipcc ... -DGBX_POA_PHASE_STATS -c poa_kernels.hip -o /tmp/poa_ps.o; link into genomicsbench_amd/libgbx_ps.so
+usage: GBX_LIB=$PWD/genomicsbench_amd/libgbx_ps.so python scripts/dbg_poa_phases.py [n_windows]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from genomicsbench_amd import _native as N
+from genomicsbench_amd.poa import DevicePoaWindowSet, make_params
 from genomicsbench_amd.datagen import gen_poa
-from genomicsbench_amd import poa as PO
-dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-ws = gen_poa(n, 4001); p = PO.make_params(); d = PO.DevicePoaWindowSet(ws, dev)
-d.run(p, s); torch.cuda.synchronize()
-t = time.perf_counter(); d.run(p, s); torch.cuda.synchronize(); dt = time.perf_counter() - t
-tail = d.work[d.work_bytes - 128:].cpu().numpy().view(np.uint64)
-print("windows", n, "ms", round(dt * 1e3, 1), "cells", tail[0], "cycles dp/tb/add/cons", tail[1:5], "shares", np.round(tail[1:5] / max(1, tail[1:5].sum()), 3), flush=True)
-print("topo (cumulative over both runs; block 0 snapshot): cycles", tail[5], "nodes", tail[6], "cyc/node", tail[5] / max(1, tail[6]),
-      "visits", tail[7], "visits/node", tail[7] / max(1, tail[6]), "block loads", tail[8], "dfs-loop cycles", tail[9],
-      "dfs cyc/visit", tail[9] / max(1, tail[7]), flush=True)
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+ws = gen_poa(n, 4001)
+d = DevicePoaWindowSet(ws, torch.device("cuda:0"))
+p = make_params()
+d.run(p); torch.cuda.synchronize()
+t = time.perf_counter(); d.run(p); torch.cuda.synchronize(); ms = (time.perf_counter() - t) * 1e3
+c = d.work[d.work_bytes - 128:].cpu().numpy().view(np.uint64)
+dp, tb, add, cons, topo, topo_n, vis, blk, dfs = [int(x) for x in c[1:10]]
+tot = dp + tb + add + cons
+print("%d windows %.1f ms; wave clocks: DP %.1f%%  traceback %.1f%%  add_alignment %.1f%% (of which topological sort %.1f%%, DFS part %.1f%%)  consensus %.1f%%" % (
+    n, ms, 100 * dp / tot, 100 * tb / tot, 100 * add / tot, 100 * topo / tot, 100 * dfs / tot, 100 * cons / tot))
+roots, triv = int(c[10]), int(c[11])
+print("sort roots per node %.3f, single-visit roots per node %.3f" % (roots / max(topo_n, 1), triv / max(topo_n, 1)))
+print("sort: %.0f clocks per node, %.2f visits per node, %.3f block loads per node" % (topo / max(topo_n, 1), vis / max(topo_n, 1), blk / max(topo_n, 1)))
