@@ -656,8 +656,17 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         return hv - (int)FO[byte];
     };
     int plo = -1, phi = -1;                      // positions come out in descending order
-#define PG_PUSH(nd, ps) do { const int ps_ = (ps); if (np < g.aln_path_cap) { g.path_node[np] = (nd); g.path_pos[np] = ps_; } \
-                             if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; } while (0)
+    // The path collects in registers (entry np in lane np & 63) and leaves 64 entries at a time: a store per step
+    // would sit in front of every gather below (gfx9 counts loads and stores in one in-order counter, so the wait
+    // for a gather is also a wait for the acknowledgement of every store issued before it).
+    int pbn = 0, pbp = 0;
+    auto path_flush = [&](int first, int count) {
+        if (lane < count && first + lane < g.aln_path_cap) { g.path_node[first + lane] = pbn; g.path_pos[first + lane] = pbp; }
+    };
+#define PG_PUSH(nd, ps) do { const int ps_ = (ps), nd_ = (nd); const bool me_ = lane == (np & 63); \
+                             pbn = me_ ? nd_ : pbn; pbp = me_ ? ps_ : pbp; \
+                             if (ps_ != -1) { if (phi < 0) phi = ps_; plo = ps_; } ++np; \
+                             if ((np & 63) == 0) path_flush(np - 64, 64); } while (0)
     // A step is two dependent memory round trips: the row descriptor (first predecessor's row, letter, in-degree,
     // node) and then the predecessor's cell.  Most steps go to the first predecessor, so that row's descriptor is
     // requested together with its cell, and the cell that decided the move is the next step's H(i,j): a step
@@ -778,6 +787,7 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     }
 #undef PG_AT
 #undef PG_PUSH
+    if (np & 63) path_flush(np & ~63, np & 63);
     g.n_path = np <= g.aln_path_cap ? np : 0;
     g.path_lo = plo; g.path_hi = phi;
 }
