@@ -266,11 +266,11 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                     auto slot_of = [&](int a) -> int { const int v = si - (i - a); return v < 0 ? v + RING_PHYS : v; };
 
                     STAMP(0);
-                    int max_f = q_span, max_j = -1, n_skip = 0, last_bl = 64;
+                    int max_f = q_span, max_j = -1, max_pk = 0, n_skip = 0, last_bl = 64;   // max_pk: peak of anchor max_j (:92)
                     // One 64-wide chunk of the look-back, lane 0 = anchor jhi.  Returns true when the max_skip break fired.
                     // The anchor words and DP state of the chunk arrive as arguments, so that the ring path below is
                     // made of LDS reads only.
-                    auto chunk = [&](int jhi, bool valid, uint64_t xj, uint64_t yj, int fj, int pj, int tj) -> bool {
+                    auto chunk = [&](int jhi, bool valid, uint64_t xj, uint64_t yj, int fj, int pj, int tj, int kj) -> bool {
                         // ---- phase 1: candidate score / `continue` mask (:59-80)
     #ifdef GBX_CHAIN_STAMPS
                         { unsigned lo_ = (unsigned)xj, a_ = (unsigned)fj, b_ = (unsigned)pj, c_ = (unsigned)tj, d_ = (unsigned)yj;
@@ -395,6 +395,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             const int li = 63 - __builtin_clzll(imp);  // last improving lane before the break
                             max_j = jhi - li;
                             max_f = __builtin_amdgcn_readlane(sc, li);
+                            max_pk = __builtin_amdgcn_readlane(kj, li);    // travels with the chunk: no LDS round trip at the anchor's end
                         }
                         STAMP(5);
                         // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89): in the ring while
@@ -418,7 +419,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         const int rs = slot_of(valid ? j : st);
                         const uint4 wxy = rxy[rs];
                         const int4 wst = rst[rs];
-                        if ((broke = chunk(jhi, valid, ((uint64_t)wxy.y << 32) | wxy.x, ((uint64_t)wxy.w << 32) | wxy.z, wst.x, wst.y, wst.z))) break;
+                        if ((broke = chunk(jhi, valid, ((uint64_t)wxy.y << 32) | wxy.x, ((uint64_t)wxy.w << 32) | wxy.z, wst.x, wst.y, wst.z, wst.w))) break;
                     }
                     // deeper chunks: the global arrays (blocks that left the ring are complete there; a chunk that straddles
                     // the ring's edge reads its newer lanes from the ring)
@@ -427,27 +428,22 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             const int j = jhi - lane;
                             const bool valid = j >= st;
                             const int jj = valid ? j : st;
-                            uint64_t xj, yj; int fj, pj, tj;
+                            uint64_t xj, yj; int fj, pj, tj, kj;
                             if (jj >= live0) {
                                 const int rs = slot_of(jj);
                                 const uint4 wxy = rxy[rs];
                                 const int4 wst = rst[rs];
-                                xj = ((uint64_t)wxy.y << 32) | wxy.x; yj = ((uint64_t)wxy.w << 32) | wxy.z; fj = wst.x; pj = wst.y; tj = wst.z;
+                                xj = ((uint64_t)wxy.y << 32) | wxy.x; yj = ((uint64_t)wxy.w << 32) | wxy.z; fj = wst.x; pj = wst.y; tj = wst.z; kj = wst.w;
                             } else {
-                                xj = settle(x[jj]); yj = settle(y[jj]); fj = settle(f[jj]); pj = settle(p[jj]); tj = settle(t[jj]);
+                                xj = settle(x[jj]); yj = settle(y[jj]); fj = settle(f[jj]); pj = settle(p[jj]); tj = settle(t[jj]); kj = settle(pk[jj]);
                             }
-                            if (chunk(jhi, valid, xj, yj, fj, pj, tj)) break;
+                            if (chunk(jhi, valid, xj, yj, fj, pj, tj, kj)) break;
                         }
                     // predecessors visited (the benchmark's cell count): everything down to st, or down to the breaking lane
                     visited += (unsigned long long)(last_bl < 64 ? (i - 1 - jhi) + last_bl + 1 : i - st);
                     STAMP(7);
                     // :91-92: into the block's output registers and the ring
-                    int pkj = 0;
-                    if (max_j >= 0) {
-                        if (max_j >= live0) pkj = rst[slot_of(max_j)].w;
-                        else pkj = settle(pk[max_j]);
-                    }
-                    const int pki = (max_j >= 0 && pkj > max_f) ? pkj : max_f;
+                    const int pki = (max_j >= 0 && max_pk > max_f) ? max_pk : max_f;
                     const bool mine = lane == k;                  // one compare, three selects: no exec-mask change, no LDS
                     of_ = mine ? max_f : of_;
                     op_ = mine ? max_j : op_;
