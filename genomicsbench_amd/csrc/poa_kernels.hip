@@ -850,6 +850,8 @@ __device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo
 // LDS arrays of the topological sort, persistent per wavefront for the life of a window
 constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
 constexpr int POA_OBUF_SHORTS = 80;         // staging of the order under construction: 64 entries + one emission (1 + 8 aligned)
+constexpr int POA_LDS_FIXED = POA_LDS_STACK16 * 2 + 64 * POA_REC_SHORTS * 2 + POA_OBUF_SHORTS * 2;   // stack, block cache, staging (16-byte multiple)
+static_assert(POA_LDS_FIXED % 16 == 0, "per-node LDS arrays start 16-byte aligned");
 // The pointers carry the LDS address space in their type.  As plain (generic) pointers they depend on the compiler
 // inferring the address space through the whole inlined window kernel; when it does not (it stopped after an unrelated
 // change of the DP: SQ_INSTS_LDS fell from 2.1e9 to 2.8e6 per launch) every access below becomes a FLAT instruction,
@@ -1180,13 +1182,15 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     // serial DFS state on chip (LDS): state byte per node, order under construction, stack
     PoaTopoLds T;
     lds_u8 *const lds0 = (lds_u8 *)lds_raw;
-    T.st8 = lds0;
-    T.use = A.lds_marks;
-    T.old = (lds_s16 *)(lds0 + ncp);
-    T.stk = (lds_s16 *)(lds0 + 3 * ncp);
-    T.stk_cap = A.lds_stack;
-    T.rec = T.stk + A.lds_stack;
+    // fixed-size arrays first, at compile-time offsets (the per-node arrays behind them need the node capacity): the
+    // bases then fold into the ds instructions' offset fields instead of living in (spilled) scalar registers
+    T.stk = (lds_s16 *)lds0;
+    T.rec = (lds_s16 *)(lds0 + POA_LDS_STACK16 * 2);
     T.obuf = T.rec + 64 * POA_REC_SHORTS;
+    T.st8 = lds0 + POA_LDS_FIXED;
+    T.use = A.lds_marks;
+    T.old = (lds_s16 *)(lds0 + POA_LDS_FIXED + ncp);
+    T.stk_cap = A.lds_stack;
     T.n_sorted = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
@@ -1282,7 +1286,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 // global-memory sort).  Returns the bytes, or 0 when the node capacity does not fit LDS at all.
 static size_t poa_lds_plan(int ncap, int *stack_entries)
 {
-    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + 64 * POA_REC_SHORTS * 2 + POA_OBUF_SHORTS * 2;
+    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + POA_LDS_FIXED;
     if (ncap >= 32768) return 0;
     int max_waves = 12;
     if (const char *e = getenv("GBX_POA_MAX_WAVES")) { const int v = atoi(e); if (v >= 8 && v <= 16) max_waves = v; }   // tuning aid
@@ -1290,12 +1294,11 @@ static size_t poa_lds_plan(int ncap, int *stack_entries)
         // measured (node capacity 3364): twelve windows of 12304 B run together (336 ms); at 13024 B the twelfth is
         // resident only some of the time (362-386 ms), so the budget is 12 x 12544 B, not the nominal 160 KB
         const size_t share = ((size_t)12 * 12544 / (size_t)waves) & ~(size_t)31;
-        if (share < fixed + 128 * 2) continue;
-        size_t st = (share - fixed) / 2;
-        if (st > (size_t)POA_LDS_STACK16) st = POA_LDS_STACK16;
+        if (share < fixed) continue;
+        size_t st = POA_LDS_STACK16;                      // the stack's region is fixed; fewer entries only as a tuning aid
         if (const char *e = getenv("GBX_POA_LDS_STACK")) { const size_t v = (size_t)atoi(e); if (v >= 32 && v <= st) st = v; }   // tuning aid
         *stack_entries = (int)st;
-        return fixed + st * 2;
+        return fixed;
     }
     return 0;
 }
