@@ -85,7 +85,7 @@ __device__ inline uint32_t base_rank(char b) { return b == 'C' ? 1u : b == 'G' ?
 // last k-mer's column) drops the per-band bounds, the trim cell, the end-cell test and the cell count.
 struct AbeaBest { float s; int ev, off, e_default; };
 
-__global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
+__global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tring[16 * ROW];      // the last (up to) 16 trace rows, flushed as 1 KB
     const int lane = threadIdx.x;
@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
         // Indices outside the read are clamped: such values only ever reach cells that are not filled.
         auto eload = [&](int idx) -> float { return evm[min(max(idx, 0), n_events - 1)]; };
         auto kload = [&](int idx) -> float4 { return kp[min(max(idx, 0), n_kmers - 1)]; };
-        float evA = eload(e_b - oA), evB = eload(e_b - oB);
-        float kmA, kmB, ksA, ksB, kcA, kcB, krA, krB;
-        { const float4 t = kload(k_b + oA); kmA = t.x; ksA = t.y; kcA = t.z; krA = t.w; }
-        { const float4 t = kload(k_b + oB); kmB = t.x; ksB = t.y; kcB = t.z; krB = t.w; }
+        // (x = the lane's cell A, y = cell B: pairs, because both cells go through the packed-float pipe together)
+        v2f ev = {eload(e_b - oA), eload(e_b - oB)}, km, ks, kc, kr;
+        { const float4 t = kload(k_b + oA); km.x = t.x; ks.x = t.y; kc.x = t.z; kr.x = t.w; }
+        { const float4 t = kload(k_b + oB); km.y = t.x; ks.y = t.y; kc.y = t.z; kr.y = t.w; }
         // look-ahead windows: lane j holds the value that enters j moves after the window's base.  A window serves one
         // block of 16 bands and is loaded two blocks ahead, at the top of a block (a block moves at most 16 times in
         // either direction, the window holds 64).  The band loop contains no load and no wait on the vector-memory
@@ -174,8 +174,7 @@ __global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
         float4 kwc = kload(kw_base + lane);
         int en_base = ew_base, kn_base = kw_base;                // the windows of the next block
         // everything loaded so far is waited for here, once, so that no wait is left inside the band loop
-        asm volatile("" : "+v"(ewc), "+v"(kwc.x), "+v"(kwc.y), "+v"(kwc.z), "+v"(kwc.w), "+v"(evA), "+v"(evB), "+v"(kmA), "+v"(kmB),
-                          "+v"(ksA), "+v"(ksB), "+v"(kcA), "+v"(kcB), "+v"(krA), "+v"(krB));
+        asm volatile("" : "+v"(ewc), "+v"(kwc.x), "+v"(kwc.y), "+v"(kwc.z), "+v"(kwc.w), "+v"(ev), "+v"(km), "+v"(ks), "+v"(kc), "+v"(kr));
         float ewn = ewc;
         float4 kwn = kwc;
         AbeaBest best = {NINF, 0, -1, 0};                        // :416-432, tracked on the fly
@@ -197,18 +196,15 @@ __global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
                 // k-mer parameters move one offset down; offset 127 takes the next one of the look-ahead block
                 const int j = k_b + 127 - kw_base;
                 const float im = rlf(kwc.x, j), is = rlf(kwc.y, j), ic = rlf(kwc.z, j);
-                const float nmB = shl1(kmA, im), nsB = shl1(ksA, is), ncB = shl1(kcA, ic);
-                kmA = kmB; ksA = ksB; kcA = kcB;
-                kmB = nmB; ksB = nsB; kcB = ncB;
-                if constexpr (FDIV) { const float nrB = shl1(krA, rlf(kwc.w, j)); krA = krB; krB = nrB; }
+                km = (v2f){km.y, shl1(km.x, im)}; ks = (v2f){ks.y, shl1(ks.x, is)}; kc = (v2f){kc.y, shl1(kc.x, ic)};
+                if constexpr (FDIV) kr = (v2f){kr.y, shl1(kr.x, rlf(kwc.w, j))};
                 dgA = upA; dgB = upB;                            // up = band[b-1][o+1], left = band[b-1][o]
                 upA = p1b; upB = shl1(p1a, NINF);
                 lfA = p1a; lfB = p1b;
             } else {
                 e_b += 1;
                 const float ie = rlf(ewc, e_b - ew_base);
-                const float neA = shr1(evB, ie);
-                evB = evA; evA = neA;
+                ev = (v2f){shr1(ev.y, ie), ev.x};
                 dgA = lfA; dgB = lfB;                            // up = band[b-1][o], left = band[b-1][o-1]
                 upA = p1a; upB = p1b;
                 lfB = p1a; lfA = shr1(p1b, NINF);
@@ -232,17 +228,16 @@ __global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
             if constexpr (FDIV) {
                 // both cells at once on the packed-float pipe: q = a / gs as the compiler's division computes it once
                 // its rescaling is the identity - a first quotient and two residual corrections against gs
-                const v2f x = {evA, evB}, gm = {kmA, kmB}, gs = {ksA, ksB}, gc = {kcA, kcB}, rr = {krA, krB};
-                const v2f a = x - gm;
-                const v2f q0 = a * rr;
-                const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-gs, q0, a), rr, q0);
-                const v2f q = __builtin_elementwise_fma(__builtin_elementwise_fma(-gs, q1, a), rr, q1);
-                const v2f l = gc + (-0.5f * q) * q;
+                const v2f a = ev - km;
+                const v2f q0 = a * kr;
+                const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-ks, q0, a), kr, q0);
+                const v2f q = __builtin_elementwise_fma(__builtin_elementwise_fma(-ks, q1, a), kr, q1);
+                const v2f l = kc + (-0.5f * q) * q;
                 lpeA = l.x; lpeB = l.y;
             } else {
-                const float aA = (evA - kmA) / ksA, aB = (evB - kmB) / ksB;
-                lpeA = kcA + (-0.5f * aA * aA);
-                lpeB = kcB + (-0.5f * aB * aB);
+                const float aA = (ev.x - km.x) / ks.x, aB = (ev.y - km.y) / ks.y;
+                lpeA = kc.x + (-0.5f * aA * aA);
+                lpeB = kc.y + (-0.5f * aB * aB);
             }
             auto cell = [&](int o, float diag, float up, float left, float lpe, float &val, int &from) {
                 const float score_d = (float)(((double)diag + lp_step) + (double)lpe);       // :371-373
@@ -250,10 +245,19 @@ __global__ void __launch_bounds__(64) abea_kernel(AbeaArgs A)
                 const float score_l = (float)((double)left + lp_skip);
                 float max_score = score_d;
                 int f = 0;                                                                    // FROM_D
-                max_score = score_u > max_score ? score_u : max_score;
-                f = max_score == score_u ? 1 : f;                                             // FROM_U
-                max_score = score_l > max_score ? score_l : max_score;
-                f = max_score == score_l ? 2 : f;                                             // FROM_L
+                if constexpr (FDIV) {
+                    // a read that passed the range check has no NaN anywhere (finite emissions, scores finite or -inf),
+                    // and without NaNs `u > m ? u : m` is the hardware maximum
+                    max_score = __builtin_fmaxf(score_u, max_score);
+                    f = max_score == score_u ? 1 : f;                                         // FROM_U
+                    max_score = __builtin_fmaxf(score_l, max_score);
+                    f = max_score == score_l ? 2 : f;                                         // FROM_L
+                } else {
+                    max_score = score_u > max_score ? score_u : max_score;
+                    f = max_score == score_u ? 1 : f;                                         // FROM_U
+                    max_score = score_l > max_score ? score_l : max_score;
+                    f = max_score == score_l ? 2 : f;                                         // FROM_L
+                }
                 if constexpr (FAST) {
                     val = lane_in ? max_score : NINF;
                     from = f;                                    // the bytes of offsets >= BW are never read
