@@ -650,7 +650,7 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         line["gather_verified"] = work.check_gathered(full, ranges, parts, args.verify_units or
                                                       {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8}[kind])
         line["shard_units"] = [hi - lo for lo, hi in ranges]
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:                      # the CPU baseline is an N=1 figure (rank 0's host cores)
         line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
         if hasattr(work, "host_entry"):
             line["host_entry"] = work.host_entry()
@@ -663,13 +663,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kernel", choices=sorted(WORKLOADS), default=None,
-                    help="one kernel only (default: bsw headline + chain, phmm, poa under 'kernels')")
+                    help="one kernel only (default: bsw headline + chain, phmm, poa, abea under 'kernels')")
     ap.add_argument("--mode", choices=["scatter", "local"], default="scatter")
-    ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows); 0 = 'large'")
+    ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows / reads); 0 = 'large'")
     ap.add_argument("--pairs", type=int, default=0, help="alias of --size for bsw")
     ap.add_argument("--cpu-units", type=int, default=0, help="units in the CPU-baseline sample (0 = kernel default)")
     ap.add_argument("--verify-units", type=int, default=0, help="units per shard checked against the oracle after the gather")
-    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of chain / phmm / poa in the all-kernel run")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of chain / phmm / poa / abea in the all-kernel run")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     if args.pairs:
