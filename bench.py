@@ -483,6 +483,33 @@ class AbeaWork:
         d = self.d
         return int(d.n_bands_total * 130 + d.n_kmers_total * 33 + d.n_events_total * 16), self.units
 
+    def host_entry(self):
+        """PCIe-inclusive rate of the same shard through gbx_abea_align_host (pageable host arrays in - the events as the
+        24-byte records a reference caller holds - aligned pairs out): reported beside `value`, never as it."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.abea import PAIR_DTYPE
+        rs = self.rs
+        N.check(N.lib().gbx_host_prepare())
+        ev = rs.events_struct()
+        out = np.zeros(2 * max(int(rs.event_off[-1]), 1), dtype=PAIR_DTYPE)
+        out["ref_pos"][:] = -1                                                # touched pages, like a caller's array
+        n_pairs = np.zeros(max(rs.n_reads, 1), dtype=np.int32)
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            N.check(N.lib().gbx_abea_align_host(rs.n_reads, N.ptr(rs.seq_off), N.ptr(rs.seq_len), N.ptr(rs.seq_arena), rs.seq_arena.size,
+                                                N.ptr(rs.event_off), N.ptr(ev), N.ptr(rs.model), N.ptr(rs.scale), N.ptr(rs.shift),
+                                                N.ptr(out), N.ptr(n_pairs)))
+            ms.append((time.perf_counter() - t0) * 1e3)
+        go, gn = self.d.results()
+        same = np.array_equal(gn[:rs.n_reads], n_pairs[:rs.n_reads]) and all(
+            np.array_equal(go[2 * int(rs.event_off[r]):2 * int(rs.event_off[r]) + int(gn[r])],
+                           out[2 * int(rs.event_off[r]):2 * int(rs.event_off[r]) + int(gn[r])]) for r in range(0, rs.n_reads, max(rs.n_reads // 512, 1)))
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": float(self.units or 0.0) / (min(ms) * 1e-3) / 1e9, "unit": "GCUPS",
+                "what": "gbx_abea_align_host on the rank-0 shard: H2D (%.2f GB of event records, means gathered on the way) + kernel "
+                        "+ D2H (%.2f GB of pair slots) from pageable memory" % (ev.nbytes / 1e9, out.nbytes / 1e9),
+                "same_as_device_entry": bool(same)}
+
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1

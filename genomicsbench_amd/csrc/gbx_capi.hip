@@ -1030,6 +1030,9 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
                         gbx_abea_pair *out, int32_t *n_pairs)
 {
     RoctxRange range_("gbx_abea_align_host");
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;
+    const double t_begin = wall_s();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[gbx abea host] %9.3f ms %s\n", (wall_s() - t_begin) * 1e3, what); };
     if (n_reads < 0 || seq_bytes < 0) { set_error("gbx_abea_align_host: bad argument"); return GBX_ERR_ARG; }
     if (n_reads == 0) return GBX_OK;
     if (!seq_off || !seq_len || !seq_arena || !event_off || !events || !models || !scale || !shift || !out || !n_pairs) {
@@ -1052,12 +1055,9 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
     const int64_t e0 = event_off[0], n_ev = event_off[n_reads] - e0;
     int64_t n_kmers_total = 0;
     for (int64_t r = 0; r < n_reads; ++r) n_kmers_total += (int64_t)seq_len[r] - GBX_ABEA_KMER + 1;
-    // only the means of the events are read (align.c:125): compact them before the upload
-    std::vector<float> mean((size_t)n_ev + 4);
-    {
-        const int T = host_workers();
-        parallel_ranges(n_ev, T, [&](int, int64_t lo, int64_t hi) { for (int64_t k = lo; k < hi; ++k) mean[(size_t)k] = events[e0 + k].mean; });
-    }
+    // only the means of the events are read (align.c:125): the upload workers gather them from the 24-byte records
+    // straight into the pinned slabs (no compact host copy)
+    mark("planned");
     std::vector<int64_t> eoff((size_t)n_reads + 1);
     for (int64_t r = 0; r <= n_reads; ++r) eoff[(size_t)r] = event_off[r] - e0;
     HostLane lane;
@@ -1073,13 +1073,15 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
     HostPipe pipe(L, (size_t)seq_bytes + (size_t)n_ev * 4 + (size_t)n_reads * 60, false);
     if ((rc = pipe.prepare(1))) return rc;
     pipe.stage(0, dso.p, seq_off, n_reads * 8); pipe.stage(0, dsl.p, seq_len, n_reads * 4); pipe.stage(0, dsq.p, seq_arena, (size_t)seq_bytes);
-    pipe.stage(0, deo.p, eoff.data(), (n_reads + 1) * 8); pipe.stage(0, dem.p, mean.data(), (size_t)n_ev * 4);
+    pipe.stage(0, deo.p, eoff.data(), (n_reads + 1) * 8); if (n_ev) pipe.stage_field4(0, dem.p, &events[e0].mean, (size_t)n_ev, (int)sizeof(gbx_abea_event));
     pipe.stage(0, dmo.p, models, GBX_ABEA_NMODEL * sizeof(gbx_abea_model));
     pipe.stage(0, dsc.p, scale, n_reads * 4); pipe.stage(0, dsh.p, shift, n_reads * 4);
     pipe.stage(0, dbo.p, band_off.data(), (n_reads + 1) * 8); pipe.stage(0, dor.p, order.data(), n_reads * 4);
     pipe.stage(0, dlp.p, lp.data(), n_reads * 16);
+    mark("device buffers ready");
     pipe.start();
     if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+    mark("uploads queued");
     rc = abea_launch(n_reads, dso.as<int64_t>(), dsl.as<int32_t>(), dsq.as<char>(), deo.as<int64_t>(), dem.as<float>(),
                      dmo.as<gbx_abea_model>(), dsc.as<float>(), dsh.as<float>(), dbo.as<int64_t>(), dor.as<int32_t>(), dlp.as<double>(),
                      n_kmers_total, band_off[(size_t)n_reads], dout.as<gbx_abea_pair>(), dnp.as<int32_t>(), dw.p, wb, lane.l->compute);
@@ -1088,7 +1090,10 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
     pipe.fetch(0, out + 2 * e0, dout.p, (size_t)n_ev * 2 * sizeof(gbx_abea_pair));
     pipe.fetch(0, n_pairs, dnp.p, n_reads * 4);
     if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
-    return pipe.finish();
+    mark("kernel queued");
+    rc = pipe.finish();
+    mark("results downloaded");
+    return rc;
 }
 
 }  // extern "C"

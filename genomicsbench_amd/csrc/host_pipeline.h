@@ -13,6 +13,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <thread>
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
@@ -213,7 +214,8 @@ struct DevBuf {
 //          the chunk is done
 //   P.finish()  -> joins the threads, returns the first error
 struct HostPipe {
-    struct Piece { char *dst; const char *src; size_t len; int chunk; bool pack; };     // pack: len source bytes -> (len+1)/2 at dst
+    // pack: len source bytes -> (len+1)/2 at dst; stride != 0: len / 4 four-byte fields, `stride` bytes apart at src, -> len bytes
+    struct Piece { char *dst; const char *src; size_t len; int chunk; bool pack; int stride; };
     struct Fetch { void *dst; const void *src; size_t len; int chunk; };
     Lane *L;
     bool staged;
@@ -221,6 +223,7 @@ struct HostPipe {
     std::vector<Piece> pieces;
     std::vector<int> remaining;            // pieces of chunk c not yet queued on the copy stream
     std::vector<Fetch> fetches;
+    std::deque<std::vector<char>> gathered;    // compact copies of strided pieces of calls too small to stage (alive until the pipe goes)
     std::vector<int> chunk_nev;            // join events recorded for chunk c
     hipStream_t xfer;                      // L->copy, or L->compute for calls that do not overlap
     std::atomic<size_t> next{0};
@@ -267,7 +270,7 @@ struct HostPipe {
         const size_t cap = staged ? Lane::PIECE : bytes;
         while (bytes) {
             const size_t len = bytes < cap ? bytes : cap;
-            pieces.push_back(Piece{d, s, len, (int)chunk, false});
+            pieces.push_back(Piece{d, s, len, (int)chunk, false, 0});
             ++remaining[(size_t)chunk];
             d += len; s += len; bytes -= len;
         }
@@ -280,9 +283,23 @@ struct HostPipe {
         const char *s = (const char *)src;
         while (bytes) {
             const size_t len = bytes < Lane::PIECE ? bytes : Lane::PIECE;      // PIECE is even: only the last piece can be odd
-            pieces.push_back(Piece{d, s, len, (int)chunk, true});
+            pieces.push_back(Piece{d, s, len, (int)chunk, true, 0});
             ++remaining[(size_t)chunk];
             d += len / 2; s += len; bytes -= len;
+        }
+    }
+    // like stage(), for one 4-byte field of an array of records (abea: the mean of a 24-byte event): the upload workers
+    // gather the field into the pinned slab instead of copying, so no compact host copy is ever made (staged calls only)
+    void stage_field4(int64_t chunk, void *dst, const void *first_field, size_t n_records, int stride)
+    {
+        char *d = (char *)dst;
+        const char *s = (const char *)first_field;
+        const size_t per = Lane::PIECE / 4;
+        while (n_records) {
+            const size_t k = n_records < per ? n_records : per;
+            pieces.push_back(Piece{d, s, k * 4, (int)chunk, false, stride});
+            ++remaining[(size_t)chunk];
+            d += k * 4; s += k * (size_t)stride; n_records -= k;
         }
     }
     void fail_hip(hipError_t e)
@@ -307,7 +324,11 @@ struct HostPipe {
             if (e == hipSuccess) {
                 RoctxRange range_("gbx:h2d piece (stage into pinned slab + DMA)");
                 if (p.pack) pack4((uint8_t *)L->wslab[w][slot], (const uint8_t *)p.src, p.len);
-                else memcpy(L->wslab[w][slot], p.src, p.len);
+                else if (p.stride) {
+                    uint32_t *o = (uint32_t *)L->wslab[w][slot];
+                    const char *q = p.src;
+                    for (size_t k = 0, n = p.len / 4; k < n; ++k, q += p.stride) memcpy(o + k, q, 4);
+                } else memcpy(L->wslab[w][slot], p.src, p.len);
                 e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.pack ? (p.len + 1) / 2 : p.len, hipMemcpyHostToDevice, xfer);
             }
             if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], xfer);
@@ -320,6 +341,22 @@ struct HostPipe {
     }
     // D2H of one chunk's results behind its join event, through the two halves of the pinned slab when staged
     // (the copy of one half to the caller's memory overlaps the DMA into the other)
+    // slab -> caller memory; large pieces with a few threads (one core moves about 10 GB/s, the DMA five times that)
+    void copy_out(char *dst, const char *src, size_t len)
+    {
+        const int T = workers < 6 ? workers : 6;
+        if (len < ((size_t)2 << 20) || T <= 1) { memcpy(dst, src, len); return; }
+        const size_t per = (len / (size_t)T + 63) & ~(size_t)63;
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) {
+            const size_t a = per * (size_t)t;
+            if (a >= len) break;
+            const size_t n = t == T - 1 || a + per > len ? len - a : per;
+            th.emplace_back([=] { memcpy(dst + a, src + a, n); });
+        }
+        memcpy(dst, src, per < len ? per : len);
+        for (auto &x : th) x.join();
+    }
     hipError_t fetch_chunk(int64_t c)
     {
         RoctxRange range_("gbx:d2h chunk (wait for the chunk's kernels + DMA + copy out)");
@@ -361,7 +398,7 @@ struct HostPipe {
                 if ((e = hipEventRecord(L->ev_half[half], xfer)) != hipSuccess) return e;
                 if (pend_len) {
                     if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
-                    memcpy(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
+                    copy_out(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
                 }
                 pend_dst = d; pend_len = len; half ^= 1;
                 d += len; s += len; left -= len;
@@ -369,7 +406,7 @@ struct HostPipe {
         }
         if (pend_len) {
             if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
-            memcpy(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
+            copy_out(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
         }
         return hipSuccess;
     }
@@ -401,9 +438,16 @@ struct HostPipe {
             for (; next < pieces.size() && pieces[next].chunk <= c; ++next) {
                 const Piece &p = pieces[next];
                 const void *src = p.src;
+                if (p.stride) {                                  // a field of records: gathered here (small calls only)
+                    gathered.emplace_back(p.len);
+                    char *o = gathered.back().data();
+                    const char *q = p.src;
+                    for (size_t k = 0, n = p.len / 4; k < n; ++k, q += p.stride) memcpy(o + 4 * k, q, 4);
+                    src = o;
+                }
                 if (packed && pack_off + p.len <= Lane::PIECE) {
                     char *slab = L->wslab[0][0] + pack_off;
-                    memcpy(slab, p.src, p.len);
+                    memcpy(slab, src, p.len);
                     pack_off += (p.len + 63) & ~(size_t)63;
                     src = slab;
                 }
