@@ -678,9 +678,10 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
                                                       {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8}[kind])
         line["shard_units"] = [hi - lo for lo, hi in ranges]
     if not args.no_cpu and world == 1:                      # the CPU baseline is an N=1 figure (rank 0's host cores)
-        line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
+        # the host-buffer entry first, on quiet host cores (the CPU baseline runs OpenMP teams on all of them)
         if hasattr(work, "host_entry"):
             line["host_entry"] = work.host_entry()
+        line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
     return line
 
 
