@@ -48,6 +48,16 @@ PHMM_CLASS.update({"phmm_f32_rpl4": (249, 256), "phmm_f32_rpl6": (257, 384), "ph
 
 
 # ------------------------------------------------------------------------------------------ workloads
+def _host_timed(fn, reps=3):
+    ms = []
+    res = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = fn()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    return ms, res
+
+
 class BswWork:
     metric, unit, dtype = "bsw_large_gcups", "GCUPS", "int32"
 
@@ -226,6 +236,17 @@ class ChainWork:
         # 16 B anchor in + 4 x 4 B outputs (16 in + 8 out + 8 with targets / peaks exported)
         return 32 * self.d.n_anchors, self.units
 
+    def host_entry(self):
+        """PCIe-inclusive rate of the same shard through gbx_chain_host (pageable arrays in, the four result arrays out)."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.chain import chain_host
+        N.check(N.lib().gbx_host_prepare())
+        ms, got = _host_timed(lambda: chain_host(*self.case))
+        dev = self.d.results()
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": float(self.units or 0.0) / (min(ms) * 1e-3) / 1e9, "unit": self.unit,
+                "what": "gbx_chain_host on the rank-0 shard: H2D + kernels + D2H from pageable memory (output arrays allocated per call)",
+                "same_as_device_entry": bool(all(np.array_equal(a, b) for a, b in zip(got, dev)))}
+
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
@@ -310,6 +331,17 @@ class PhmmWork:
         rl, hl = bs.read_len[bs.pair_read].astype(np.int64), bs.hap_len[bs.pair_hap].astype(np.int64)
         sel = (rl >= lo) & (rl <= hi)
         return int((5 * rl[sel] + hl[sel] + 8).sum()), float((rl[sel] * hl[sel]).sum())
+
+    def host_entry(self):
+        """PCIe-inclusive rate of the same shard through gbx_phmm_forward_host."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.phmm import forward_host
+        N.check(N.lib().gbx_host_prepare())
+        ms, got = _host_timed(lambda: forward_host(self.bs))
+        dev = self.d.results()
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": float(self.units or 0.0) / (min(ms) * 1e-3) / 1e9, "unit": self.unit,
+                "what": "gbx_phmm_forward_host on the rank-0 shard: H2D + kernels + D2H from pageable memory",
+                "same_as_device_entry": bool(np.array_equal(got, dev))}
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
@@ -398,6 +430,18 @@ class PoaWork:
         # per cell: 4 B written (H int16 + one byte each of H-F and H-O) + 4 B x ~1.2 predecessor rows read = 8.8 B
         # (measured, profiles/hbm_traffic.json: 747 GB per 6000-window launch = 8.4 B/cell)
         return int(self.units * 8.8), self.units
+
+    def host_entry(self):
+        """PCIe-inclusive rate of the same shard through gbx_poa_consensus_host."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.poa import consensus_host
+        N.check(N.lib().gbx_host_prepare())
+        ms, got = _host_timed(lambda: consensus_host(self.params, self.ws), reps=2)
+        dev = self.d.results()
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": float(self.units or 0.0) / (min(ms) * 1e-3) / 1e9, "unit": self.unit,
+                "what": "gbx_poa_consensus_host on the rank-0 shard: H2D + kernel + D2H from pageable memory (its own workspace: the "
+                        "first call allocates it)",
+                "same_as_device_entry": bool(list(got) == list(dev))}
 
     def cpu_baseline(self, max_units):
         from oracle import oracle_py as O
