@@ -52,9 +52,12 @@ def _host_timed(fn, reps=3):
     ms = []
     res = None
     for _ in range(reps):
+        res = None                                          # the previous call's result arrays are freed outside the timed region
         t0 = time.perf_counter()
-        res = fn()
+        out = fn()
         ms.append((time.perf_counter() - t0) * 1e3)
+        res = out
+        del out
     return ms, res
 
 

@@ -568,6 +568,9 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
                    const gbx_chain_call *hdr, int32_t *score, int32_t *parent, int32_t *target, int32_t *peak)
 {
     RoctxRange range_("gbx_chain_host");
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;
+    const double t_begin = wall_s();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[gbx chain host] %9.3f ms %s\n", (wall_s() - t_begin) * 1e3, what); };
     if (n_calls < 0) { set_error("gbx_chain_host: bad argument"); return GBX_ERR_ARG; }
     if (n_calls == 0) return GBX_OK;
     if (!anchor_off || !hdr || !score || !parent) { set_error("gbx_chain_host: null pointer"); return GBX_ERR_ARG; }
@@ -598,8 +601,10 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
     pipe.stage(0, dh.p, hdr, n_calls * sizeof(gbx_chain_call));
     pipe.stage(0, dx.p, ax, na * 8);
     pipe.stage(0, dy.p, ay, na * 8);
+    mark("device buffers ready");
     pipe.start();
     if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+    mark("uploads queued");
     rc = chain_launch(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
                       ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute);
     if (rc) return pipe.finish(rc);
@@ -608,7 +613,10 @@ int gbx_chain_host(int64_t n_calls, const int64_t *anchor_off, const uint64_t *a
     if (target) pipe.fetch(0, target, dt.p, na * 4);
     if (peak) pipe.fetch(0, peak, dk.p, na * 4);
     if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
-    return pipe.finish();
+    mark("kernels queued");
+    rc = pipe.finish();
+    mark("results downloaded");
+    return rc;
 }
 
 /* -------------------------------------------------------------------- phmm */
@@ -654,6 +662,9 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
                           const uint8_t *hap, double *out)
 {
     RoctxRange range_("gbx_phmm_forward_host");
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;
+    const double t_begin = wall_s();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[gbx phmm host] %9.3f ms %s\n", (wall_s() - t_begin) * 1e3, what); };
     if (n_pairs < 0 || n_reads < 0 || n_haps < 0 || read_bytes < 0 || hap_bytes < 0) {
         set_error("gbx_phmm_forward_host: bad argument");
         return GBX_ERR_ARG;
@@ -703,6 +714,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
                 return GBX_ERR_ARG;
             }
     }
+    mark("validated");
     int rc = require_device();
     if (rc) return rc;
     HostLane lane;
@@ -724,8 +736,10 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     pipe.stage(0, dd.p, d, read_bytes); pipe.stage(0, dc.p, c, read_bytes);
     pipe.stage(0, dho.p, hap_off, n_haps * 8); pipe.stage(0, dhl.p, hap_len, n_haps * 4);
     pipe.stage(0, dh.p, hap, hap_bytes);
+    mark("device buffers ready");
     pipe.start();
     if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+    mark("uploads queued");
     rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), n_reads, dro.as<int64_t>(), drl.as<int32_t>(),
                      drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
                      dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb,
@@ -733,7 +747,10 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     if (rc) return pipe.finish(rc);
     pipe.fetch(0, out, dout.p, n_pairs * 8);
     if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
-    return pipe.finish();
+    mark("kernels queued");
+    rc = pipe.finish();
+    mark("results downloaded");
+    return rc;
 }
 
 /* --------------------------------------------------------------------- poa */
