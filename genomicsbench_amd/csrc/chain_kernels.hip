@@ -111,11 +111,14 @@ __device__ unsigned long long g_chain_stamps[16];
 // look-backs reach past 256 anchors in a tenth of its chunks: 256 anchors (10.5 KB, 15 calls per CU) 76.7-78.0 ms,
 // 512 (18.7 KB, 8 per CU) 74.1-75.0, 768 (26.9 KB, 6 per CU) 72.2-73.3.  512 keeps eight calls per CU for jobs made of
 // many short calls.
+// The kernel exists for two ring sizes and a job takes one of them (chain_pick_kernel): the larger when the job is as
+// long as its longest call anyway.
 #ifndef GBX_CHAIN_RING_LIVE
 #define GBX_CHAIN_RING_LIVE 512
 #endif
-constexpr int RING_LIVE = GBX_CHAIN_RING_LIVE;
-constexpr int RING_PHYS = RING_LIVE + 64;
+#ifndef GBX_CHAIN_RING_LIVE_LONG
+#define GBX_CHAIN_RING_LIVE_LONG 768
+#endif
 
 // Loaded values that are produced on a rare path and consumed after the paths merge make the compiler put
 // `s_waitcnt vmcnt(0)` at the merge point - which, on the common path, waits for this wavefront's
@@ -183,6 +186,21 @@ __global__ void __launch_bounds__(256) chain_st_kernel(int n_calls, const int64_
     if (fl && threadIdx.x == 0) atomicOr(&unsorted[call], fl);
 }
 
+// which of the two instances of chain_kernel runs this job (W.next[4]: 0 = the short ring, 1 = the long one).  The job is
+// bound by its longest call when that call alone takes longer than the whole job spread over the calls the chip keeps
+// in flight with the long ring (6 per CU): longest > anchors / (CUs x 6).  The longest call is known to within a factor
+// of two from the size buckets; the test uses the bucket's lower bound.
+__global__ void chain_pick_kernel(ChainWork W, long long n_anchors, int cus, int force)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    if (force >= 0) { W.next[4] = force; return; }
+    int top = -1;                                           // bucket 0 holds the longest calls (bucket_of)
+    for (int b = NBUCKET - 1; b >= 0; --b) if (W.counts[b] > 0) top = b;
+    const long long longest = top < 0 ? 0 : 1ll << (NBUCKET - 1 - top);
+    W.next[4] = longest * (long long)cus * 6 > n_anchors ? 1 : 0;
+}
+
+template <int RING_LIVE>
 __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *__restrict__ off,
                                                    const uint64_t *__restrict__ ax, const uint64_t *__restrict__ ay,
                                                    const gbx_chain_call *__restrict__ hdr,
@@ -192,6 +210,8 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     // ring entries: the anchor words {x, y} and the DP state {score, parent, target, peak} of the reference's four
     // vectors, 16 bytes each, so that a look-back chunk is two ds_read_b128 per lane.  Scores / parents / peaks go
     // to global memory once per block of 64 anchors (coalesced), targets when their block leaves the ring.
+    constexpr int RING_PHYS = RING_LIVE + 64;
+    if (W.next[4] != (RING_LIVE == GBX_CHAIN_RING_LIVE ? 0 : 1)) return;      // the other instance has this job
     __shared__ uint4 rxy[RING_PHYS];
     __shared__ int4 rst[RING_PHYS + 64];    // + a dump entry per lane for phase 4
     __shared__ int mark[128];               // [0,64) the chunk's marks, [64,128) dump slots of the lanes that mark nothing
@@ -543,7 +563,13 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     const int blocks = (int)(n_calls < cap ? n_calls : cap);
     {
         Stage st("chain_dp", s);
-        hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
+        // both instances are queued; the one the job did not pick returns at once (no host round trip for the choice)
+        const char *renv = getenv("GBX_CHAIN_RING");         // test / tuning aid: "short" or "long" for every job
+        const int force = renv ? (renv[0] == 'l' ? 1 : renv[0] == 's' ? 0 : -1) : -1;
+        hipLaunchKernelGGL(chain_pick_kernel, dim3(1), dim3(64), 0, s, W, (long long)n_anchors, cus, force);
+        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3(blocks), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
+                           d_score, d_parent, d_target, d_peak, W);
+        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3(blocks), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
                            d_score, d_parent, d_target, d_peak, W);
     }
     GBX_HIP(hipGetLastError());

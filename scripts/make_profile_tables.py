@@ -30,6 +30,8 @@ def stage_name(kname):
     m = re.match(r"phmm_stream_kernel<(\d+)>", kname)
     if m:
         return "phmm_stream_rpl" + m.group(1)
+    if re.match(r"chain_kernel<\d+>", kname):
+        return "chain_dp"
     m = re.match(r"phmm_f32_kernel<(\d+)>", kname)
     if m:
         return "phmm_f32_rpl" + m.group(1)

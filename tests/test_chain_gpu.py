@@ -20,10 +20,27 @@ def assert_same(got, want):
                                  (name, int((g != w).sum()), k, g[k], w[k]))
 
 
+@pytest.mark.parametrize("ring", ["auto", "short", "long"])
 @pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg"])
-def test_goldens(name):
+def test_goldens(name, ring, monkeypatch):
+    """Both instances of the DP kernel (512- and 768-anchor ring; a job picks one on the device) against the goldens."""
+    if ring != "auto":
+        monkeypatch.setenv("GBX_CHAIN_RING", ring)
     case, g = load_chain_golden(name)
     assert_same(chain_host(*case), [g[:, 0], g[:, 1], g[:, 2], g[:, 3]])
+
+
+def test_many_short_calls_take_the_short_ring_and_long_jobs_the_long_one(monkeypatch):
+    """The device-side choice: a job as long as its longest call gets the 768-anchor ring, a job of many short calls the
+    512-anchor one (more calls in flight per CU); forced either way the four arrays are the same."""
+    case = gen_chain(2500, 77)
+    want = O.chain_oracle(*case, nthreads=8)
+    for ring in ("short", "long", None):
+        if ring:
+            monkeypatch.setenv("GBX_CHAIN_RING", ring)
+        else:
+            monkeypatch.delenv("GBX_CHAIN_RING", raising=False)
+        assert_same(chain_host(*case), want)
 
 
 @pytest.mark.parametrize("seed", [1, 2])
