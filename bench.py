@@ -544,7 +544,7 @@ class AbeaWork:
         out["ref_pos"][:] = -1                                                # touched pages, like a caller's array
         n_pairs = np.zeros(max(rs.n_reads, 1), dtype=np.int32)
         ms = []
-        for _ in range(3):
+        for _ in range(4):
             t0 = time.perf_counter()
             N.check(N.lib().gbx_abea_align_host(rs.n_reads, N.ptr(rs.seq_off), N.ptr(rs.seq_len), N.ptr(rs.seq_arena), rs.seq_arena.size,
                                                 N.ptr(rs.event_off), N.ptr(ev), N.ptr(rs.model), N.ptr(rs.scale), N.ptr(rs.shift),
