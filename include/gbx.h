@@ -302,7 +302,8 @@ typedef struct gbx_abea_pair {    /* AlignedPair, f5c.h:163-166 */
 /* Read r: bases seq_arena[seq_off[r] .. +seq_len[r]) (A/C/G/T; anything else ranks as A, align.c:10-24), events
  * [event_off[r], event_off[r+1]) of the concatenated event array, scalings scale[r], shift[r] (scalings_t, f5c.h:139-155).
  * Output: pairs of read r at out + 2*event_off[r] (the reference sizes the array 2 x n_events, f5c.c), n_pairs[r] of
- * them in ascending order, 0 when a QC rule failed (align.c:530-541).  seq_len >= KMER and >= 1 event per read. */
+ * them in ascending order, 0 when a QC rule failed (align.c:530-541); the slots of a read behind its n_pairs are
+ * unspecified.  seq_len >= KMER and >= 1 event per read. */
 int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *seq_len, const char *seq_arena,
                         int64_t seq_bytes, const int64_t *event_off, const gbx_abea_event *events,
                         const gbx_abea_model *models, const float *scale, const float *shift,

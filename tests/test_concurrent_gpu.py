@@ -7,7 +7,8 @@ import pytest
 
 from genomicsbench_amd.bsw import extend_host, make_params as bsw_params
 from genomicsbench_amd.chain import chain_host
-from genomicsbench_amd.datagen import gen_bsw, gen_chain, gen_phmm, gen_poa
+from genomicsbench_amd.abea import align_host
+from genomicsbench_amd.datagen import gen_abea, gen_bsw, gen_chain, gen_phmm, gen_poa
 from genomicsbench_amd.phmm import forward_host
 from genomicsbench_amd.poa import consensus_host, make_params as poa_params
 
@@ -22,6 +23,9 @@ def test_mixed_kernels_from_concurrent_threads():
         ("chain", lambda c=gen_chain(200, 73): chain_host(*c)),
         ("phmm", lambda s=gen_phmm(12, 74): forward_host(s)),
         ("poa", lambda w=gen_poa(40, 75): consensus_host(pp, w)),
+        # 3.8 M events: the staged path (means gathered by the upload workers, threaded copy-out); the slots behind a
+        # read's n_pairs are not part of the result
+        ("abea", lambda r=gen_abea(300, 76): (lambda o, n: (r.split_pairs(o, n), n))(*align_host(r))),
     ]
     want = [f() for _, f in jobs]
 
