@@ -443,6 +443,18 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
 
 }  // namespace
 
+// host-buffer entry: read r's pairs out + 2 * event_off[r] .. + n_pairs[r] -> packed + prefix[r] (a block per read)
+__global__ void __launch_bounds__(256) abea_pack_kernel(int n_reads, const int64_t *__restrict__ event_off, const gbx_abea_pair *__restrict__ out,
+                                                        const int32_t *__restrict__ n_pairs, const int64_t *__restrict__ prefix,
+                                                        gbx_abea_pair *__restrict__ packed)
+{
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const gbx_abea_pair *src = out + 2 * (event_off[r] - event_off[0]);
+        gbx_abea_pair *dst = packed + prefix[r];
+        for (int k = threadIdx.x; k < n_pairs[r]; k += 256) dst[k] = src[k];
+    }
+}
+
 // workspace: [256 B header: cursor, cells] [16 B per k-mer] [trace rows]
 static size_t abea_align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t abea_workspace_bytes(int64_t n_reads, int64_t n_kmers_total, int64_t n_bands_total)
@@ -458,6 +470,21 @@ int abea_read_cells(const void *d_work, int64_t *cells, hipStream_t s)
     GBX_HIP(hipMemcpyAsync(&v, (const char *)d_work + 8, sizeof(v), hipMemcpyDeviceToHost, s));
     GBX_HIP(hipStreamSynchronize(s));
     *cells = (int64_t)v;
+    return GBX_OK;
+}
+
+int abea_pack_pairs(int64_t n_reads, const int64_t *d_event_off, const gbx_abea_pair *d_out, const int32_t *d_n_pairs,
+                    const int64_t *d_prefix, void *d_work, int64_t n_kmers_total, gbx_abea_pair **d_packed, hipStream_t s)
+{
+    const size_t nk = (size_t)n_kmers_total + 64;
+    gbx_abea_pair *packed = (gbx_abea_pair *)((char *)d_work + 256 + abea_align_up(nk * 16));      // the trace area (64 B per band >> 8 B per pair)
+    *d_packed = packed;
+    if (n_reads == 0) return GBX_OK;
+    {
+        Stage st("abea_pack", s);
+        hipLaunchKernelGGL(abea_pack_kernel, dim3((unsigned)(n_reads < 16384 ? n_reads : 16384)), dim3(256), 0, s, (int)n_reads, d_event_off, d_out, d_n_pairs, d_prefix, packed);
+    }
+    GBX_HIP(hipGetLastError());
     return GBX_OK;
 }
 

@@ -1104,8 +1104,37 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
                      n_kmers_total, band_off[(size_t)n_reads], dout.as<gbx_abea_pair>(), dnp.as<int32_t>(), dw.p, wb, lane.l->compute);
     if (rc) return pipe.finish(rc);
     // the caller's pair array is indexed by its own event_off (out + 2*event_off[r])
-    pipe.fetch(0, out + 2 * e0, dout.p, (size_t)n_ev * 2 * sizeof(gbx_abea_pair));
-    pipe.fetch(0, n_pairs, dnp.p, n_reads * 4);
+    std::vector<HostPipe::Seg> segs;
+    std::vector<int64_t> prefix;
+    DevBuf dpre(L);
+    if (pipe.staged) {
+        // large calls: half of the 2 x n_events slots are slack, so the counts come first (the calling thread waits for the
+        // kernel here instead of in finish()), the pairs are packed on the device and their download is scattered to
+        // the reads' places by the copy-out threads
+        GBX_HIP(hipMemcpyAsync(n_pairs, dnp.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, lane.l->compute));
+        GBX_HIP(hipStreamSynchronize(lane.l->compute));
+        mark("kernel done, counts on the host");
+        prefix.resize((size_t)n_reads + 1);
+        segs.resize((size_t)n_reads);
+        int64_t tot = 0;
+        for (int64_t r = 0; r < n_reads; ++r) {
+            prefix[(size_t)r] = tot;
+            const int64_t np = n_pairs[r] > 0 ? n_pairs[r] : 0;
+            segs[(size_t)r] = HostPipe::Seg{(char *)(out + 2 * event_off[r]), (size_t)np * sizeof(gbx_abea_pair)};
+            tot += np;
+        }
+        prefix[(size_t)n_reads] = tot;
+        if ((rc = dpre.alloc((size_t)(n_reads + 1) * 8))) return pipe.finish(rc);
+        GBX_HIP(hipMemcpyAsync(dpre.p, prefix.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, lane.l->compute));
+        gbx_abea_pair *packed = nullptr;
+        if ((rc = abea_pack_pairs(n_reads, deo.as<int64_t>(), dout.as<gbx_abea_pair>(), dnp.as<int32_t>(), dpre.as<int64_t>(), dw.p,
+                                  n_kmers_total, &packed, lane.l->compute)))
+            return pipe.finish(rc);
+        if (tot) pipe.fetch_scatter(0, packed, (size_t)tot * sizeof(gbx_abea_pair), &segs);
+    } else {
+        pipe.fetch(0, out + 2 * e0, dout.p, (size_t)n_ev * 2 * sizeof(gbx_abea_pair));
+        pipe.fetch(0, n_pairs, dnp.p, n_reads * 4);
+    }
     if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
     mark("kernel queued");
     rc = pipe.finish();

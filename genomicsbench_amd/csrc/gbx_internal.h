@@ -92,6 +92,10 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
 // ---- abea (abea_kernels.hip)
 size_t abea_workspace_bytes(int64_t n_reads, int64_t n_kmers_total, int64_t n_bands_total);
 int abea_read_cells(const void *d_work, int64_t *cells, hipStream_t s);
+// after abea_launch: the aligned pairs of all reads packed back to back (read r's n_pairs[r] pairs at d_prefix[r]) into the
+// workspace's trace area, which is free by then; returns where
+int abea_pack_pairs(int64_t n_reads, const int64_t *d_event_off, const gbx_abea_pair *d_out, const int32_t *d_n_pairs,
+                    const int64_t *d_prefix, void *d_work, int64_t n_kmers_total, gbx_abea_pair **d_packed, hipStream_t s);
 int abea_launch(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_len, const char *d_seq,
                 const int64_t *d_event_off, const float *d_event_mean, const gbx_abea_model *d_models,
                 const float *d_scale, const float *d_shift, const int64_t *d_band_off, const int32_t *d_order,

@@ -216,7 +216,9 @@ struct DevBuf {
 struct HostPipe {
     // pack: len source bytes -> (len+1)/2 at dst; stride != 0: len / 4 four-byte fields, `stride` bytes apart at src, -> len bytes
     struct Piece { char *dst; const char *src; size_t len; int chunk; bool pack; int stride; };
-    struct Fetch { void *dst; const void *src; size_t len; int chunk; };
+    // a contiguous device range -> one host range, or (segs) -> consecutive pieces of it to different host addresses
+    struct Seg { char *dst; size_t len; };
+    struct Fetch { void *dst; const void *src; size_t len; int chunk; const std::vector<Seg> *segs; };
     Lane *L;
     bool staged;
     int workers;
@@ -357,6 +359,31 @@ struct HostPipe {
         memcpy(dst, src, per < len ? per : len);
         for (auto &x : th) x.join();
     }
+    // slab bytes [0, len) = bytes [pos, pos + len) of a packed stream -> the segments they belong to (cursor: first segment
+    // not yet complete and the bytes of it already delivered)
+    void copy_out_scatter(const char *slab, size_t len, const std::vector<Seg> &segs, size_t &si, size_t &so)
+    {
+        struct Job { char *dst; const char *src; size_t n; };
+        std::vector<Job> jobs;
+        size_t off = 0;
+        while (off < len && si < segs.size()) {
+            const size_t n = segs[si].len - so < len - off ? segs[si].len - so : len - off;
+            if (n) jobs.push_back(Job{segs[si].dst + so, slab + off, n});
+            off += n; so += n;
+            if (so == segs[si].len) { ++si; so = 0; }
+        }
+        const int T = workers < 6 ? workers : 6;
+        if (len < ((size_t)2 << 20) || T <= 1) { for (const Job &j : jobs) memcpy(j.dst, j.src, j.n); return; }
+        std::vector<std::thread> th;
+        const size_t per = (jobs.size() + (size_t)T - 1) / (size_t)T;
+        for (int t = 1; t < T; ++t) {
+            const size_t a = per * (size_t)t, b = a + per < jobs.size() ? a + per : jobs.size();
+            if (a >= b) break;
+            th.emplace_back([&jobs, a, b] { for (size_t k = a; k < b; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n); });
+        }
+        for (size_t k = 0; k < per && k < jobs.size(); ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n);
+        for (auto &x : th) x.join();
+    }
     hipError_t fetch_chunk(int64_t c)
     {
         RoctxRange range_("gbx:d2h chunk (wait for the chunk's kernels + DMA + copy out)");
@@ -389,6 +416,12 @@ struct HostPipe {
         }
         const size_t HALF = Lane::DOWN / 2;
         char *pend_dst = nullptr; size_t pend_len = 0; int half = 0;
+        const std::vector<Seg> *pend_segs = nullptr;
+        size_t si = 0, so = 0;                                 // cursor of the scatter plan being delivered
+        auto deliver = [&](int h) {
+            if (pend_segs) copy_out_scatter(L->dslab + h * HALF, pend_len, *pend_segs, si, so);
+            else copy_out(pend_dst, L->dslab + h * HALF, pend_len);
+        };
         for (const Fetch &f : mine) {
             char *d = (char *)f.dst;
             const char *s = (const char *)f.src;
@@ -398,15 +431,17 @@ struct HostPipe {
                 if ((e = hipEventRecord(L->ev_half[half], xfer)) != hipSuccess) return e;
                 if (pend_len) {
                     if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
-                    copy_out(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
+                    deliver(half ^ 1);
                 }
-                pend_dst = d; pend_len = len; half ^= 1;
-                d += len; s += len; left -= len;
+                if (f.segs && pend_segs != f.segs) { si = 0; so = 0; }      // (the plan's first piece: after the previous delivery)
+                pend_dst = d; pend_len = len; pend_segs = f.segs; half ^= 1;
+                if (d) d += len;
+                s += len; left -= len;
             }
         }
         if (pend_len) {
             if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
-            copy_out(pend_dst, L->dslab + (half ^ 1) * HALF, pend_len);
+            deliver(half ^ 1);
         }
         return hipSuccess;
     }
@@ -468,7 +503,14 @@ struct HostPipe {
     void fetch(int64_t c, void *host_dst, const void *dev_src, size_t bytes)
     {
         std::lock_guard<std::mutex> lk(mu);
-        fetches.push_back(Fetch{host_dst, dev_src, bytes, (int)c});
+        fetches.push_back(Fetch{host_dst, dev_src, bytes, (int)c, nullptr});
+    }
+    // a packed result array of chunk c whose consecutive pieces go to different places in the caller's memory (abea: a
+    // read's pairs).  segs must stay alive until finish(); their lengths add up to bytes.  Staged calls only.
+    void fetch_scatter(int64_t c, const void *dev_src, size_t bytes, const std::vector<Seg> *segs)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        fetches.push_back(Fetch{nullptr, dev_src, bytes, (int)c, segs});
     }
     // the events a launch function records when chunk c's kernels are queued (one per stream they run on)
     hipEvent_t *join_events(int64_t c) { return &L->ev_chunk[(size_t)c * Lane::JOIN_EVENTS]; }
