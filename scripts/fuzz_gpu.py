@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity run on the GPU: host entries of the four kernels against the oracle on random jobs of random
+"""Randomised parity run on the GPU: host entries of the five kernels against the oracle on random jobs of random
 sizes (small-job modes, class modes, staged and packed transfers all get hit).  usage: fuzz_gpu.py [seconds] [seed]"""
 import os
 import sys
@@ -13,7 +13,8 @@ from cases import adversarial_bsw  # noqa: E402
 from genomicsbench_amd import _native as N  # noqa: E402
 from genomicsbench_amd.bsw import extend_host, fill_scmat, make_params as bsw_params  # noqa: E402
 from genomicsbench_amd.chain import chain_host  # noqa: E402
-from genomicsbench_amd.datagen import gen_bsw, gen_chain, gen_phmm, gen_poa  # noqa: E402
+from genomicsbench_amd.abea import align_host  # noqa: E402
+from genomicsbench_amd.datagen import gen_abea, gen_bsw, gen_chain, gen_phmm, gen_poa  # noqa: E402
 from genomicsbench_amd.phmm import forward_host  # noqa: E402
 from genomicsbench_amd.poa import consensus_host, make_params as poa_params  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
@@ -22,9 +23,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N.check(N.lib().gbx_host_prepare())
 t_end = time.time() + budget
-count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0}
+count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0}
 while time.time() < t_end:
-    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa"])
+    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea"])
     seed = int(rng.integers(1, 1 << 30))
     if k == "bsw":
         n = int(rng.choice([1, 7, 64, 513, 4000, 16384, 16385, 40000, 260000]))
@@ -49,6 +50,17 @@ while time.time() < t_end:
         got = forward_host(bs)
         ok = bool(np.all(np.abs(got - want) <= 1e-5 * np.maximum(1, np.abs(want)) + 5e-7))
         what = "batches=%d pairs=%d" % (nb, bs.n_pairs)
+    elif k == "abea":
+        nr = int(rng.choice([1, 3, 24, 150, 700]))             # 700 reads: the staged transfers and the packed download
+        rs = gen_abea(nr, seed % 100000, first=int(rng.integers(0, 5000)))
+        if rng.random() < 0.3:                                   # push some reads out of the fast-division range
+            ev = rs.event_mean
+            for r in rng.choice(nr, size=max(1, nr // 4), replace=False):
+                a, b = int(rs.event_off[r]), int(rs.event_off[r + 1])
+                ev[a + int(rng.integers(0, b - a))] = np.float32(rng.choice([1e-30, 3e13, 0.0]))
+        (go, gn), (wo, wn) = align_host(rs), O.abea_oracle(rs, 16)
+        ok = np.array_equal(gn, wn) and all(np.array_equal(g, w) for g, w in zip(rs.split_pairs(go, gn), rs.split_pairs(wo, wn)))
+        what = "reads=%d" % nr
     else:
         nw = int(rng.choice([1, 5, 40]))
         ws = gen_poa(nw, seed)
