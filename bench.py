@@ -734,6 +734,54 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     return line
 
 
+def launch_plan(args, argv):
+    """argv + environment of every rank a plain `python bench.py --gpus N` starts (one process per GPU, rendezvous on
+    127.0.0.1, the same variables torch.distributed.run sets).  Pure: no torch, no GPU."""
+    import socket
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    child_argv = [a for a in argv if a != "--launch-dry-run"]
+    base = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(args.gpus),
+            "LOCAL_WORLD_SIZE": str(args.gpus), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    # rank 0 generates and cuts the whole dataset (OpenMP generator) and runs the checks: it gets the host's cores
+    cores = os.cpu_count() or 1
+    return [{"argv": [sys.executable, os.path.abspath(__file__)] + child_argv,
+             "env": dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0",
+                         OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(cores if r == 0 else 4)))}
+            for r in range(args.gpus)]
+
+
+def self_launch(args, argv):
+    """Parent of a self-launched run: starts the ranks as children, relays rank 0's stdout (the JSON line) and every
+    rank's stderr, returns the worst child return code; when one rank fails the others are terminated (by PID)."""
+    import subprocess
+    plan = launch_plan(args, argv)
+    if args.launch_dry_run:
+        print(json.dumps({"launch": plan}), flush=True)
+        return 0
+    procs = []
+    for r, p in enumerate(plan):
+        env = dict(os.environ)
+        env.update(p["env"])
+        procs.append(subprocess.Popen(p["argv"], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0:
+                rc = rc or (code if code > 0 else 128 - code)
+                for other in live:                         # a dead rank leaves the others in a collective: stop them
+                    other.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -748,20 +796,52 @@ def main():
     ap.add_argument("--verify-units", type=int, default=0, help="units per shard checked against the oracle after the gather")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of chain / phmm / poa / abea in the all-kernel run")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="print the argv / environment of the ranks `--gpus N` would start, start nothing")
+    ap.add_argument("--launch-echo", action="store_true",
+                    help="launcher self-test without GPUs: the ranks rendezvous over gloo, all-reduce their ranks, rank 0 "
+                         "prints one JSON line (tests/test_bench_launch.py); --launch-echo-fail R makes rank R exit 7")
+    ap.add_argument("--launch-echo-fail", type=int, default=-1)
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched ranks (0 = a free one)")
     args = ap.parse_args()
     if args.pairs:
         args.size = args.pairs
 
+    # ---- self-launch: `python bench.py --gpus N` with no rank environment starts its own N ranks.  This happens BEFORE
+    # torch.cuda / libgbx are imported and before any GPU call: the parent never touches the GPU, the ranks are child
+    # processes (never an exec of a process that initialised HIP), rank 0's JSON line is relayed and the children's worst
+    # return code is ours.
+    if "RANK" not in os.environ and (args.gpus > 1 or args.launch_dry_run):
+        sys.exit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node %d, or run plain "
+                         "`python bench.py --gpus %d`, which starts its own ranks)" % (world, args.gpus, args.gpus, args.gpus))
 
+    if rank == 0 and world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+        # torch.distributed.run pins every rank to one OpenMP thread; rank 0 generates N x 'large' with the OpenMP
+        # generator and runs the oracle checks, outside every timed region: give it the cores back (before libgomp loads)
+        os.environ["OMP_NUM_THREADS"] = str(os.cpu_count() or 1)
     import torch
     import torch.distributed as dist
     global S
     from genomicsbench_amd import shard as S
 
+    if args.launch_echo:
+        if rank == args.launch_echo_fail:
+            sys.exit(7)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_echo": True, "world": world, "rank_sum": float(t.item()),
+                              "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libgbx has no CPU path)")
     # GBX_BENCH_COMM=gloo is a TEST AID for boxes with fewer GPUs than ranks (the builder's 1-GPU box): ranks share

@@ -1,0 +1,73 @@
+"""bench.py --gpus N starts its own ranks: the launcher is proven here without GPUs.
+
+The parent must not import torch.cuda / libgbx, must start N children with the rank environment, relay rank 0's JSON line
+and return a non-zero code when any rank fails."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    return env
+
+
+def test_dry_run_prints_one_child_per_gpu():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "3", "--warmup", "1", "--launch-dry-run"],
+                       capture_output=True, text=True, env=_env(), timeout=120)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert len(plan) == 8
+    ports = {p["env"]["MASTER_PORT"] for p in plan}
+    assert len(ports) == 1
+    for rank, p in enumerate(plan):
+        assert p["argv"][1] == BENCH and p["argv"][2:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+        e = p["env"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"]) == (str(rank), str(rank), "8", "127.0.0.1")
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_parent_never_loads_torch_or_libgbx():
+    code = ("import sys, runpy\n"
+            "sys.argv = ['bench.py', '--gpus', '2', '--launch-dry-run']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert not e.code, e.code\n"
+            "assert 'torch' not in sys.modules and 'genomicsbench_amd._native' not in sys.modules, 'parent touched torch/libgbx'\n"
+            % BENCH)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=_env(), timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+
+
+def test_self_launch_two_ranks_relays_rank0_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-echo"], capture_output=True, text=True, env=_env(),
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # rank 1's stdout is not relayed
+    line = json.loads(lines[0])
+    assert line["launch_echo"] and line["world"] == 2 and line["rank_sum"] == 1.0
+
+
+def test_failing_rank_fails_the_launch():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-echo", "--launch-echo-fail", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr)
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    env = dict(_env(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in r.stderr
+
+
+def test_torchrun_launch_still_works():
+    """The driver's own launch shape for N > 1 (python -m torch.distributed.run ... bench.py --gpus N)."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", BENCH, "--gpus", "2", "--launch-echo"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world"] == 2 and line["omp_num_threads"] == str(os.cpu_count())
