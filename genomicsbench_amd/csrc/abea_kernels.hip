@@ -92,7 +92,13 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
     const float NINF = ABEA_NEG_INF;
     const int NINF_BITS = (int)0xff800000u;
     const bool lane_in = lane < BW / 2;                                   // both of the lane's offsets are < BW
-    unsigned long long fills = 0, cyc_pre = 0, cyc_dp = 0, cyc_tb = 0, cyc_p2 = 0, steps = 0;
+    unsigned long long fills = 0;
+#ifdef GBX_ABEA_PHASE_STATS                                                    // development aid, scripts/dbg_abea_phases.py
+    unsigned long long cyc_pre = 0, cyc_dp = 0, cyc_tb = 0, cyc_p2 = 0, steps = 0;
+#define ABEA_STAMP(t) const unsigned long long t = __builtin_readcyclecounter()
+#else
+#define ABEA_STAMP(t) do { } while (0)
+#endif
     for (;;) {
         unsigned q = 0;
         if (lane == 0) q = atomicAdd(A.cursor, 1u);
@@ -105,7 +111,7 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         else if (q < 2 * A.prio_cut) __builtin_amdgcn_s_setprio(2);
         else if (q < 3 * A.prio_cut) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
-        const unsigned long long t0 = __builtin_readcyclecounter();
+        ABEA_STAMP(t0);
         const char *seq = A.seq + A.seq_off[r];
         const int n_kmers = A.seq_len[r] - KSZ + 1;
         const int64_t ev0 = A.event_off[r];
@@ -142,7 +148,7 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const unsigned long long t1 = __builtin_readcyclecounter();
+        ABEA_STAMP(t1);
         // ---- bands 0 and 1 (:264-279)
         int e_b = BW / 2 - 1, k_b = -1 - BW / 2;                 // lower-left corner of band 0
         const int oA = 2 * lane, oB = 2 * lane + 1;
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const unsigned long long t2 = __builtin_readcyclecounter();
+        ABEA_STAMP(t2);
         // ---- traceback (:409-500), in two passes.
         // (1) The walk: serial, wave-uniform, on the scalar unit but for one v_readlane per step.  A 16-band trace block
         // is four registers per lane (lane = column, register = 4 bands, byte = band); four blocks are resident and a
@@ -378,7 +384,7 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long t2b = __builtin_readcyclecounter();
+        ABEA_STAMP(t2b);
         // (2) 64 records at a time, a lane per record: where each block's walk started (a scan of the moves), its pairs
         // into the caller's array in reverse (std::reverse, :502), the emissions of its steps - and then their sum
         // in the order of the walk (:448-449; a double sum of floats, so the order is part of the result).  The
@@ -431,13 +437,17 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         bool ok = n_out >= 1 && fits && last_ck == 0;
         ok = ok && !(avg_log_emission < -5.0) && !(max_gap > 50);
         if (lane == 0) A.n_pairs[r] = ok ? n_out : 0;
-        const unsigned long long t3 = __builtin_readcyclecounter();
+        ABEA_STAMP(t3);
+#ifdef GBX_ABEA_PHASE_STATS
         cyc_pre += t1 - t0; cyc_dp += t2 - t1; cyc_tb += t2b - t2; cyc_p2 += t3 - t2b; steps += (unsigned long long)n_out;
+#endif
     }
     if (lane == 0) {
         atomicAdd(A.cells, fills);
+#ifdef GBX_ABEA_PHASE_STATS
         atomicAdd(A.cells + 1, cyc_pre); atomicAdd(A.cells + 2, cyc_dp); atomicAdd(A.cells + 3, cyc_tb);   // s_memtime ticks, summed over wavefronts
         atomicAdd(A.cells + 4, cyc_p2); atomicAdd(A.cells + 5, steps);
+#endif
     }
 }
 
@@ -449,7 +459,7 @@ __global__ void __launch_bounds__(256) abea_pack_kernel(int n_reads, const int64
                                                         gbx_abea_pair *__restrict__ packed)
 {
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
-        const gbx_abea_pair *src = out + 2 * (event_off[r] - event_off[0]);
+        const gbx_abea_pair *src = out + 2 * event_off[r];              // the same absolute indexing as abea_kernel
         gbx_abea_pair *dst = packed + prefix[r];
         for (int k = threadIdx.x; k < n_pairs[r]; k += 256) dst[k] = src[k];
     }
@@ -529,7 +539,7 @@ int abea_launch(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_
 
 }  // namespace gbx
 
-// development aid (scripts/dbg_abea_phases.py): s_memtime ticks the wavefronts of the last launch spent in the per-k-mer
+// development aid (scripts/dbg_abea_phases.py; build with EXTRA=-DGBX_ABEA_PHASE_STATS, zeros otherwise): s_memtime ticks the wavefronts of the last launch spent in the per-k-mer
 // prologue, the band loop, the traceback walk and its second pass, and the number of traceback steps
 extern "C" int gbx_debug_abea_ticks(const void *d_work, unsigned long long *out5)
 {

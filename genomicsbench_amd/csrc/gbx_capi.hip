@@ -1111,8 +1111,11 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
         // large calls: half of the 2 x n_events slots are slack, so the counts come first (the calling thread waits for the
         // kernel here instead of in finish()), the pairs are packed on the device and their download is scattered to
         // the reads' places by the copy-out threads
-        GBX_HIP(hipMemcpyAsync(n_pairs, dnp.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, lane.l->compute));
-        GBX_HIP(hipStreamSynchronize(lane.l->compute));
+        // (an asynchronous fault of abea_kernel surfaces at this synchronize: every error leaves through pipe.finish(),
+        // which cancels the downloader thread - a bare return here would leave it waiting for chunk 0 for ever)
+        hipError_t he = hipMemcpyAsync(n_pairs, dnp.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, lane.l->compute);
+        if (he == hipSuccess) he = hipStreamSynchronize(lane.l->compute);
+        if (he != hipSuccess) return pipe.finish(hip_fail(he, "gbx_abea_align_host: kernel / pair counts"));
         mark("kernel done, counts on the host");
         prefix.resize((size_t)n_reads + 1);
         segs.resize((size_t)n_reads);
@@ -1125,7 +1128,8 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
         }
         prefix[(size_t)n_reads] = tot;
         if ((rc = dpre.alloc((size_t)(n_reads + 1) * 8))) return pipe.finish(rc);
-        GBX_HIP(hipMemcpyAsync(dpre.p, prefix.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, lane.l->compute));
+        he = hipMemcpyAsync(dpre.p, prefix.data(), (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, lane.l->compute);
+        if (he != hipSuccess) return pipe.finish(hip_fail(he, "gbx_abea_align_host: pair prefix upload"));
         gbx_abea_pair *packed = nullptr;
         if ((rc = abea_pack_pairs(n_reads, deo.as<int64_t>(), dout.as<gbx_abea_pair>(), dnp.as<int32_t>(), dpre.as<int64_t>(), dw.p,
                                   n_kmers_total, &packed, lane.l->compute)))

@@ -251,7 +251,14 @@ struct HostPipe {
         : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
           xfer(overlap ? l->copy : l->compute),
           packed(!staged && l->staged_ready && total_bytes <= Lane::PIECE / 2 && !getenv("GBX_HOST_PAGEABLE")) {}
-    ~HostPipe() { (void)finish(); }
+    // an early return between start() and the last chunk_launched() must not leave the downloader waiting for a chunk
+    // that will never be launched: such a pipe is cancelled, not finished
+    ~HostPipe()
+    {
+        bool unlaunched;
+        { std::lock_guard<std::mutex> lk(mu); unlaunched = started && staged && launched < n_chunks; }
+        (void)finish(unlaunched ? GBX_ERR_HIP : GBX_OK);
+    }
 
     int prepare(int64_t chunks)
     {
@@ -374,14 +381,22 @@ struct HostPipe {
         }
         const int T = workers < 6 ? workers : 6;
         if (len < ((size_t)2 << 20) || T <= 1) { for (const Job &j : jobs) memcpy(j.dst, j.src, j.n); return; }
+        // shares of equal BYTES (a few long reads in one thread's share would serialise the copy): cut[t] = first job of share t
         std::vector<std::thread> th;
-        const size_t per = (jobs.size() + (size_t)T - 1) / (size_t)T;
+        std::vector<size_t> cut((size_t)T + 1, jobs.size());
+        cut[0] = 0;
+        size_t acc = 0;
+        int t_next = 1;
+        for (size_t k = 0; k < jobs.size() && t_next < T; ++k) {
+            if (acc >= len * (size_t)t_next / (size_t)T) cut[(size_t)t_next++] = k;
+            acc += jobs[k].n;
+        }
         for (int t = 1; t < T; ++t) {
-            const size_t a = per * (size_t)t, b = a + per < jobs.size() ? a + per : jobs.size();
-            if (a >= b) break;
+            const size_t a = cut[(size_t)t], b = cut[(size_t)t + 1];
+            if (a >= b) continue;
             th.emplace_back([&jobs, a, b] { for (size_t k = a; k < b; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n); });
         }
-        for (size_t k = 0; k < per && k < jobs.size(); ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n);
+        for (size_t k = 0; k < cut[1]; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n);
         for (auto &x : th) x.join();
     }
     hipError_t fetch_chunk(int64_t c)
@@ -414,7 +429,11 @@ struct HostPipe {
                     return e;
             return hipStreamSynchronize(xfer);
         }
-        const size_t HALF = Lane::DOWN / 2;
+        size_t HALF = Lane::DOWN / 2;
+        if (const char *env = getenv("GBX_HOST_DOWN_PIECE")) {      /* bytes; the tests shrink it so that small jobs span pieces */
+            const size_t v = (size_t)atoll(env) & ~(size_t)63;
+            if (v >= 64 && v < HALF) HALF = v;
+        }
         char *pend_dst = nullptr; size_t pend_len = 0; int half = 0;
         const std::vector<Seg> *pend_segs = nullptr;
         size_t si = 0, so = 0;                                 // cursor of the scatter plan being delivered

@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 
     unsigned long long cells = 0;
 #ifdef GBX_POA_PHASE_STATS
-    unsigned long long t_dp = 0, t_tb = 0, t_add = 0, t_cons = 0;
+    unsigned long long t_dp = 0, t_tb = 0, t_add = 0, t_cons = 0, n_rows = 0, n_steps = 0;
 #define PH_T0 unsigned long long ph0_ = __builtin_readcyclecounter();
 #define PH_ACC(x) { unsigned long long ph1_ = __builtin_readcyclecounter(); x += ph1_ - ph0_; ph0_ = ph1_; }
 #else
@@ -1249,6 +1249,9 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                 else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
+#ifdef GBX_POA_PHASE_STATS
+                n_rows += (unsigned long long)g.n_nodes; n_steps += (unsigned long long)g.n_path;
+#endif
             }
             {
                 PH_T0
@@ -1268,7 +1271,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     }
     if ((threadIdx.x & 63) == 0) atomicAdd(A.cells, cells);
 #ifdef GBX_POA_PHASE_STATS
-    if ((threadIdx.x & 63) == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); atomicAdd(A.cells + 12, n_rows); atomicAdd(A.cells + 13, n_steps); }
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
         A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;

@@ -313,7 +313,9 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
  * (band_off[n_reads+1], in bands), the processing order (longest first) and the two read-dependent transition
  * penalties, which are double logarithms (align.c:195-204) and are taken with the host C library so that they are the
  * reference's bits; the device entry takes the compact float array of event means.  n_kmers_total = sum of
- * seq_len - KMER + 1, n_bands_total = band_off[n_reads]. */
+ * seq_len - KMER + 1, n_bands_total = band_off[n_reads].
+ * Indexing of the device entry: ABSOLUTE - read r's means are d_event_mean[d_event_off[r] ..], its pairs are written at
+ * d_out + 2*d_event_off[r]; d_event_off[0] need not be 0 (both arrays must then reach up to d_event_off[n_reads]). */
 int gbx_abea_plan_host(int64_t n_reads, const int32_t *seq_len, const int64_t *event_off,
                        int64_t *band_off, int32_t *order, double *lp /* [n_reads][2]: lp_stay, lp_step, align.c:195-204 */);
 size_t gbx_abea_workspace_bytes(int64_t n_reads, int64_t n_kmers_total, int64_t n_bands_total);

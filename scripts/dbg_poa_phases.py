@@ -22,3 +22,7 @@ print("%d windows %.1f ms; wave clocks: DP %.1f%%  traceback %.1f%%  add_alignme
 roots, triv = int(c[10]), int(c[11])
 print("sort roots per node %.3f, single-visit roots per node %.3f" % (roots / max(topo_n, 1), triv / max(topo_n, 1)))
 print("sort: %.0f clocks per node, %.2f visits per node, %.3f block loads per node" % (topo / max(topo_n, 1), vis / max(topo_n, 1), blk / max(topo_n, 1)))
+rows, steps = int(c[12]), int(c[13])
+if rows:
+    print("DP: %d rows, %.0f wave clocks per row; traceback: %d steps, %.0f clocks per step; add_alignment without the sort: %.0f clocks per path element"
+          % (rows, dp / rows, steps, tb / max(steps, 1), (add - topo) / max(steps, 1)))

@@ -97,3 +97,19 @@ def test_reads_outside_the_fast_division_range():
     scale[10] = np.float32(1e-14)                           # scaled means of read 10 become ~1e-12 < 2^-40
     rs2 = AbeaReadSet(rs.seq_off, rs.seq_len, rs.seq_arena, rs.event_off, ev, scale, rs.shift, rs.model)
     assert_same(rs2, align_host(rs2), O.abea_oracle(rs2, 8))
+
+
+def test_staged_host_entry_scatters_every_read(monkeypatch):
+    """The staged branch of gbx_abea_align_host (stage_field4 gather in the upload workers, abea_pack_kernel,
+    HostPipe::fetch_scatter): forced on a small job, with reads that produce no pairs (failed QC) among the others and
+    enough pairs to span several download pieces, every read compared with the oracle."""
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    monkeypatch.setenv("GBX_HOST_DOWN_PIECE", str(1 << 16))       # small pieces: the scatter cursor carries across them
+    rs = gen_abea(96, 77, first=300)
+    rng = np.random.default_rng(5)
+    for r in (3, 4, 50, 95):                                      # garbage signal: QC rejects the read, n_pairs == 0
+        a, b = int(rs.event_off[r]), int(rs.event_off[r + 1])
+        rs.event_mean[a:b] = rng.uniform(20, 200, b - a).astype(np.float32)
+    want = O.abea_oracle(rs, 8)
+    assert (want[1][[3, 4, 50, 95]] == 0).all() and (want[1] > 0).sum() > 80
+    assert_same(rs, align_host(rs), want)

@@ -91,7 +91,7 @@ def test_abea_large_all_reads():
     from genomicsbench_amd.abea import DeviceAbeaReadSet
     from genomicsbench_amd.datagen import gen_abea
     from oracle import oracle_py as O
-    rs = gen_abea(4096, 5001)
+    rs = gen_abea(10_000, 5001)                      # the whole 'large' job of bench.py, longest reads included
     d = DeviceAbeaReadSet(rs, torch.device("cuda:0"))
     d.run(_stream())
     torch.cuda.synchronize()
