@@ -46,6 +46,8 @@ struct BswDev {
     uint32_t row0[5];      // row0[t]    = bytes mat[t][0], mat[t][1], mat[t][2], mat[t][3]
     uint32_t row1[5];      // row1[t]    = byte  mat[t][4]
     uint8_t remap[24];     // query class -> the class whose kernel runs it (identity, or a wider class for small jobs)
+    uint32_t lrow[5];      // lane path: lrow[t] = mat[t][q] as five signed 6-bit fields at bit 6q (read with one v_bfe_i32)
+    int lane_on;           // 1: pairs that qualify (lane_ok) run on bsw_lane_kernel, one pair per lane
 };
 
 struct BswPairs {
@@ -60,6 +62,10 @@ struct BswPairs {
 constexpr int WS_HDR = 4 * HDR;
 struct BswWork {
     int32_t *counts, *cursors, *base, *bad, *order, *wband;
+    // lane path (bsw_lane_kernel): pairs sorted by (query length, seed score): lbase[] = exclusive prefix of the key
+    // histogram (LANE_BINS + 1 entries), lcur[] = scatter cursors, lorder[] = sorted pair indices, lchunk[] = per-launch
+    // chunk cursors
+    int32_t *lbase, *lcur, *lorder, *lchunk;
 };
 
 __host__ __device__ inline int cls_of(int qlen, int bound)
@@ -69,6 +75,28 @@ __host__ __device__ inline int cls_of(int qlen, int bound)
     if (qlen <= 128) return (qlen - 1) >> 3;          // 8 columns per class: a pair wastes at most 7
     return qlen <= 160 ? 16 : qlen <= 192 ? 17 : 18;
 }
+// ---- lane path: one pair per LANE ------------------------------------------------------------------------------
+// Sort key of a pair = (qlen, min(h0, 255)): the live window of a row is a function of the row, the query length and
+// the seed score far more than of the bases, so the 64 pairs of a wavefront taken from consecutive keys sweep nearly
+// the same columns in every row (measured on 'large': 97 % of the lane-iterations do live work).
+constexpr int LANE_QMAX = 159;                       // longest query on the lane path
+constexpr int LANE_ROWS = 2 * (LANE_QMAX + 1);       // key rows: format (0 = compact cells, 1 = wide) x query length
+constexpr int LANE_BINS = LANE_ROWS * 256;
+constexpr int LANE_SCORE_LIMIT = 8192;               // wide cell word = h:14 | e:13 | query code x 6 : 5
+constexpr int LANE_COMPACT_LIMIT = 256;              // compact cell = h:8 | e:8, query code in a byte plane
+constexpr int LANE_NRANGE = 5;
+// query-length ranges of the launches = LDS classes: compact 16, 10, 8, 6, 5 wavefronts per CU, wide 15, 7, 5, 4, 3
+constexpr int LANE_RANGE_HI[2][LANE_NRANGE] = {{48, 80, 101, 137, LANE_QMAX}, {39, 79, 103, 127, LANE_QMAX}};
+__host__ __device__ inline bool lane_ok(int lane_on, int qlen, int tlen, int h0, int max_mat)
+{
+    return lane_on && qlen >= 1 && qlen <= LANE_QMAX && tlen >= 1 && h0 >= 0 && h0 + qlen * (max_mat > 0 ? max_mat : 0) < LANE_SCORE_LIMIT;
+}
+__host__ __device__ inline int lane_key(int qlen, int h0, int max_mat)
+{
+    const int wide = h0 + qlen * (max_mat > 0 ? max_mat : 0) < LANE_COMPACT_LIMIT ? 0 : 1;
+    return ((wide * (LANE_QMAX + 1) + qlen) << 8) | (h0 < 255 ? h0 : 255);
+}
+
 __host__ __device__ inline int bin_of(int cls, int tlen)
 {
     const int tb = tlen >> 4;
@@ -196,6 +224,8 @@ __global__ void __launch_bounds__(CLS_THREADS) bsw_classify_kernel(BswDev prm, B
                 else { int left = max(h0 - (prm.o_del + prm.e_del), 0); r.gtle = 1; r.gscore = max(-1, left); }
                 P.out[k] = r;
             }
+        } else if (lane_ok(prm.lane_on, qlen, tlen, h0, prm.max_mat)) {
+            // bsw_lane_kernel's pair (sorted by bsw_lane_sort_kernel)
         } else {
             const int bound = max(h0, 0) + qlen * max(prm.max_mat, 0);
             bin = bin_of(prm.remap[cls_of(qlen, bound)], tlen);
@@ -537,6 +567,197 @@ __global__ void __launch_bounds__(64) bsw_lds_kernel(BswDev prm, BswPairs P, Bsw
     }
 }
 
+// ---- one pair per lane --------------------------------------------------------------------------------------
+// The row kernels above give a pair 2-64 lanes and pay for it twice on the 151-bp workload: 45 % of the columns they
+// compute lie outside the live window (a lane owns fixed columns), and a third of their instructions are window masks,
+// scans and reductions.  Measured instruction rates (profiles/valu_peak.json) say the rest cannot be bought back by
+// recoding: max / max3 / DPP / SDWA / compare / select all issue at one wave64 instruction per 4 cycles.
+// Here a LANE owns a pair and walks its own window [beg, end) of every row, exactly as scalarBandedSWA
+// (bandedSWA.cpp:128-249) does: no dead columns, no masks, no cross-lane traffic at all.  The eh[] array of the 64
+// pairs of a wavefront lives in LDS, one 32-bit word per cell (h:14 | e:13 | query code x 6 : 5), column-major
+// ([column][lane]: every access is bank-conflict free whatever column each lane is at).  The wavefront runs the rows
+// in lock-step (a row lasts as long as its widest window), which costs nothing when the lanes' windows agree: the
+// pairs are sorted by (query length, seed score) first (bsw_lane_sort_kernel).
+__global__ void __launch_bounds__(256) bsw_lane_sort_kernel(BswDev prm, BswPairs P, int64_t n, BswWork W, int pass)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int qlen = P.len2[k], tlen = P.len1[k], h0 = P.h0[k];
+    if (!lane_ok(prm.lane_on, qlen, tlen, h0, prm.max_mat) || tlen > GBX_BSW_MAX_TLEN) return;
+    const int key = lane_key(qlen, h0, prm.max_mat);
+    if (pass == 0) atomicAdd(&W.lbase[key + 1], 1);
+    else W.lorder[W.lbase[key] + atomicAdd(&W.lcur[key], 1)] = (int)k;
+}
+// exclusive prefix of the key histogram in place: lbase[k + 1] holds count(k) on entry, lbase[k] = pairs with a key below k
+// on exit (one block)
+__global__ void __launch_bounds__(1024) bsw_lane_scan_kernel(BswWork W)
+{
+    constexpr int PER = (LANE_BINS + 1023) / 1024;
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    int sum = 0;
+    for (int k = 0; k < PER; ++k) { const int b = tid * PER + k; if (b < LANE_BINS) sum += W.lbase[b + 1]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int add = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int k = 0; k < PER; ++k) {
+        const int b = tid * PER + k;
+        if (b < LANE_BINS) { const int c = W.lbase[b + 1]; run += c; W.lbase[b + 1] = run; }
+    }
+}
+
+// COMPACT: every score of the pair stays below 256 (a 151-bp read's extension always does: seed score + query length <=
+// read length) - the cell is 16 bits (h:8 | e:8) and the query codes live in a byte plane behind the cells, 3 bytes per
+// column and lane instead of 4: queries up to 104 long run at two wavefronts per SIMD and more, which is what it takes
+// to keep a SIMD's issue slots full (a lone wavefront issues one instruction per ~5 cycles, whatever its rate).
+template <bool SYM, bool COMPACT>
+__global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, BswWork W, int rlo, int rhi, int cols, int slot)
+{
+    extern __shared__ uint32_t lcell[];                 // wide: [column][lane] words; compact: [column][lane] halves, then [column][lane] bytes
+#define LCELL(byte_addr) (*(uint32_t *)((char *)lcell + (byte_addr)))
+#define LCELL16(byte_addr) (*(uint16_t *)((char *)lcell + (byte_addr)))
+#define LQ8(byte_addr) (*((uint8_t *)lcell + (byte_addr)))
+    const int lane = threadIdx.x;
+    const int first = W.lbase[rlo << 8], count = W.lbase[(rhi + 1) << 8] - first;
+    const int nchunks = (count + 63) >> 6;
+    const int32_t *order = W.lorder + first;
+    const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
+    constexpr int CS = COMPACT ? 128 : 256;             // bytes per column of cells
+    const int cb = lane * (COMPACT ? 2 : 4);            // the lane's byte offset inside a column of cells
+    const int qb = cols * 128 + lane;                   // compact: the lane's byte in column 0 of the query plane
+    for (;;) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&W.lchunk[slot], 1);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= nchunks) break;
+        // the sorted list ascends in query length: chunks are taken from its end, so the kernel's tail is short pairs
+        const int hi_ = count - (c << 6), idx = hi_ - 64 + lane;
+        const bool have = idx >= 0;                     // only the last chunk of a launch is ragged: its spare lanes repeat entry 0
+        const int pair = order[have ? idx : 0];
+        const int qlen = P.len2[pair], tlen = P.len1[pair], h0 = P.h0[pair];
+        const uint8_t *q = P.qer + P.idq[pair];
+        const uint8_t *t = P.ref + P.idr[pair];
+        // first row, :155-157, and the query codes (x 6: the bit offset of the score field in the matrix row word)
+        for (int j = 0; j <= qlen; ++j) {
+            const int hv = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
+            const int qc = j < qlen ? min((int)q[j], 4) * 6 : 0;
+            if (COMPACT) { LCELL16(j * CS + cb) = (uint16_t)(hv << 8); LQ8(qb + j * 64) = (uint8_t)qc; }
+            else LCELL(j * CS + cb) = ((uint32_t)hv << 18) | (uint32_t)qc;
+        }
+        const int w = band_width(prm, qlen);
+        int best = h0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
+        int beg = 0, end = qlen;
+        int tb = min((int)t[0], 4);
+        for (int i = 0; i < tlen; ++i) {
+            const uint32_t rw = tb == 0 ? prm.lrow[0] : tb == 1 ? prm.lrow[1] : tb == 2 ? prm.lrow[2] : tb == 3 ? prm.lrow[3] : prm.lrow[4];
+            tb = min((int)t[min(i + 1, tlen - 1)], 4);      // next row's base: in flight during this row
+            if (beg < i - w) beg = i - w;                  // :179-181
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            int left = beg == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;      // :183-186
+            int f = 0;
+            uint32_t key = 0;                              // (row maximum << 18) | byte address of the cell of its last arg-max
+            int ab = beg * CS + cb;                        // byte address of the cell in LDS
+            const int abend = end * CS + cb;
+            if (COMPACT) {
+                int aq = qb + beg * 64;
+                // one column, :187-212; cw = the cell, qo = the query code's field offset
+                auto step = [&](uint32_t cw, uint32_t qo, int at) {
+                    const int diag = (int)(cw >> 8), e = (int)(cw & 0xffu);
+                    const int sc = __builtin_amdgcn_sbfe((int)rw, qo, 6u);
+                    const int m = diag ? diag + sc : 0;    // :196
+                    const int h = imax3(m, e, f);
+                    key = max(key, ((uint32_t)h << 18) | (uint32_t)at);          // ties: the larger address wins = last arg-max, :200-201
+                    const int td = m - oe_del;
+                    const int en = imax3(e - e_del, td, 0);                      // E(i+1,j), :202-206
+                    f = imax3(f - e_ins, SYM ? td : m - oe_ins, 0);              // F(i,j+1), :207-210
+                    LCELL16(at) = (uint16_t)((left << 8) | en);                  // eh[j] = {H(i,j-1), E(i+1,j)}
+                    left = h;
+                };
+                // The columns are taken two at a time with the loads two columns ahead of their use (an LDS round trip is
+                // 100+ cycles under load and a wavefront has nothing else to do meanwhile: with the load one column ahead
+                // every column waited for it).  An odd column count is evened out by one plain step first.
+                if ((end - beg) & 1) {
+                    if (beg < end) { step(LCELL16(ab), LQ8(aq), ab); ab += CS; aq += 64; }
+                }
+                uint32_t c0 = LCELL16(ab), q0 = LQ8(aq), c1 = LCELL16(ab + CS), q1 = LQ8(aq + 64);
+#pragma unroll 2
+                for (; ab < abend; ab += 2 * CS, aq += 128) {
+                    const uint32_t n0 = LCELL16(ab + 2 * CS), nq0 = LQ8(aq + 128), n1 = LCELL16(ab + 3 * CS), nq1 = LQ8(aq + 192);
+                    step(c0, q0, ab);
+                    step(c1, q1, ab + CS);
+                    c0 = n0; q0 = nq0; c1 = n1; q1 = nq1;
+                }
+                LCELL16(end * CS + cb) = (uint16_t)(left << 8);                  // eh[end] = {h1, 0}, :213
+            } else {
+                uint32_t left18 = (uint32_t)left << 18;
+                uint32_t cw = LCELL(ab);
+#pragma unroll 2
+                for (; ab < abend; ab += CS) {
+                    const uint32_t nw = LCELL(ab + CS);
+                    const int diag = (int)(cw >> 18), e = (int)((cw >> 5) & 0x1fffu);
+                    const uint32_t qo = cw & 31u;
+                    const int sc = __builtin_amdgcn_sbfe((int)rw, qo, 6u);
+                    const int m = diag ? diag + sc : 0;
+                    const int h = imax3(m, e, f);
+                    const uint32_t h18 = (uint32_t)h << 18;
+                    key = max(key, h18 | (uint32_t)ab);
+                    const int td = m - oe_del;
+                    const int en = imax3(e - e_del, td, 0);
+                    f = imax3(f - e_ins, SYM ? td : m - oe_ins, 0);
+                    LCELL(ab) = left18 | ((uint32_t)en << 5) | qo;
+                    left18 = h18;
+                    cw = nw;
+                }
+                left = (int)(left18 >> 18);
+                const int ae = end * CS + cb;
+                LCELL(ae) = left18 | (LCELL(ae) & 31u);
+            }
+            const int jfin = beg < end ? end : beg;
+            if (jfin == qlen) {                             // :214-217
+                if (!(g_score > left)) g_i = i;
+                g_score = max(g_score, left);
+            }
+            const int row_best = (int)(key >> 18), row_arg = (int)(key & 0x3ffffu) / CS;
+            if (row_best == 0) break;                       // :218
+            if (row_best > best) {                          // :219-221
+                best = row_best; best_i = i; best_j = row_arg;
+                off = max(off, abs(row_arg - i));
+            } else if (prm.zdrop > 0) {                     // :222-228
+                const int di = i - best_i, dj = row_arg - best_j;
+                if (di > dj) { if (best - row_best - (di - dj) * e_del > prm.zdrop) break; }
+                else if (best - row_best - (dj - di) * e_ins > prm.zdrop) break;
+            }
+            // the next row's window, :230-233 (h == 0 and e == 0 <=> the cell is zero / the word is below 32)
+            int j = beg;
+            if (COMPACT) {
+                while (j < end && LCELL16(j * CS + cb) == 0) ++j;
+                beg = j;
+                j = end;
+                while (j >= beg && LCELL16(j * CS + cb) == 0) --j;
+            } else {
+                while (j < end && LCELL(j * CS + cb) < 32u) ++j;
+                beg = j;
+                j = end;
+                while (j >= beg && LCELL(j * CS + cb) < 32u) --j;
+            }
+            end = min(j + 2, qlen);
+        }
+        gbx_bsw_result r;
+        r.score = best; r.tle = best_i + 1; r.gtle = g_i + 1; r.qle = best_j + 1; r.gscore = g_score; r.max_off = off;
+        if (have) P.out[pair] = r;
+    }
+#undef LCELL
+#undef LCELL16
+#undef LQ8
+}
+
 // ---- kernel shapes ----------------------------------------------------------
 // class c (query length) -> (lanes per pair, columns per lane).  Short queries use narrow groups:
 // the per-row fixed cost (scan, reductions, epilogue) is paid once per wavefront row, so 16 pairs per
@@ -628,14 +849,26 @@ int make_dev_params(const gbx_bsw_params *p, BswDev *d)
         d->row0[t] = wv;
         d->row1[t] = (uint32_t)(uint8_t)p->mat[t * 5 + 4];
     }
+    // lane path: the matrix row as five signed 6-bit fields; scorings outside [-32, 31] keep every pair on the row kernels
+    d->lane_on = 0;
+    bool fits6 = true;
+    for (int k = 0; k < 25; ++k) fits6 = fits6 && p->mat[k] >= -32 && p->mat[k] <= 31;
+    for (int t = 0; t < 5; ++t) {
+        uint32_t wv = 0;
+        for (int q = 0; q < 5; ++q) wv |= ((uint32_t)p->mat[t * 5 + q] & 63u) << (6 * q);
+        d->lrow[t] = wv;
+    }
+    if (fits6 && p->o_del + p->e_del < LANE_SCORE_LIMIT && p->o_ins + p->e_ins < LANE_SCORE_LIMIT) d->lane_on = -1;   // -1: allowed, the launch decides
     return GBX_OK;
 }
 
 }  // namespace
 
+// ints: header | order[n] | wband[n] | lorder[n] | lbase[LANE_BINS + 1] (+pad) | lcur[LANE_BINS] | lchunk[64]
+constexpr int64_t WS_LANE = (int64_t)(LANE_BINS + 64) + LANE_BINS + 64;
 size_t bsw_workspace_bytes(int64_t n)
 {
-    return (size_t)(WS_HDR + 2 * (n > 0 ? n : 0)) * sizeof(int32_t);
+    return (size_t)(WS_HDR + 3 * (n > 0 ? n : 0) + WS_LANE) * sizeof(int32_t);
 }
 
 // Expands the packed image of a byte arena (two base codes per byte, host_pipeline.h: pack4) over [lo, hi) of the
@@ -679,7 +912,8 @@ int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,
     if (rc) return rc;
     for (int c = 0; c < NCLS; ++c) dev.remap[c] = (uint8_t)c;
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
-    BswWork W = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    BswWork W = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    dev.lane_on = 0;
     if (max_qlen > 256) { set_error("bsw: direct launch needs queries of at most 256"); return GBX_ERR_ARG; }
     const int lpp = max_qlen <= 128 ? 8 : 16;
     RowKernel *k = find_row_kernel(lpp, 16);
@@ -709,8 +943,25 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     for (int c = 0; c < NCLS; ++c) dev.remap[c] = CLASS_REMAP[mode][c];
     BswPairs P = {d_ref, d_qer, d_idr, d_idq, d_len1, d_len2, d_h0, d_out};
     int32_t *wi = (int32_t *)d_work;
-    BswWork W = {wi, wi + HDR, wi + 2 * HDR, wi + 3 * HDR, wi + WS_HDR, wi + WS_HDR + n};
+    int32_t *wl = wi + WS_HDR + 3 * n;
+    BswWork W = {wi, wi + HDR, wi + 2 * HDR, wi + 3 * HDR, wi + WS_HDR, wi + WS_HDR + n, wl, wl + LANE_BINS + 64, wi + WS_HDR + 2 * n,
+                 wl + LANE_BINS + 64 + LANE_BINS};
     GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s));
+    // lane path: large jobs only (a wavefront holds 64 pairs: the chip wants a few thousand wavefronts), GBX_BSW_LANE=0/1 overrides
+    {
+        const char *lane_env = getenv("GBX_BSW_LANE");              /* read per call: the tests vary it */
+        const int64_t lane_min = getenv("GBX_BSW_LANE_MIN") ? atoll(getenv("GBX_BSW_LANE_MIN")) : 262144;
+        const bool want = lane_env ? atoi(lane_env) != 0 : n >= lane_min;
+        dev.lane_on = dev.lane_on && want ? 1 : 0;
+    }
+    if (dev.lane_on) {
+        GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
+        Stage st("bsw_lane_sort", s);
+        const int sblocks = (int)((n + 255) / 256);
+        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, s, dev, P, n, W, 0);
+        hipLaunchKernelGGL(bsw_lane_scan_kernel, dim3(1), dim3(1024), 0, s, W);
+        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, s, dev, P, n, W, 1);
+    }
     const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
         Stage st("bsw_classify", s);
@@ -741,6 +992,35 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         if ((rc = side_streams(&ss))) return rc;
         side_lock = std::unique_lock<std::mutex>(ss->mu);
         if ((rc = ss->fork(s))) return rc;
+    }
+    if (dev.lane_on) {
+        // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
+        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c48", "bsw_lane_c80", "bsw_lane_c101", "bsw_lane_c137", "bsw_lane_c159"},
+                                                    {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
+        int nl = 0;
+        for (int r = LANE_NRANGE - 1; r >= 0; --r)
+            for (int fmt = 0; fmt < 2; ++fmt, ++nl) {
+                const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
+                const int cols = qhi + 5;                          // column `end` and three columns of look-ahead
+                const size_t lds = (size_t)cols * (fmt ? 256 : 192);
+                int per_cu = (int)((size_t)160 * 1024 / lds);
+                if (per_cu > 16) per_cu = 16;
+                // both formats of a range share a stream (one of the two is usually empty; an empty launch still has to get its
+                // LDS before it can see that, so it must not sit in front of a working kernel of another range)
+                const int sk = (LANE_NRANGE - 1 - r) & 3;
+                hipStream_t sc = serial || sk == 0 ? s : ss->side[sk - 1];
+                int64_t blocks = (int64_t)cus * per_cu, want = (n + 63) / 64;
+                if (blocks > want) blocks = want;
+                const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
+                Stage st(names[fmt][r], sc);
+                if (fmt == 0) {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                } else {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                }
+            }
     }
     int launched = 0;
     for (int c = 0; c < NCLS - 1; ++c) {

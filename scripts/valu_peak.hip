@@ -98,6 +98,9 @@
 #define I_AND_SDWA(k) "v_and_b32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
 #define I_SUBF(k)     "v_sub_f32 %" #k ", %" #k ", %9\n"
 #define I_MACF(k)     "v_fmac_f32 %" #k ", %8, %9\n"
+#define I_PAIR_VCC(k)  "v_cmp_gt_i32 vcc, %" #k ", %8\nv_cndmask_b32 %" #k ", %" #k ", %9, vcc\n"
+#define I_PAIR_SGPR(k) "v_cmp_gt_i32 s[40:41], %" #k ", %8\nv_cndmask_b32_e64 %" #k ", %" #k ", %9, s[40:41]\n"
+#define I_PAIR_VCC_FAR(k)  "v_cmp_gt_i32 vcc, %" #k ", %8\nv_add_u32 %" #k ", %" #k ", %8\nv_add_u32 %" #k ", %" #k ", %8\nv_cndmask_b32 %" #k ", %" #k ", %9, vcc\n"
 #define I_CMP(k)      "v_cmp_gt_i32 vcc, %" #k ", %8\n"
 #define I_CMP_S(k)    "v_cmp_gt_i32 s[40:41], %" #k ", %8\n"
 #define I_MULLO(k)    "v_mul_lo_u32 %" #k ", %" #k ", %8\n"
@@ -147,6 +150,7 @@ KERNEL32(k_add_co_u32, I_ADDCO) KERNEL32(k_subrev_u32, I_SUBREV) KERNEL32(k_mul_
 KERNEL32(k_max_i16, I_MAXI16) KERNEL32(k_add_u16, I_ADDU16) KERNEL32(k_pk_mad_i16, I_PKMAD16) KERNEL32(k_pk_lshlrev_b16, I_PKLSHL16)
 KERNEL32(k_pk_ashrrev_i16, I_PKASHR16) KERNEL32(k_pk_max_u16, I_PKMAXU16) KERNEL32(k_pk_sub_i16, I_PKSUBI16) KERNEL32(k_sad_u32, I_SAD)
 KERNEL32(k_add_u32_dpp_row_shr, I_ADD_DPP) KERNEL32(k_and_b32_sdwa_byte, I_AND_SDWA) KERNEL32(k_sub_f32, I_SUBF) KERNEL32(k_fmac_f32, I_MACF)
+KERNEL32(k_pair_cmp_cndmask_vcc, I_PAIR_VCC) KERNEL32(k_pair_cmp_cndmask_sgpr, I_PAIR_SGPR) KERNEL32(k_quad_cmp_add_add_cndmask_vcc, I_PAIR_VCC_FAR)
 KERNEL32(k_cmp_gt_i32_vcc, I_CMP) KERNEL32(k_cmp_gt_i32_sgpr, I_CMP_S) KERNEL32(k_mul_lo_u32, I_MULLO) KERNEL32(k_mad_u32_u24, I_MAD24)
 KERNEL32(k_mbcnt_lo, I_MBCNT)
 KERNEL32(k_max_i32_dpp_quad_perm, I_MAX_QP) KERNEL32(k_max_i32_dpp_row_shr, I_MAX_SHR) KERNEL32(k_max_i32_dpp_row_ror, I_MAX_ROR)
@@ -200,6 +204,7 @@ static const Form forms[] = {
     F(cndmask_b32_e64_sgpr), F(cndmask_b32_const), F(or_b32), F(xor_b32), F(lshrrev_b32), F(min_i32), F(max_u32), F(med3_i32), F(min3_i32),
     F(add_co_u32), F(subrev_u32), F(mul_u32_u24), F(alignbit_b32), F(max_i16), F(add_u16), F2(pk_mad_i16), F2(pk_lshlrev_b16), F2(pk_ashrrev_i16),
     F2(pk_max_u16), F2(pk_sub_i16), F(sad_u32), F(add_u32_dpp_row_shr), F(and_b32_sdwa_byte), F(sub_f32), F(fmac_f32),
+    F(pair_cmp_cndmask_vcc), F(pair_cmp_cndmask_sgpr), F(quad_cmp_add_add_cndmask_vcc),
     F(cmp_gt_i32_sgpr), F(mul_lo_u32), F(mad_u32_u24), F(mbcnt_lo),
     F(max_i32_dpp_quad_perm), F(max_i32_dpp_row_shr), F(max_i32_dpp_row_ror), F(max_i32_dpp_row_half_mirror),
     F(max_i32_dpp_wave_shr), F(max_i32_dpp_row_bcast15), F(mov_b32_dpp_row_shr),
@@ -229,7 +234,7 @@ int main(int argc, char **argv)
     printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"iters\": %d, \"insts_per_wave\": %lld,\n"
            " \"command\": \"./scripts/valu_peak %d\",\n \"note\": \"blocks of 4 wavefronts (one per SIMD); W wavefronts per SIMD = W blocks per CU; "
            "lane_ops_per_s = wave instructions x 64 / wall time; cyc_per_inst_simd = s_memtime ticks per instruction of one wavefront / W "
-           "(s_memtime ticks at 100 MHz are rescaled by clock_khz when they are not shader cycles: see tick_hz)\",\n \"forms\": {\n",
+           "forms named pair_* / quad_* are 2 / 4 instructions per counted instruction: divide their cycles accordingly\",\n \"forms\": {\n",
            prop.name, prop.gcnArchName, cus, prop.clockRate, iters, (long long)iters * 64, iters);
     bool first = true;
     for (const Form &f : forms) {

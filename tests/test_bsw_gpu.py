@@ -217,3 +217,56 @@ def test_direct_launch_for_small_plain_jobs(monkeypatch):
     pq = make_params(o_del=5, e_del=2, o_ins=7, e_ins=3, zdrop=50, end_bonus=9, w=37, mat=fill_scmat(2, 5, -2))
     b = gen_bsw(3000, 10)
     assert_same(extend_host(pq, b), O.bsw_oracle(pq, b, 4), b)      # asymmetric gaps through the direct launch
+
+
+# ---- lane path (bsw_lane_kernel: one pair per lane, pairs sorted by (query length, seed score)) -------------------------
+# Large jobs take it by default (tests/test_fullsize_gpu.py runs the 2 M-pair job through it); GBX_BSW_LANE=1 forces it
+# on the small parity sets, where pairs that do not qualify (queries over 159, scores of 8192 and more, scorings
+# outside six bits) share the call with the row kernels.
+@pytest.fixture
+def lane(monkeypatch):
+    monkeypatch.setenv("GBX_BSW_LANE", "1")
+    monkeypatch.setenv("GBX_BSW_DIRECT", "0")
+
+
+@pytest.mark.parametrize("name", ["realistic", "adversarial", "edge"])
+def test_lane_goldens(name, lane):
+    b, scalar, avx2 = load_bsw_golden(name)
+    got = extend_host(make_params(), b)
+    assert_same(got, scalar, b)
+    assert np.array_equal(got[:, [0, 1, 3, 5]], avx2[:, [0, 1, 3, 5]])
+
+
+def test_lane_edge_cases(lane):
+    b = edge_bsw()
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_lane_adversarial_random(seed, lane):
+    b = adversarial_bsw(6000, seed)
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+def test_lane_mixed_with_long_queries(lane):
+    b = adversarial_bsw(600, 9, max_q=3000, max_t=4000)
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 4), b)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(o_del=5, e_del=2, o_ins=7, e_ins=3, zdrop=50, end_bonus=9, w=37, mat=fill_scmat(2, 5, -2)),
+    dict(zdrop=0, w=5),
+    dict(w=1000, zdrop=10),
+    dict(o_del=0, e_del=1, o_ins=0, e_ins=1, mat=fill_scmat(3, 1, 0)),
+    dict(mat=fill_scmat(31, 32, -7)),             # the corners of the six-bit score fields
+    dict(mat=fill_scmat(40, 3, -1)),              # does not fit six bits: every pair stays on the row kernels
+])
+def test_lane_non_default_scoring(kw, lane):
+    p = make_params(**kw)
+    b = adversarial_bsw(3000, 21)
+    assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
+
+
+def test_lane_generated_reads_and_ragged_last_chunk(lane):
+    b = gen_bsw(30_011, 77)                        # not a multiple of 64 in any length class
+    assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
