@@ -86,7 +86,7 @@ constexpr int LANE_SCORE_LIMIT = 8192;               // wide cell word = h:14 | 
 constexpr int LANE_COMPACT_LIMIT = 256;              // compact cell = h:8 | e:8, query code in a byte plane
 constexpr int LANE_NRANGE = 5;
 // query-length ranges of the launches = LDS classes: compact 16, 10, 8, 6, 5 wavefronts per CU, wide 15, 7, 5, 4, 3
-constexpr int LANE_RANGE_HI[2][LANE_NRANGE] = {{48, 80, 101, 137, LANE_QMAX}, {39, 79, 103, 127, LANE_QMAX}};
+constexpr int LANE_RANGE_HI[2][LANE_NRANGE] = {{47, 79, 99, 135, LANE_QMAX}, {39, 79, 103, 127, LANE_QMAX}};
 __host__ __device__ inline bool lane_ok(int lane_on, int qlen, int tlen, int h0, int max_mat)
 {
     return lane_on && qlen >= 1 && qlen <= LANE_QMAX && tlen >= 1 && h0 >= 0 && h0 + qlen * (max_mat > 0 ? max_mat : 0) < LANE_SCORE_LIMIT;
@@ -612,14 +612,110 @@ __global__ void __launch_bounds__(1024) bsw_lane_scan_kernel(BswWork W)
     }
 }
 
+// Two columns of the compact lane kernel, scheduled by hand (30 VALU instructions; the compiler's version of the same
+// C++ needs 43).  w = the lane's dword of the column pair, bytes {e(2p), h(2p), e(2p+1), h(2p+1)}; qq = the pair's query
+// codes (x 6) in bytes 0 and 1; the cell fields are byte operands (SDWA), never unpacked.  Returns the new dword;
+// updates f, left (the previous column's h), key.  vcc is written two instructions before it is read.
+template <bool SYM>
+__device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint32_t rw, int &f, int &left, uint32_t &key, int pa, int pa1,
+                                                   int zero, int oe_del, int oe_ins, int e_del, int e_ins)
+{
+    uint32_t wn;
+    int hb;
+    if (SYM) {
+        int sa, sb, ta, tb, ma, mb, x, ha, td, ed, ena, enb, fd, ka, kb, qb, u, v;
+        asm volatile(
+            "v_bfe_i32 %[sa], %[rw], %[qq], 6\n"
+            "v_lshrrev_b32 %[qb], 8, %[qq]\n"
+            "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n"
+            "v_add_u32_sdwa %[ta], %[sa], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+            "v_bfe_i32 %[sb], %[rw], %[qb], 6\n"
+            "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_cndmask_b32 %[ma], 0, %[ta], vcc\n"
+            "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_3 src1_sel:DWORD\n"
+            "v_max_i32_sdwa %[x], %[ma], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
+            "v_add_u32_sdwa %[tb], %[sb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n"
+            "v_max_i32 %[ha], %[x], %[f]\n"
+            "v_subrev_u32 %[td], %[oed], %[ma]\n"
+            "v_cndmask_b32 %[mb], 0, %[tb], vcc\n"
+            "v_sub_u32_sdwa %[ed], %[w], %[edel] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+            "v_max3_i32 %[f], %[fd], %[td], 0\n"
+            "v_max3_i32 %[ena], %[ed], %[td], 0\n"
+            "v_max_i32_sdwa %[x], %[mb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+            "v_lshl_or_b32 %[ka], %[ha], 18, %[pa]\n"
+            "v_max_i32 %[hb], %[x], %[f]\n"
+            "v_subrev_u32 %[td], %[oed], %[mb]\n"
+            "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_sub_u32_sdwa %[ed], %[w], %[edel] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+            "v_max3_i32 %[f], %[fd], %[td], 0\n"
+            "v_max3_i32 %[enb], %[ed], %[td], 0\n"
+            "v_lshl_or_b32 %[kb], %[hb], 18, %[pa1]\n"
+            "v_lshl_or_b32 %[u], %[left], 8, %[ena]\n"
+            "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
+            "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
+            "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
+            : [sa] "=&v"(sa), [sb] "=&v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
+              [hb] "=&v"(hb), [td] "=&v"(td), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
+              [kb] "=&v"(kb), [qb] "=&v"(qb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [edel] "s"(e_del), [eins] "s"(e_ins)
+            : "vcc");
+    } else {
+        int sa, sb, ta, tb, ma, mb, x, ha, td, ti, ed, ena, enb, fd, ka, kb, qb, u, v;
+        asm volatile(
+            "v_bfe_i32 %[sa], %[rw], %[qq], 6\n"
+            "v_lshrrev_b32 %[qb], 8, %[qq]\n"
+            "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n"
+            "v_add_u32_sdwa %[ta], %[sa], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+            "v_bfe_i32 %[sb], %[rw], %[qb], 6\n"
+            "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_cndmask_b32 %[ma], 0, %[ta], vcc\n"
+            "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_3 src1_sel:DWORD\n"
+            "v_max_i32_sdwa %[x], %[ma], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
+            "v_add_u32_sdwa %[tb], %[sb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n"
+            "v_max_i32 %[ha], %[x], %[f]\n"
+            "v_subrev_u32 %[td], %[oed], %[ma]\n"
+            "v_subrev_u32 %[ti], %[oei], %[ma]\n"
+            "v_cndmask_b32 %[mb], 0, %[tb], vcc\n"
+            "v_sub_u32_sdwa %[ed], %[w], %[edel] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+            "v_max3_i32 %[f], %[fd], %[ti], 0\n"
+            "v_max3_i32 %[ena], %[ed], %[td], 0\n"
+            "v_max_i32_sdwa %[x], %[mb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"
+            "v_lshl_or_b32 %[ka], %[ha], 18, %[pa]\n"
+            "v_max_i32 %[hb], %[x], %[f]\n"
+            "v_subrev_u32 %[td], %[oed], %[mb]\n"
+            "v_subrev_u32 %[ti], %[oei], %[mb]\n"
+            "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_sub_u32_sdwa %[ed], %[w], %[edel] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+            "v_max3_i32 %[f], %[fd], %[ti], 0\n"
+            "v_max3_i32 %[enb], %[ed], %[td], 0\n"
+            "v_lshl_or_b32 %[kb], %[hb], 18, %[pa1]\n"
+            "v_lshl_or_b32 %[u], %[left], 8, %[ena]\n"
+            "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
+            "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
+            "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
+            : [sa] "=&v"(sa), [sb] "=&v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
+              [hb] "=&v"(hb), [td] "=&v"(td), [ti] "=&v"(ti), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
+              [kb] "=&v"(kb), [qb] "=&v"(qb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [oei] "s"(oe_ins), [edel] "s"(e_del), [eins] "s"(e_ins)
+            : "vcc");
+    }
+    left = hb;
+    return wn;
+}
+
 // COMPACT: every score of the pair stays below 256 (a 151-bp read's extension always does: seed score + query length <=
-// read length) - the cell is 16 bits (h:8 | e:8) and the query codes live in a byte plane behind the cells, 3 bytes per
-// column and lane instead of 4: queries up to 104 long run at two wavefronts per SIMD and more, which is what it takes
-// to keep a SIMD's issue slots full (a lone wavefront issues one instruction per ~5 cycles, whatever its rate).
+// read length) - the cell is 16 bits (h:8 | e:8), the cells of columns 2p and 2p+1 share the lane's dword of row p of the
+// cell plane ([column pair][lane] dwords: bank = lane for any column), and the query codes of a column pair are a
+// halfword of row p of a second plane ([pair][lane & 31][lane >> 5]: lanes l and l + 32 are served in different LDS
+// cycles, so again no two lanes of a group meet in a bank).  3 bytes per column and lane instead of 4: queries up to
+// ~100 long run at two wavefronts per SIMD and more; a column pair is one dword read, one halfword read and one dword
+// write, and its fields are byte operands of the arithmetic (SDWA), never unpacked.
 template <bool SYM, bool COMPACT>
 __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, BswWork W, int rlo, int rhi, int cols, int slot)
 {
-    extern __shared__ uint32_t lcell[];                 // wide: [column][lane] words; compact: [column][lane] halves, then [column][lane] bytes
+    extern __shared__ uint32_t lcell[];
 #define LCELL(byte_addr) (*(uint32_t *)((char *)lcell + (byte_addr)))
 #define LCELL16(byte_addr) (*(uint16_t *)((char *)lcell + (byte_addr)))
 #define LQ8(byte_addr) (*((uint8_t *)lcell + (byte_addr)))
@@ -628,9 +724,12 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
     const int nchunks = (count + 63) >> 6;
     const int32_t *order = W.lorder + first;
     const int e_ins = prm.e_ins, e_del = prm.e_del, oe_ins = prm.oe_ins, oe_del = prm.oe_del;
-    constexpr int CS = COMPACT ? 128 : 256;             // bytes per column of cells
-    const int cb = lane * (COMPACT ? 2 : 4);            // the lane's byte offset inside a column of cells
-    const int qb = cols * 128 + lane;                   // compact: the lane's byte in column 0 of the query plane
+    // wide: cell of column j = dword at j * 256 + lane * 4
+    // compact: cell of column j = halfword at (j >> 1) * 256 + lane * 4 + (j & 1) * 2; query code of column j = byte at
+    //          qb + (j >> 1) * 128 + (j & 1)
+    const int cb = lane * 4;
+    const int qb = (cols >> 1) * 256 + (lane & 31) * 4 + (lane >> 5) * 2;       // cols is even
+    auto cell_at = [&](int j) { return COMPACT ? (j >> 1) * 256 + cb + (j & 1) * 2 : j * 256 + cb; };
     for (;;) {
         int c = 0;
         if (lane == 0) c = atomicAdd(&W.lchunk[slot], 1);
@@ -647,8 +746,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         for (int j = 0; j <= qlen; ++j) {
             const int hv = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
             const int qc = j < qlen ? min((int)q[j], 4) * 6 : 0;
-            if (COMPACT) { LCELL16(j * CS + cb) = (uint16_t)(hv << 8); LQ8(qb + j * 64) = (uint8_t)qc; }
-            else LCELL(j * CS + cb) = ((uint32_t)hv << 18) | (uint32_t)qc;
+            if (COMPACT) { LCELL16(cell_at(j)) = (uint16_t)(hv << 8); LQ8(qb + (j >> 1) * 128 + (j & 1)) = (uint8_t)qc; }
+            else LCELL(cell_at(j)) = ((uint32_t)hv << 18) | (uint32_t)qc;
         }
         const int w = band_width(prm, qlen);
         int best = h0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
@@ -663,13 +762,11 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
             int left = beg == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;      // :183-186
             int f = 0;
             uint32_t key = 0;                              // (row maximum << 18) | byte address of the cell of its last arg-max
-            int ab = beg * CS + cb;                        // byte address of the cell in LDS
-            const int abend = end * CS + cb;
+            int vzero = 0;
+            asm volatile("" : "+v"(vzero));                  // a zero in a vector register (SDWA compare operand)
             if (COMPACT) {
-                int aq = qb + beg * 64;
-                // one column, :187-212; cw = the cell, qo = the query code's field offset
-                auto step = [&](uint32_t cw, uint32_t qo, int at) {
-                    const int diag = (int)(cw >> 8), e = (int)(cw & 0xffu);
+                // one column, :187-212: h8 / e8 = the cell's fields (byte operands), qo = the query code's field offset; returns the new cell
+                auto step = [&](int diag, int e, uint32_t qo, int at) -> uint32_t {
                     const int sc = __builtin_amdgcn_sbfe((int)rw, qo, 6u);
                     const int m = diag ? diag + sc : 0;    // :196
                     const int h = imax3(m, e, f);
@@ -677,30 +774,56 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                     const int td = m - oe_del;
                     const int en = imax3(e - e_del, td, 0);                      // E(i+1,j), :202-206
                     f = imax3(f - e_ins, SYM ? td : m - oe_ins, 0);              // F(i,j+1), :207-210
-                    LCELL16(at) = (uint16_t)((left << 8) | en);                  // eh[j] = {H(i,j-1), E(i+1,j)}
+                    const uint32_t cell = ((uint32_t)left << 8) | (uint32_t)en;  // eh[j] = {H(i,j-1), E(i+1,j)}
                     left = h;
+                    return cell;
                 };
-                // The columns are taken two at a time with the loads two columns ahead of their use (an LDS round trip is
-                // 100+ cycles under load and a wavefront has nothing else to do meanwhile: with the load one column ahead
-                // every column waited for it).  An odd column count is evened out by one plain step first.
-                if ((end - beg) & 1) {
-                    if (beg < end) { step(LCELL16(ab), LQ8(aq), ab); ab += CS; aq += 64; }
+                int j = beg;
+                if ((j & 1) && j < end) {                  // odd first column: the high half of its dword, alone
+                    const int at = cell_at(j);
+                    const uint32_t cw = LCELL16(at);
+                    LCELL16(at) = (uint16_t)step((int)(cw >> 8), (int)(cw & 0xffu), LQ8(qb + (j >> 1) * 128 + 1), at);
+                    ++j;
                 }
-                uint32_t c0 = LCELL16(ab), q0 = LQ8(aq), c1 = LCELL16(ab + CS), q1 = LQ8(aq + 64);
-#pragma unroll 2
-                for (; ab < abend; ab += 2 * CS, aq += 128) {
-                    const uint32_t n0 = LCELL16(ab + 2 * CS), nq0 = LQ8(aq + 128), n1 = LCELL16(ab + 3 * CS), nq1 = LQ8(aq + 192);
-                    step(c0, q0, ab);
-                    step(c1, q1, ab + CS);
-                    c0 = n0; q0 = nq0; c1 = n1; q1 = nq1;
+                // Whole column pairs, four per trip, the loads two to four pairs ahead of their use (an LDS round trip is 100+
+                // cycles under load and the wavefront has nothing else to do meanwhile).  Two register sets take turns, so
+                // nothing is copied.  Loads past the window read cells that exist (look-ahead rows are part of the allocation)
+                // and are not used.
+                int pa = (j >> 1) * 256 + cb, qa = qb + (j >> 1) * 128;
+                uint32_t w0 = LCELL(pa), q0 = LCELL16(qa), w1 = LCELL(pa + 256), q1 = LCELL16(qa + 128);
+                for (; j + 7 < end; j += 8, pa += 1024, qa += 512) {
+                    const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256), x1 = LCELL(pa + 768), y1 = LCELL16(qa + 384);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    w0 = LCELL(pa + 1024); q0 = LCELL16(qa + 512); w1 = LCELL(pa + 1280); q1 = LCELL16(qa + 640);
+                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, f, left, key, pa + 512, pa + 514, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, f, left, key, pa + 768, pa + 770, vzero, oe_del, oe_ins, e_del, e_ins);
                 }
-                LCELL16(end * CS + cb) = (uint16_t)(left << 8);                  // eh[end] = {h1, 0}, :213
+                if (j + 3 < end) {
+                    const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    w0 = x0; q0 = y0;
+                    w1 = LCELL(pa + 768); q1 = LCELL16(qa + 384);
+                    j += 4; pa += 512; qa += 256;
+                }
+                if (j + 1 < end) {
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    w0 = w1; q0 = q1;
+                    j += 2; pa += 256; qa += 128;
+                }
+                if (j < end) {                             // even last column: the low half of its dword, alone
+                    LCELL16(pa) = (uint16_t)step((int)((w0 >> 8) & 0xffu), (int)(w0 & 0xffu), q0 & 0xffu, pa);
+                }
+                LCELL16(cell_at(end)) = (uint16_t)(left << 8);                   // eh[end] = {h1, 0}, :213
             } else {
                 uint32_t left18 = (uint32_t)left << 18;
+                int ab = cell_at(beg);
+                const int abend = cell_at(end);
                 uint32_t cw = LCELL(ab);
 #pragma unroll 2
-                for (; ab < abend; ab += CS) {
-                    const uint32_t nw = LCELL(ab + CS);
+                for (; ab < abend; ab += 256) {
+                    const uint32_t nw = LCELL(ab + 256);
                     const int diag = (int)(cw >> 18), e = (int)((cw >> 5) & 0x1fffu);
                     const uint32_t qo = cw & 31u;
                     const int sc = __builtin_amdgcn_sbfe((int)rw, qo, 6u);
@@ -716,15 +839,16 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                     cw = nw;
                 }
                 left = (int)(left18 >> 18);
-                const int ae = end * CS + cb;
-                LCELL(ae) = left18 | (LCELL(ae) & 31u);
+                LCELL(abend) = left18 | (LCELL(abend) & 31u);
             }
             const int jfin = beg < end ? end : beg;
             if (jfin == qlen) {                             // :214-217
                 if (!(g_score > left)) g_i = i;
                 g_score = max(g_score, left);
             }
-            const int row_best = (int)(key >> 18), row_arg = (int)(key & 0x3ffffu) / CS;
+            const int row_best = (int)(key >> 18);
+            const int karg = (int)(key & 0x3ffffu) - cb;    // byte offset of the arg-max cell from the lane's first cell
+            const int row_arg = COMPACT ? ((karg >> 8) << 1) | ((karg >> 1) & 1) : karg >> 8;
             if (row_best == 0) break;                       // :218
             if (row_best > best) {                          // :219-221
                 best = row_best; best_i = i; best_j = row_arg;
@@ -737,15 +861,15 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
             // the next row's window, :230-233 (h == 0 and e == 0 <=> the cell is zero / the word is below 32)
             int j = beg;
             if (COMPACT) {
-                while (j < end && LCELL16(j * CS + cb) == 0) ++j;
+                while (j < end && LCELL16(cell_at(j)) == 0) ++j;
                 beg = j;
                 j = end;
-                while (j >= beg && LCELL16(j * CS + cb) == 0) --j;
+                while (j >= beg && LCELL16(cell_at(j)) == 0) --j;
             } else {
-                while (j < end && LCELL(j * CS + cb) < 32u) ++j;
+                while (j < end && LCELL(cell_at(j)) < 32u) ++j;
                 beg = j;
                 j = end;
-                while (j >= beg && LCELL(j * CS + cb) < 32u) --j;
+                while (j >= beg && LCELL(cell_at(j)) < 32u) --j;
             }
             end = min(j + 2, qlen);
         }
@@ -995,14 +1119,16 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     }
     if (dev.lane_on) {
         // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
-        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c48", "bsw_lane_c80", "bsw_lane_c101", "bsw_lane_c137", "bsw_lane_c159"},
+        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
                                                     {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
         int nl = 0;
         for (int r = LANE_NRANGE - 1; r >= 0; --r)
             for (int fmt = 0; fmt < 2; ++fmt, ++nl) {
                 const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
-                const int cols = qhi + 5;                          // column `end` and three columns of look-ahead
-                const size_t lds = (size_t)cols * (fmt ? 256 : 192);
+                const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
+                // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
+                // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
+                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
                 int per_cu = (int)((size_t)160 * 1024 / lds);
                 if (per_cu > 16) per_cu = 16;
                 // both formats of a range share a stream (one of the two is usually empty; an empty launch still has to get its
