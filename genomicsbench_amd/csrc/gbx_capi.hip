@@ -767,7 +767,7 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
         return GBX_ERR_ARG;
     }
     int lmax = 1, smax = 1;
-    int64_t bmax = 1;
+    int64_t bmax = 1, n_long = 0;
     for (int64_t w = 0; w < n_windows; ++w) {
         const int64_t a = win_first_seq[w], b = win_first_seq[w + 1];
         if (b < a) { set_error("gbx_poa_plan_host: win_first_seq not monotone at window %lld", (long long)w); return GBX_ERR_ARG; }
@@ -776,14 +776,18 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
             return GBX_ERR_UNSUPPORTED;
         }
         int64_t bases = 0;
+        bool is_long = false;
         for (int64_t s = a; s < b; ++s) {
             if (seq_len[s] < 0) { set_error("gbx_poa_plan_host: negative sequence length"); return GBX_ERR_ARG; }
             if (seq_len[s] > lmax) lmax = seq_len[s];
+            if (seq_len[s] > POA_PIPE_MAXLEN) is_long = true;
             bases += seq_len[s];
         }
+        if (is_long) ++n_long;
         if (b - a > smax) smax = (int)(b - a);
         if (bases > bmax) bmax = bases;
     }
+    if (n_long > 0x7fffffff) { set_error("gbx_poa_plan_host: too many windows"); return GBX_ERR_UNSUPPORTED; }
     plan->max_seq_len = lmax;
     plan->max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);     /* multiple of 4: 16-byte aligned edge rows */
     int nf = 6;                                            /* typical windows stay below ~3.6x the read length */
@@ -794,22 +798,32 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     else (void)hipGetLastError();
-    int64_t slots = (int64_t)cus * poa_waves_per_cu(plan->node_cap);   /* one window per resident wavefront */
-    if (n_windows < slots) slots = n_windows > 0 ? n_windows : 1;
-    plan->n_slots = (int32_t)slots;
+    const int64_t resident = (int64_t)cus * poa_waves_per_cu(plan->node_cap);   /* one window per resident wavefront */
+    const int64_t n_main = n_windows - n_long;
+    plan->n_slots = (int32_t)(n_main < resident ? n_main : resident);
+    plan->n_long_windows = (int32_t)n_long;
+    plan->long_slots = (int32_t)(n_long < resident ? n_long : resident);
+    plan->n_windows = n_windows;
     return GBX_OK;
 }
 
 size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan)
 {
     if (!plan) return 0;
-    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len) * (size_t)plan->n_slots + 128;
+    return poa_workspace_bytes(plan);
 }
 
 int gbx_poa_cells(const gbx_poa_plan *plan, const void *d_work, int64_t *cells, void *stream)
 {
     if (!plan || !d_work || !cells) { set_error("gbx_poa_cells: null pointer"); return GBX_ERR_ARG; }
-    return poa_read_cells(d_work, gbx_poa_workspace_bytes(plan) - 128, cells, (hipStream_t)stream);
+    return poa_read_cells(d_work, poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len, false) * (size_t)(plan->n_slots > 0 ? plan->n_slots : 0),
+                          cells, (hipStream_t)stream);
+}
+
+/* development aid (scripts/dbg_poa_phases.py): byte offset of the 32-counter block inside a poa workspace */
+size_t gbx_debug_poa_counter_offset(const gbx_poa_plan *plan)
+{
+    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len, false) * (size_t)(plan->n_slots > 0 ? plan->n_slots : 0);
 }
 
 int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream)
@@ -831,9 +845,8 @@ int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, 
     }
     int rc = require_device();
     if (rc) return rc;
-    return poa_launch(p, n_windows, d_win_first_seq, d_seq_off, d_seq_len, (const uint8_t *)d_arena, plan->max_seq_len,
-                      plan->max_seqs_per_window, plan->node_cap, plan->n_slots, (uint8_t *)d_cons, d_cons_len, d_status,
-                      cons_stride, d_work, work_bytes, (hipStream_t)stream);
+    return poa_launch(p, plan, n_windows, d_win_first_seq, d_seq_off, d_seq_len, (const uint8_t *)d_arena, (uint8_t *)d_cons, d_cons_len,
+                      d_status, cons_stride, d_work, work_bytes, (hipStream_t)stream);
 }
 
 int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
@@ -887,9 +900,8 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         pipe.stage(0, dar.p, arena, arena_bytes);
         pipe.start();
         if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
-        rc = poa_launch(p, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
-                        plan.max_seq_len, plan.max_seqs_per_window, plan.node_cap, plan.n_slots, dcons.as<uint8_t>(),
-                        dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, lane.l->compute);
+        rc = poa_launch(p, &plan, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
+                        dcons.as<uint8_t>(), dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, lane.l->compute);
             if (rc) return pipe.finish(rc);
         pipe.fetch(0, cons, dcons.p, n_windows * cons_stride);
         pipe.fetch(0, cons_len, dcl.p, n_windows * 4);
@@ -905,20 +917,23 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
     // (msa_spoa_omp.cpp:237-252), so only a window that cannot be represented at all fails the call.
     std::vector<int64_t> redo;
     for (int64_t w = 0; w < n_windows; ++w)
-        if (status[w] == GBX_POA_ST_NODES) redo.push_back(w);
+        if (status[w] & GBX_POA_ST_NODES) redo.push_back(w);      // (other bits set next to it are re-decided by the second pass)
     if (!redo.empty()) {
         std::vector<int64_t> wf(redo.size() + 1, 0), off;
         std::vector<int32_t> len;
-        int64_t bmax = 1;
+        int64_t bmax = 1, n_long = 0;
         int lmax = 1, smax = 1;
         for (size_t k = 0; k < redo.size(); ++k) {
             const int64_t a = win_first_seq[redo[k]], b = win_first_seq[redo[k] + 1];
             int64_t bases = 0;
+            bool is_long = false;
             for (int64_t sidx = a; sidx < b; ++sidx) {
                 off.push_back(seq_off[sidx]); len.push_back(seq_len[sidx]);
                 bases += seq_len[sidx];
                 if (seq_len[sidx] > lmax) lmax = seq_len[sidx];
+                if (seq_len[sidx] > POA_PIPE_MAXLEN) is_long = true;
             }
+            if (is_long) ++n_long;
             if (b - a > smax) smax = (int)(b - a);
             if (bases > bmax) bmax = bases;
             wf[k + 1] = (int64_t)off.size();
@@ -926,30 +941,43 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         int64_t cap = bmax + 8;
         while (cap > plan.node_cap && !poa_scores_fit_int16(p, cap, lmax)) cap -= (cap - plan.node_cap + 1) / 2;
         if (cap > plan.node_cap) {
+            const int64_t nr = (int64_t)redo.size(), ns = (int64_t)off.size();
             gbx_poa_plan big = plan;
             big.max_seq_len = lmax;
             big.max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);
             big.node_cap = (int32_t)cap;
-            const size_t slot = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len);
-            int64_t slots = (int64_t)(((size_t)16 << 30) / (slot ? slot : 1));
-            if (slots < 1) slots = 1;
-            if (slots > (int64_t)redo.size()) slots = (int64_t)redo.size();
-            if (slots > plan.n_slots && plan.n_slots > 0) slots = plan.n_slots;
-            big.n_slots = (int32_t)slots;
-            const size_t wb2 = gbx_poa_workspace_bytes(&big);
-            const int64_t nr = (int64_t)redo.size(), ns = (int64_t)off.size();
+            big.n_windows = nr;
+            big.n_long_windows = (int32_t)n_long;
+            // slots: what the device has room for beside the first pass's buffers (still held), at most 16 GB, at most one per window
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+            size_t budget = free_b / 2 < ((size_t)16 << 30) ? free_b / 2 : ((size_t)16 << 30);
             DevBuf dwf2(L), doff2(L), dlen2(L), dcons2(L), dcl2(L), dst2(L), dw2(L);
             if ((rc = dwf2.alloc((nr + 1) * 8)) || (rc = doff2.alloc(ns * 8)) || (rc = dlen2.alloc(ns * 4)) ||
-                (rc = dcons2.alloc(nr * cons_stride)) || (rc = dcl2.alloc(nr * 4)) || (rc = dst2.alloc(nr * 4)) ||
-                (rc = dw2.alloc(wb2)))
+                (rc = dcons2.alloc(nr * cons_stride)) || (rc = dcl2.alloc(nr * 4)) || (rc = dst2.alloc(nr * 4)))
                 return rc;
+            size_t wb2 = 0;
+            for (;;) {                                      // fewer slots when the allocation fails
+                const size_t ms = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len, false);
+                const size_t ls = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len, true);
+                int64_t slots = (int64_t)(budget / (ls ? ls : 1));
+                if (slots < 1) slots = 1;
+                if (slots > plan.n_slots + plan.long_slots && plan.n_slots + plan.long_slots > 0) slots = plan.n_slots + plan.long_slots;
+                const int64_t n_main = nr - n_long;
+                big.n_slots = (int32_t)(n_main < slots ? n_main : slots);
+                big.long_slots = (int32_t)(n_long < slots ? n_long : slots);
+                (void)ms;
+                wb2 = gbx_poa_workspace_bytes(&big);
+                if (dw2.alloc(wb2) == GBX_OK) break;
+                if (budget <= ls) { set_error("gbx_poa_consensus_host: no device memory for the second pass of %lld oversized window(s)", (long long)nr); return GBX_ERR_NOMEM; }
+                budget /= 2;
+            }
             hipStream_t st = lane.l->compute;
             GBX_HIP(hipMemcpyAsync(dwf2.p, wf.data(), (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, st));
             GBX_HIP(hipMemcpyAsync(doff2.p, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st));
             GBX_HIP(hipMemcpyAsync(dlen2.p, len.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
-            if ((rc = poa_launch(p, nr, dwf2.as<int64_t>(), doff2.as<int64_t>(), dlen2.as<int32_t>(), dar.as<uint8_t>(),
-                                 big.max_seq_len, big.max_seqs_per_window, big.node_cap, big.n_slots, dcons2.as<uint8_t>(),
-                                 dcl2.as<int32_t>(), dst2.as<int32_t>(), cons_stride, dw2.p, wb2, st)))
+            if ((rc = poa_launch(p, &big, nr, dwf2.as<int64_t>(), doff2.as<int64_t>(), dlen2.as<int32_t>(), dar.as<uint8_t>(),
+                                 dcons2.as<uint8_t>(), dcl2.as<int32_t>(), dst2.as<int32_t>(), cons_stride, dw2.p, wb2, st)))
                 return rc;
             std::vector<char> c2((size_t)nr * (size_t)cons_stride);
             std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);

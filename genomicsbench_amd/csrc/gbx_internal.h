@@ -103,11 +103,13 @@ int abea_launch(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_
                 gbx_abea_pair *d_out, int32_t *d_n_pairs, void *d_work, size_t work_bytes, hipStream_t s);
 
 // ---- poa (poa_kernels.hip)
-size_t poa_slot_bytes(int ncap, int deg, int lmax);
+constexpr int POA_PIPE_MAXLEN = 512;     // longest sequence of the pipelined DP (two-plane slots)
+size_t poa_slot_bytes(int ncap, int deg, int lmax, bool long_slot);
+size_t poa_workspace_bytes(const gbx_poa_plan *plan);
 int poa_waves_per_cu(int ncap);
 bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax);
-int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
-               const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
+int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
+               const int32_t *d_seq_len, const uint8_t *d_arena,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
                void *d_work, size_t work_bytes, hipStream_t s);
 

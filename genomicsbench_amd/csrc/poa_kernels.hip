@@ -23,6 +23,7 @@
 //     consensus are inherently serial; every lane of the wave executes them
 //     with identical (wave-uniform) data, so no election or broadcast is needed.
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 #include "gbx_internal.h"
 #include "poa_graph.h"
@@ -62,7 +63,10 @@ struct PoaArgs {
     const uint8_t *arena;
     uint8_t *cons; int32_t *cons_len; int32_t *status; int64_t cons_stride;
     char *work; int64_t slot_bytes;
-    unsigned long long *cells;        // DP cells (graph nodes x sequence length, summed over alignments)
+    unsigned long long *cells;        // counter block: [0] DP cells (graph nodes x sequence length, summed over alignments), [1..13] phase
+                                      // statistics, [14] windows of the main launch, [15] its cursor, [16] long windows, [17] their cursor
+    const int32_t *wlist;             // this launch's windows, heaviest class first
+    int cnt_idx, cur_idx;             // which counters of the block are this launch's
     int ncap, deg, lmax;
     int lds_marks;                    // 1: mark/check/DFS stack live in LDS (dynamic shared memory)
     int lds_stack;                    // entries of the DFS stack in LDS (poa_lds_plan)
@@ -85,7 +89,7 @@ struct SlotLayout {
 
 __host__ __device__ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-__host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
+__host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, bool long_slot)
 {
     SlotLayout L;
     int64_t o = 0;
@@ -101,12 +105,12 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax)
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
-    #ifndef GBX_POA_PLANES
+#ifndef GBX_POA_PLANES
 #define GBX_POA_PLANES 2
 #endif
-    // pipelined DP (sequences up to 512 columns): the H plane + one plane of (H-F, H-O) byte pairs; the column-block
-    // DP of longer sequences keeps spoa's five int16 planes
-    L.mat = take((int64_t)(ncap + 1) * poa_cap_stride(lmax) * (lmax <= 512 ? GBX_POA_PLANES : 5) * (int64_t)sizeof(poa_cell_t) + 64);
+    // pipelined DP (sequences up to 512 columns): the H plane + one plane of (H-F, H-O) byte pairs.  Only the slots of the
+    // second launch (windows that hold a longer sequence: column-block DP) keep spoa's five int16 planes.
+    L.mat = take((int64_t)(ncap + 1) * (long_slot ? poa_cap_stride(lmax) : POA_PIPE_STRIDE) * (long_slot ? 5 : GBX_POA_PLANES) * (int64_t)sizeof(poa_cell_t) + 64);
     L.total = align_up(o, 256);
     return L;
 }
@@ -1150,10 +1154,43 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
 }
 
 constexpr int POA_SWEEPS = 8;
-// cells[14] = number of sequences of the job (for the window classes of the cursor sweep)
-__global__ void poa_job_stats_kernel(PoaArgs A)
+constexpr int POA_CNT_MAIN = 14, POA_CUR_MAIN = 15, POA_CNT_LONG = 16, POA_CUR_LONG = 17, POA_NCOUNTERS = 32;
+// Work lists (one block).  A window's cost grows with the square of its sequence count, so the main launch hands the
+// windows out heaviest class first (class = sequences per window against the job's mean: the kernel's tail is then made of
+// light windows); windows that hold a sequence of more than POA_PIPE_MAXLEN bases go to the second launch's list.
+__global__ void __launch_bounds__(1024) poa_classify_kernel(PoaArgs A, int32_t *wlist, int32_t *llist, int llist_cap)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) A.cells[14] = (unsigned long long)(A.win_first_seq[A.n_windows] - A.win_first_seq[0]);
+    __shared__ int cnt[POA_SWEEPS + 1], base[POA_SWEEPS + 1];
+    const int tid = threadIdx.x;
+    if (tid <= POA_SWEEPS) cnt[tid] = 0;
+    __syncthreads();
+    const long long nw = (long long)A.n_windows;
+    const long long seq_sum = (long long)(A.win_first_seq[A.n_windows] - A.win_first_seq[0]);
+    auto class_of = [&](int64_t w) {
+        const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+        for (int64_t s = s0; s < s1; ++s) if (A.seq_len[s] > POA_PIPE_MAXLEN) return POA_SWEEPS;
+        // class = floor((1.4 - sequences / mean) * 10) clamped to [0, POA_SWEEPS): 0 = 1.4 x the mean and more
+        const long long ns10 = 10ll * (long long)(s1 - s0) * nw;
+        const long long d = 14 * seq_sum - ns10;
+        return d <= 0 ? 0 : (int)min((long long)(POA_SWEEPS - 1), d / max(seq_sum, 1ll));
+    };
+    for (int64_t w = tid; w < A.n_windows; w += 1024) atomicAdd(&cnt[class_of(w)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < POA_SWEEPS; ++c) { base[c] = run; run += cnt[c]; }
+        base[POA_SWEEPS] = 0;
+        A.cells[POA_CNT_MAIN] = (unsigned long long)run;
+        A.cells[POA_CNT_LONG] = (unsigned long long)min(cnt[POA_SWEEPS], llist_cap);
+    }
+    __syncthreads();
+    for (int64_t w = tid; w < A.n_windows; w += 1024) {
+        const int c = class_of(w);
+        const int at = atomicAdd(&base[c], 1);
+        if (c < POA_SWEEPS) wlist[at] = (int32_t)w;
+        else if (at < llist_cap) llist[at] = (int32_t)w;
+        else if (A.status) A.status[w] = POA_ERR_NODES;       // (cannot happen with a plan made for these windows)
+    }
 }
 
 // The phase functions above are always_inline: the window kernel is one function on purpose.  Left to its cost model the
@@ -1161,6 +1198,7 @@ __global__ void poa_job_stats_kernel(PoaArgs A)
 // DP grew by a dozen instructions) takes `PoaGraph &` by reference: the graph's pointers then live in scratch memory,
 // lose their address space, and every access of the kernel becomes a FLAT instruction (993 of them, 397 instead of
 // 330 ms, found through SQ_INSTS_LDS dropping to nothing).
+template <bool LONG>
 __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
@@ -1204,27 +1242,15 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 #define PH_T0
 #define PH_ACC(x)
 #endif
-    // Windows are handed out by an atomic cursor (A.cells[15]): a slot that finishes early takes the next one (a
-    // static stride left the slots with three windows running alone for a third of the kernel).  The cursor
-    // sweeps the list POA_SWEEPS times, heaviest class first (sequences per window against the job's mean, A.cells[14] =
-    // their sum; the cost of a window grows with the square of that), so the tail of the kernel is made of light
-    // windows.
-    const unsigned long long nw = (unsigned long long)A.n_windows;
-    const long long seq_sum = (long long)A.cells[14];
+    // Windows are handed out by an atomic cursor over the launch's work list (poa_classify_kernel): a slot that finishes early
+    // takes the next one (a static stride left the slots with three windows running alone for a third of the kernel).
+    const unsigned nwork = (unsigned)A.cells[A.cnt_idx];
     for (;;) {
         unsigned long long wq = 0;
-        if ((threadIdx.x & 63) == 0) wq = atomicAdd(A.cells + 15, 1ull);
+        if ((threadIdx.x & 63) == 0) wq = atomicAdd(A.cells + A.cur_idx, 1ull);
         const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane((int)wq);
-        if (q32 >= (unsigned)POA_SWEEPS * (unsigned)nw) break;
-        const int pass = (int)(q32 / (unsigned)nw);
-        const int64_t w = (int64_t)(q32 % (unsigned)nw);
-        {
-            // class = floor((1.4 - sequences / mean) * 10) clamped to [0, POA_SWEEPS): 0 = 1.4 x the mean and more
-            const long long ns10 = 10ll * (long long)(A.win_first_seq[w + 1] - A.win_first_seq[w]) * (long long)nw;
-            const long long d = 14 * seq_sum - ns10;
-            const int cls = d <= 0 ? 0 : (int)min((long long)(POA_SWEEPS - 1), d / max(seq_sum, 1ll));
-            if (cls != pass) continue;
-        }
+        if (q32 >= nwork) break;
+        const int64_t w = (int64_t)A.wlist[q32];
         poa_graph_reset(g);
         T.n_sorted = 0;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
@@ -1233,7 +1259,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
             const int len = A.seq_len[s];
             g.n_path = 0;
             if (g.n_nodes != 0 && len != 0 && g.err == 0) {
-                const int wp = len <= 512 ? POA_PIPE_STRIDE : poa_row_stride(len);
+                const int wp = !LONG || len <= POA_PIPE_MAXLEN ? POA_PIPE_STRIDE : poa_row_stride(len);
                 const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
                 PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
                 int mi, mj;
@@ -1242,11 +1268,11 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 // The serial phases (one useful lane) are latency chains that lose issue slots to the other wavefronts' DP rows;
                 // the DP is throughput work that does not mind waiting.  Priority 3 for the former: 300.8 -> 294.7 ms.
                 __builtin_amdgcn_s_setprio(0);
-                if (len <= 512) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 __builtin_amdgcn_s_setprio(3);
-                if (len <= 512) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+                if (!LONG || len <= POA_PIPE_MAXLEN) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                 else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
 #ifdef GBX_POA_PHASE_STATS
@@ -1312,7 +1338,7 @@ int poa_waves_per_cu(int ncap)
     const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
     const bool lds_marks = lds_need != 0;
     int q = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false>, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
         (void)hipGetLastError();
         q = 8;
     }
@@ -1329,8 +1355,25 @@ int poa_waves_per_cu(int ncap)
     return q;
 }
 
-// workspace = slots * slot_bytes
-size_t poa_slot_bytes(int ncap, int deg, int lmax) { return (size_t)make_layout(ncap, deg, lmax).total; }
+// workspace = main slots | counter block | main work list | long-window list | long slots
+size_t poa_slot_bytes(int ncap, int deg, int lmax, bool long_slot) { return (size_t)make_layout(ncap, deg, lmax, long_slot).total; }
+namespace {
+struct PoaWs { size_t counters, wlist, llist, lslots, total; };
+PoaWs poa_ws(const gbx_poa_plan *pl)
+{
+    PoaWs w;
+    const size_t ms = poa_slot_bytes(pl->node_cap, pl->max_seqs_per_window, pl->max_seq_len, false);
+    const size_t ls = pl->long_slots > 0 ? poa_slot_bytes(pl->node_cap, pl->max_seqs_per_window, pl->max_seq_len, true) : 0;
+    const size_t nw = (size_t)(pl->n_windows > 0 ? pl->n_windows : 0), nl = (size_t)(pl->n_long_windows > 0 ? pl->n_long_windows : 0);
+    w.counters = ms * (size_t)(pl->n_slots > 0 ? pl->n_slots : 0);
+    w.wlist = w.counters + POA_NCOUNTERS * 8;
+    w.llist = w.wlist + ((nw * 4 + 255) & ~(size_t)255);
+    w.lslots = w.llist + ((nl * 4 + 255) & ~(size_t)255);
+    w.total = w.lslots + ls * (size_t)pl->long_slots;
+    return w;
+}
+}  // namespace
+size_t poa_workspace_bytes(const gbx_poa_plan *plan) { return poa_ws(plan).total; }
 
 int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s)
 {
@@ -1353,25 +1396,29 @@ bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax)
     return !(worst < -30000 || worst_mis < -30000 || hi > 30000);
 }
 
-int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
-               const int32_t *d_seq_len, const uint8_t *d_arena, int lmax, int deg, int ncap, int n_slots,
+int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
+               const int32_t *d_seq_len, const uint8_t *d_arena,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
                void *d_work, size_t work_bytes, hipStream_t s)
 {
     if (n_windows == 0) return GBX_OK;
+    if (n_windows != plan->n_windows) { set_error("poa: the plan was made for %lld windows, the call has %lld", (long long)plan->n_windows, (long long)n_windows); return GBX_ERR_ARG; }
+    const int lmax = plan->max_seq_len, deg = plan->max_seqs_per_window, ncap = plan->node_cap;
     PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c};
     if (S.g > 0 || S.q > 0 || S.e > 0 || S.c > 0) { set_error("poa: gap penalties must be non-positive"); return GBX_ERR_ARG; }
     if (S.g >= S.e) { set_error("poa: linear gap mode (g >= e) is not supported by the device path"); return GBX_ERR_UNSUPPORTED; }
     if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }          // affine == convex with both pieces equal
-    const SlotLayout L = make_layout(ncap, deg, lmax);
-    if (work_bytes < (size_t)L.total * (size_t)n_slots + 128) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
-    unsigned long long *d_cells = (unsigned long long *)((char *)d_work + (size_t)L.total * (size_t)n_slots);
-    GBX_HIP(hipMemsetAsync(d_cells, 0, 128, s));
+    const PoaWs ws = poa_ws(plan);
+    if (work_bytes < ws.total) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
+    if (n_windows >= ((int64_t)1 << 31)) { set_error("poa: more than 2^31 windows in one call"); return GBX_ERR_UNSUPPORTED; }
+    char *wb = (char *)d_work;
+    unsigned long long *d_cells = (unsigned long long *)(wb + ws.counters);
+    GBX_HIP(hipMemsetAsync(d_cells, 0, POA_NCOUNTERS * 8, s));
     const Mat2 T = {S.e, S.g, S.q, S.c};
     PoaArgs A;
     A.n_windows = n_windows; A.win_first_seq = d_win_first_seq; A.seq_off = d_seq_off; A.seq_len = d_seq_len;
     A.arena = d_arena; A.cons = d_cons; A.cons_len = d_cons_len; A.status = d_status; A.cons_stride = cons_stride;
-    A.work = (char *)d_work; A.slot_bytes = L.total; A.cells = d_cells; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
+    A.cells = d_cells; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
     for (int v = 0; v < 2; ++v) {
         A.Tc[v][0] = mp_pow(T, v == 0 ? 8 : 16);
         for (int k = 1; k < 4; ++k) A.Tc[v][k] = mp_mul(A.Tc[v][k - 1], A.Tc[v][k - 1]);
@@ -1381,17 +1428,45 @@ int poa_launch(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_
         set_error("poa: scores may leave the int16 range for these capacities (nodes %d, length %d)", ncap, lmax);
         return GBX_ERR_UNSUPPORTED;
     }
-    const int grid = (int)std::min<int64_t>(n_windows, n_slots);
     int lds_stack = 0;
     const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
     A.lds_marks = lds_need != 0 ? 1 : 0;
     A.lds_stack = lds_stack;
-    if (n_windows >= ((int64_t)1 << 28)) { set_error("poa: more than 2^28 windows in one call"); return GBX_ERR_UNSUPPORTED; }   // cursor: POA_SWEEPS x windows in 32 bits
-    hipLaunchKernelGGL(poa_job_stats_kernel, dim3(1), dim3(64), 0, s, A);
-    {
-        Stage st("poa_window", s);
-        hipLaunchKernelGGL(poa_kernel, dim3(grid), dim3(64), A.lds_marks ? lds_need : 0, s, A, L);
+    int32_t *d_wlist = (int32_t *)(wb + ws.wlist), *d_llist = (int32_t *)(wb + ws.llist);
+    A.work = wb; A.slot_bytes = 0; A.wlist = d_wlist; A.cnt_idx = POA_CNT_MAIN; A.cur_idx = POA_CUR_MAIN;
+    hipLaunchKernelGGL(poa_classify_kernel, dim3(1), dim3(1024), 0, s, A, d_wlist, d_llist, plan->n_long_windows);
+    // the few windows with a long sequence: their own launch on a side stream, beside the main one (alone they would be a
+    // serial tail: a window takes tens of milliseconds whatever else runs)
+    const bool has_long = plan->long_slots > 0 && plan->n_long_windows > 0;
+    const bool has_main = plan->n_slots > 0 && n_windows > plan->n_long_windows;
+    SideStreams *ss = nullptr;
+    std::unique_lock<std::mutex> side_lock;
+    int rc;
+    if (has_long && has_main) {
+        if ((rc = side_streams(&ss))) return rc;
+        side_lock = std::unique_lock<std::mutex>(ss->mu);
+        if ((rc = ss->fork(s))) return rc;
     }
+    if (has_long) {
+        const SlotLayout LL = make_layout(ncap, deg, lmax, true);
+        PoaArgs B = A;
+        B.work = wb + ws.lslots; B.slot_bytes = LL.total; B.wlist = d_llist; B.cnt_idx = POA_CNT_LONG; B.cur_idx = POA_CUR_LONG;
+        hipStream_t sl = ss ? ss->side[0] : s;
+        Stage st("poa_window_long", sl);
+        hipLaunchKernelGGL(poa_kernel<true>, dim3(plan->long_slots), dim3(64), A.lds_marks ? lds_need : 0, sl, B, LL);
+    }
+    if (has_main) {
+        const SlotLayout L = make_layout(ncap, deg, lmax, false);
+        A.slot_bytes = L.total;
+        // (the long launch was queued first and its wavefronts need their place on the chip: a full main grid would keep them
+        // out until its first wavefronts retire, i.e. turn the long windows into a tail)
+        int64_t resident = plan->n_slots;
+        if (has_long && resident > 2 * (int64_t)plan->long_slots) resident -= plan->long_slots;
+        const int grid = (int)std::min<int64_t>(n_windows - plan->n_long_windows, resident);
+        Stage st("poa_window", s);
+        hipLaunchKernelGGL(poa_kernel<false>, dim3(grid), dim3(64), A.lds_marks ? lds_need : 0, s, A, L);
+    }
+    if (ss && (rc = ss->join(s))) return rc;
     GBX_HIP(hipGetLastError());
     return GBX_OK;
 }

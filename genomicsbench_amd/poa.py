@@ -64,7 +64,7 @@ def consensus_host(params, ws, stride=None):
 
 class PoaPlan(C.Structure):
     _fields_ = [("max_seq_len", C.c_int32), ("max_seqs_per_window", C.c_int32), ("node_cap", C.c_int32),
-                ("n_slots", C.c_int32)]
+                ("n_slots", C.c_int32), ("n_long_windows", C.c_int32), ("long_slots", C.c_int32), ("n_windows", C.c_int64)]
 
 
 class DevicePoaWindowSet:

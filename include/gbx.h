@@ -240,6 +240,11 @@ typedef struct gbx_poa_plan {
     int32_t max_seqs_per_window;  /* bounds the fan-in / fan-out of a graph node          */
     int32_t node_cap;             /* graph nodes per window the workspace can hold       */
     int32_t n_slots;              /* windows processed concurrently (one wavefront each) */
+    /* Windows that hold a sequence of more than 512 bases run on a second launch with slots of their own (five int16
+     * planes per DP matrix instead of two): a handful of long sequences must not size every slot of the job. */
+    int32_t n_long_windows;       /* windows with a sequence longer than 512             */
+    int32_t long_slots;           /* slots of the second launch (0 when there is none)   */
+    int64_t n_windows;            /* windows the plan was made for                       */
 } gbx_poa_plan;
 
 #define GBX_POA_MAX_SEQS_PER_WINDOW 255

@@ -14,7 +14,12 @@ d = DevicePoaWindowSet(ws, torch.device("cuda:0"))
 p = make_params()
 d.run(p); torch.cuda.synchronize()
 t = time.perf_counter(); d.run(p); torch.cuda.synchronize(); ms = (time.perf_counter() - t) * 1e3
-c = d.work[d.work_bytes - 128:].cpu().numpy().view(np.uint64)
+import ctypes as C
+from genomicsbench_amd import _native as N
+N.lib().gbx_debug_poa_counter_offset.restype = C.c_size_t
+off = N.lib().gbx_debug_poa_counter_offset(C.byref(d.plan))
+c = d.work[off:off + 256].cpu().numpy().view(np.uint64)
+print("plan: slots %d, long windows %d on %d slots, workspace %.2f GB" % (d.plan.n_slots, d.plan.n_long_windows, d.plan.long_slots, d.work_bytes / 1e9))
 dp, tb, add, cons, topo, topo_n, vis, blk, dfs = [int(x) for x in c[1:10]]
 tot = dp + tb + add + cons
 print("%d windows %.1f ms; wave clocks: DP %.1f%%  traceback %.1f%%  add_alignment %.1f%% (of which topological sort %.1f%%, DFS part %.1f%%)  consensus %.1f%%" % (

@@ -4,7 +4,7 @@ import pytest
 
 from genomicsbench_amd import _native as N
 from genomicsbench_amd.datagen import gen_poa
-from genomicsbench_amd.poa import PoaWindowSet, consensus_host, make_params
+from genomicsbench_amd.poa import DevicePoaWindowSet, PoaWindowSet, consensus_host, make_params
 from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
@@ -109,3 +109,41 @@ def test_deep_unrelated_window_is_redone_with_a_larger_graph():
     want = O.poa_oracle(p, ws, 4)
     assert len(want[1]) > 0
     diff(consensus_host(p, ws), want)
+
+
+def test_windows_with_long_sequences_take_the_second_launch():
+    """A few sequences of more than 512 bases must not size every slot of the job: their windows go to a second launch with
+    five-plane slots of their own (column-block DP), the others keep two-plane slots.  Results are the oracle's for both."""
+    import ctypes as C
+    from genomicsbench_amd.poa import PoaPlan
+    rng = np.random.default_rng(12)
+    def window(L, n):
+        base = "".join(rng.choice(list("ACGT"), L))
+        out = []
+        for _ in range(n):
+            s = list(base)
+            for k in rng.choice(L, max(L // 20, 1), replace=False):
+                s[k] = "ACGT"[rng.integers(4)]
+            cut = int(rng.integers(0, 12))
+            out.append("".join(s)[cut:])
+        return out
+    lens = [300, 520, 180, 700, 400, 513, 512, 90, 1100, 250, 333, 512]
+    windows = [window(L, 6 + i % 5) for i, L in enumerate(lens)]
+    windows[1][0] = windows[1][0][:500]                       # a long window also holds short sequences
+    ws = PoaWindowSet.from_lists(windows)
+    plan = PoaPlan()
+    N.check(N.lib().gbx_poa_plan_host(ws.n_windows, N.ptr(ws.win_first_seq), N.ptr(ws.seq_len), C.byref(plan)))
+    n_long = sum(any(len(s) > 512 for s in w) for w in windows)
+    assert plan.n_long_windows == n_long >= 3 and plan.long_slots == n_long and plan.n_slots == ws.n_windows - n_long and plan.n_windows == ws.n_windows
+    p = make_params()
+    want = O.poa_oracle(p, ws, 4)
+    assert consensus_host(p, ws) == want
+    import torch
+    d = DevicePoaWindowSet(ws, torch.device("cuda:0"))
+    d.run(p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d.results() == want
+    # every window long / no window long
+    for sub in ([windows[3], windows[8]], [windows[0], windows[2], windows[7]]):
+        w2 = PoaWindowSet.from_lists(sub)
+        assert consensus_host(p, w2) == O.poa_oracle(p, w2, 2)
