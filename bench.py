@@ -590,18 +590,45 @@ class AbeaWork:
 WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork, "abea": AbeaWork}
 _PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy"),
                   "valu_insts": ("profiles/valu_insts.json", "valu_insts")}
-VALU_PEAK_FP32 = 7.86e13     # lane-ops/s the guide's vector FP32 rate implies (256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz)
-VALU_PEAK_INT32 = 3.93e13    # one wave64 integer instruction per SIMD every 4 cycles (16 lanes per cycle)
+_KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip"}
 
 
-def _committed(kind, kernel_name, default_size):
-    """HBM bytes per launch / VALU-busy fraction of a kernel from the committed rocprofv3 --pmc passes (they cannot be
-    collected inside the run that prints the line: PMC passes serialise the kernels); only for the default sizes."""
-    rel, key = _PROFILE_FILES[kind]
+def _hip_sha16(kind):
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "genomicsbench_amd", "csrc", _KIND_SOURCE[kind]), "rb").read()).hexdigest()[:16]
+
+
+def _committed(kind, what, kernel_name, default_size):
+    """HBM bytes per launch / VALU-busy fraction / VALU instructions of a kernel from the committed rocprofv3 --pmc passes (they
+    cannot be collected inside the run that prints the line: PMC passes serialise the kernels); only for the default sizes,
+    and only while the kernel source is the one the counters were collected on (scripts/make_profile_tables.py stamps the
+    hash of the kind's .hip file into the table): after a kernel change the field is null until the passes are re-run."""
+    rel, key = _PROFILE_FILES[what]
     path = os.path.join(ROOT, rel)
     if not default_size or not os.path.exists(path):
         return None, None
-    return json.load(open(path)).get(key, {}).get(kernel_name), rel
+    table = json.load(open(path))
+    if table.get("hip_sha16", {}).get(kind) != _hip_sha16(kind):
+        return None, rel + " (stale: %s changed since the counters were collected)" % _KIND_SOURCE[kind]
+    return table.get(key, {}).get(kernel_name), rel
+
+
+def _valu_roof(kind, kernel_name):
+    """Lane operations per second a chip issuing nothing but this kernel's VALU instruction mix would reach: the kernel's
+    static mix (scripts/isa_mix.py) weighted with the measured per-form issue rates (scripts/valu_peak.hip ->
+    profiles/valu_peak.json).  None when the mix table was made from another source."""
+    path = os.path.join(ROOT, "profiles", "valu_mix.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    if t.get("csrc_sha16", {}).get(_KIND_SOURCE[kind]) != _hip_sha16(kind):
+        return None, None
+    rows = [v for v in t["kernels"].values() if v["stage"] == kernel_name or (kernel_name.startswith("bsw_lane_c") and v["stage"] == "bsw_lane_compact")
+            or (kernel_name.startswith("bsw_lane_w") and v["stage"] == "bsw_lane_wide")]
+    if not rows:
+        return None, None
+    r = max(rows, key=lambda v: v["valu_static"])
+    return r["roof_lane_ops_per_s"], r["mean_cycles_per_valu"]
 
 
 def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
@@ -697,26 +724,31 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     k_ms = ms_sum / max(launches, 1)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     default_size = not args.size and per_gpu_units is None and world == 1
-    traffic, tsrc = _committed("traffic", name, default_size)
-    valu_b, vsrc = _committed("valu_busy", name, default_size)
+    traffic, tsrc = _committed(kind, "traffic", name, default_size)
+    valu_b, vsrc = _committed(kind, "valu_busy", name, default_size)
     valu = None
-    vi, visrc = _committed("valu_insts", name, default_size)
+    vi, visrc = _committed(kind, "valu_insts", name, default_size)
+    roof, mean_cyc = _valu_roof(kind, name)
     if vi and k_units:
-        # VALU issue of the dominant kernel: committed SQ_INSTS_VALU per launch x 64 lanes over the units it processes and
-        # over its live duration in this run; bsw / phmm / chain are bound by this, not by HBM
+        # VALU issue of the dominant kernel: committed SQ_INSTS_VALU per launch x 64 lanes over the units it processes and over
+        # its live duration in this run, against the measured roof of its own instruction mix (profiles/valu_peak.json: a
+        # wave64 v_add / v_and / v_mov issues in 2.25 SIMD cycles, v_max / v_max3 / compares / selects / DPP / SDWA / packed
+        # forms in 4.17): bsw / phmm / abea are bound by this, not by HBM
         lane_ops = vi * 64.0
-        valu = {"lane_ops_per_unit": lane_ops / k_units, "lane_ops_per_s": lane_ops / (k_ms * 1e-3),
-                "frac_of_7.86e13": lane_ops / (k_ms * 1e-3) / VALU_PEAK_FP32,
-                "frac_of_int32_issue_3.93e13": lane_ops / (k_ms * 1e-3) / VALU_PEAK_INT32, "insts_source": visrc}
+        valu = {"lane_ops_per_unit": lane_ops / k_units, "lane_ops_per_s": lane_ops / (k_ms * 1e-3), "insts_source": visrc,
+                "roof_lane_ops_per_s": roof, "mean_cycles_per_valu_instruction": mean_cyc,
+                "roof_source": "profiles/valu_mix.json x profiles/valu_peak.json" if roof else None}
+        if roof:
+            valu["frac"] = min(1.0, lane_ops / (k_ms * 1e-3) / roof)
         if kind == "bsw":
             allk = json.load(open(os.path.join(ROOT, "profiles/valu_insts.json")))["valu_insts"]
             tot = 64.0 * sum(v for kk, v in allk.items() if kk.startswith("bsw_"))
+            # the class kernels overlap on four streams, so the job-level rate is the meaningful one: every bsw kernel's lane
+            # operations over the step time
             valu["job_lane_ops_per_nominal_cell"] = tot / work.units
-            # the class kernels overlap on four streams, so the job-level rate is the meaningful one: every bsw kernel's
-            # lane operations over the step time
             valu["job_lane_ops_per_s"] = tot / (dt_max / steps)
-            valu["job_frac_of_7.86e13"] = valu["job_lane_ops_per_s"] / VALU_PEAK_FP32
-            valu["job_frac_of_int32_issue_3.93e13"] = valu["job_lane_ops_per_s"] / VALU_PEAK_INT32
+            if roof:
+                valu["job_frac"] = min(1.0, valu["job_lane_ops_per_s"] / roof)
     cfg = {"workload": label or work.workload, "mode": args.mode if world > 1 else "single",
            "parallelism": ("units sharded over %d rank(s) in contiguous cost-balanced ranges, no data-path collective; "
                            % world) + ("rank 0 scatters packed shards / gathers outputs over RCCL p2p"

@@ -17,8 +17,15 @@ import os
 import re
 import sys
 
+import hashlib
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+CSRC = os.path.join(ROOT, "genomicsbench_amd", "csrc")
+KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip"}
+
+
+def sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 WIDE_READS = ("poa_window", "phmm_stream", "phmm_f32", "phmm_f64", "abea_align")      # kernels whose reads are 16-byte-per-lane vectors
 
 
@@ -27,6 +34,15 @@ def stage_name(kname):
     m = re.match(r"bsw_rows_kernel<(\d+), (\d+), \w+>", kname)
     if m:
         return "bsw_rows_%sx%s" % (m.group(1), m.group(2))
+    m = re.match(r"bsw_lane_kernel<\w+, (\w+)>(?:@(\d+))?", kname)
+    if m:
+        # one symbol, five launches per format: the launch is identified by its LDS size (bsw_kernels.hip: bsw_launch)
+        if not m.group(2):
+            return "bsw_lane_compact" if m.group(1) == "true" else "bsw_lane_wide"
+        lds = int(m.group(2))
+        if m.group(1) == "true":
+            return "bsw_lane_c%d" % {50: 47, 82: 79, 102: 99, 138: 135, 162: 159}.get((lds - 640) // 384 * 2, 0)
+        return "bsw_lane_w%d" % ((lds // 256 - 2) - 3 | 1)
     m = re.match(r"phmm_stream_kernel<(\d+)>", kname)
     if m:
         return "phmm_stream_rpl" + m.group(1)
@@ -35,6 +51,8 @@ def stage_name(kname):
     m = re.match(r"phmm_f32_kernel<(\d+)>", kname)
     if m:
         return "phmm_f32_rpl" + m.group(1)
+    if kname.startswith("poa_kernel<"):
+        return "poa_window" if "false" in kname else "poa_window_long"
     return {"poa_kernel": "poa_window", "chain_kernel": "chain_dp", "chain_st_kernel": "chain_st", "bsw_lds_kernel": "bsw_lds",
             "bsw_classify_kernel": "bsw_classify", "phmm_f64_kernel<4>": "phmm_f64_redo", "bsw_unpack4_kernel": "bsw_unpack4",
             "abea_kernel": "abea_align"}.get(kname, kname)
@@ -47,29 +65,40 @@ def committed(name, key):
         return {}
 
 
-traffic, busy, insts = committed("hbm_traffic.json", "detail"), committed("valu_busy.json", "valu_busy"), committed("valu_insts.json", "valu_insts")
-for k in ("bsw", "chain", "phmm", "poa", "abea"):
-    path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
-    if not os.path.exists(path):
-        continue
-    for kname, v in json.load(open(path)).items():
-        if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_")):
+
+def main():
+    tag = sys.argv[1]
+
+    traffic, busy, insts = committed("hbm_traffic.json", "detail"), committed("valu_busy.json", "valu_busy"), committed("valu_insts.json", "valu_insts")
+    # which source the counters of a kind were collected on: bench.py drops a kind's figures when its .hip file has changed since
+    stamps = committed("hbm_traffic.json", "hip_sha16")
+    for k in ("bsw", "chain", "phmm", "poa", "abea"):
+        path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
+        if not os.path.exists(path):
             continue
-        name = stage_name(kname)
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            f, w = v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
-            wide = name.startswith(WIDE_READS)
-            traffic[name] = {"fetch_raw": int(f), "write": int(w), "fetch_factor": 2 if wide else 1, "bytes": int(f * (2 if wide else 1) + w)}
-        if "valu_busy" in v:
-            busy[name] = v["valu_busy"]
-        if "SQ_INSTS_VALU" in v:
-            insts[name] = int(v["SQ_INSTS_VALU"])
-note = ("rocprofv3 --pmc, separate passes per counter group (scripts/pmc.sh), default 'large' sizes, tag %s; units and the gfx950 "
-        "FETCH_SIZE correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (see scripts/make_profile_tables.py)" % tag)
-json.dump({"note": note, "bytes_per_launch": {k: v["bytes"] for k, v in traffic.items()}, "detail": traffic},
-          open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
-json.dump({"note": "fraction of SIMD cycles in which the VALU issues; " + note, "valu_busy": busy},
-          open(os.path.join(ROOT, "profiles", "valu_busy.json"), "w"), indent=1)
-json.dump({"note": "SQ_INSTS_VALU per launch (wave-level instructions, x 64 lanes = lane operations); " + note, "valu_insts": insts},
-          open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
-print("kernels: traffic %d, valu_busy %d, valu_insts %d" % (len(traffic), len(busy), len(insts)))
+        stamps[k] = sha16(os.path.join(CSRC, KIND_SOURCE[k]))
+        for kname, v in json.load(open(path)).items():
+            if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_")):
+                continue
+            name = stage_name(kname)
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                f, w = v["FETCH_SIZE"] * 1024.0, v["WRITE_SIZE"] * 1024.0
+                wide = name.startswith(WIDE_READS)
+                traffic[name] = {"fetch_raw": int(f), "write": int(w), "fetch_factor": 2 if wide else 1, "bytes": int(f * (2 if wide else 1) + w)}
+            if "valu_busy" in v:
+                busy[name] = v["valu_busy"]
+            if "SQ_INSTS_VALU" in v:
+                insts[name] = int(v["SQ_INSTS_VALU"])
+    note = ("rocprofv3 --pmc, separate passes per counter group (scripts/pmc.sh), default 'large' sizes, tag %s; units and the gfx950 "
+            "FETCH_SIZE correction as /opt/skills/guides/MI355X_MICROARCH.md prescribes (see scripts/make_profile_tables.py)" % tag)
+    json.dump({"note": note, "hip_sha16": stamps, "bytes_per_launch": {k: v["bytes"] for k, v in traffic.items()}, "detail": traffic},
+              open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+    json.dump({"note": "fraction of SIMD cycles in which the VALU issues; " + note, "hip_sha16": stamps, "valu_busy": busy},
+              open(os.path.join(ROOT, "profiles", "valu_busy.json"), "w"), indent=1)
+    json.dump({"note": "SQ_INSTS_VALU per launch (wave-level instructions, x 64 lanes = lane operations); " + note, "hip_sha16": stamps, "valu_insts": insts},
+              open(os.path.join(ROOT, "profiles", "valu_insts.json"), "w"), indent=1)
+    print("kernels: traffic %d, valu_busy %d, valu_insts %d" % (len(traffic), len(busy), len(insts)))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
+        kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gbx::", "").split("(")[0][-60:]
+        if kn.startswith("bsw_lane_kernel"): kn += "@" + r["LDS_Block_Size"]      # one symbol, one launch per LDS class
         agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
         if key not in seen: seen.add(key); cnt[(f, kn)] += 1
