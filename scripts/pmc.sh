@@ -19,7 +19,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gbx::", "").split("(")[0][-60:]
-        if kn.startswith("bsw_lane_kernel"): kn += "@" + r["LDS_Block_Size"]      # one symbol, one launch per LDS class
+        if kn.startswith("bsw_lane_kernel"): kn += "@" + str(int(r["Grid_Size"]) // 64 // 256)      # one symbol, a launch per LDS class: told apart by resident blocks per CU (dynamic LDS is not in the record)
         agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (f, r["Dispatch_Id"])
         if key not in seen: seen.add(key); cnt[(f, kn)] += 1

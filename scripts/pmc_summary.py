@@ -5,7 +5,7 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=Tru
     for r in csv.DictReader(open(f)):
         m = re.search(r"(\w+)(<[^>]*>)?\(", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
         kn = (m.group(1) + (m.group(2) or "")) if m else r["Kernel_Name"][:40]
-        if kn.startswith("bsw_lane_kernel"): kn += "@" + r["LDS_Block_Size"]      # one symbol, one launch per LDS class
+        if kn.startswith("bsw_lane_kernel"): kn += "@" + str(int(r["Grid_Size"]) // 64 // 256)      # one symbol, a launch per LDS class: told apart by resident blocks per CU (dynamic LDS is not in the record)
         agg[kn][r["Counter_Name"]] += float(r["Counter_Value"]); n[(kn, f)].add(r["Dispatch_Id"])
 out = {}
 for kn, d in agg.items():
