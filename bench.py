@@ -247,6 +247,54 @@ class ChainWork:
     def finish(self, stream):
         self.units = float(self.d.evaluated_pairs(stream))
         self.extra["evaluated_pairs_per_gpu"] = int(self.units)
+        jobs, longest = self.d.job_stats(stream)
+        self.extra["jobs_this_gpu"], self.extra["longest_job_anchors"] = jobs, longest
+
+    def realistic(self, stream, steps=3):
+        """The same call sizes with minimap2's structure inside a call (both strands, six reference ids in the upper x
+        word, repeat copies, isolated hits: datagen.c gbx_gen_chain_fill_real) - the SURVEY 8d workload has one strand and
+        one reference id, i.e. none of the points where a call falls apart into independent jobs.  Reported beside the
+        'large' line, never as it; the first 40 calls are checked against the oracle."""
+        import torch
+        from genomicsbench_amd.chain import DeviceChainBatch
+        from genomicsbench_amd.datagen import gen_chain
+        from oracle import oracle_py as O
+        case = gen_chain(self.d.n_calls, self.seed, realistic=True)
+        d = DeviceChainBatch(*case, self.d.off.device)
+        d.run(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            d.run(stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        pairs = d.evaluated_pairs(stream)
+        jobs, longest = d.job_stats(stream)
+        results = d.results()
+        # the same job with every call as one wavefront job (GBX_CHAIN_NOSPLIT, a test aid): what the cuts buy
+        os.environ["GBX_CHAIN_NOSPLIT"] = "1"
+        try:
+            d.run(stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                d.run(stream)
+            torch.cuda.synchronize()
+            ms_whole = (time.perf_counter() - t0) * 1e3 / steps
+            same_whole = all(np.array_equal(a, b) for a, b in zip(results, d.results()))
+        finally:
+            del os.environ["GBX_CHAIN_NOSPLIT"]
+        off, ax, ay, hdr = case
+        m = min(40, len(off) - 1)
+        want = O.chain_oracle(off[:m + 1], ax[:off[m]], ay[:off[m]], hdr[:m], nthreads=min(os.cpu_count() or 1, 32))
+        same = all(np.array_equal(g[:off[m]], w) for g, w in zip(results, want))
+        return {"workload": "%d calls of the 'large' sizes, realistic structure (2 strands x 6 reference ids, 55 %% true locus / "
+                            "25 %% repeat copies / 20 %% isolated hits)" % d.n_calls,
+                "ms_per_step": ms, "value": pairs / (ms * 1e-3) / 1e9, "unit": self.unit, "anchors": int(d.n_anchors),
+                "evaluated_pairs": int(pairs), "jobs": int(jobs), "longest_job_anchors": int(longest),
+                "ms_per_step_one_job_per_call": ms_whole, "one_job_per_call_same_results": bool(same_whole),
+                "verified": "first %d calls (%d anchors) vs oracle, score/parent/target/peak: %s"
+                            % (m, int(off[m]), "identical" if same else "DIFFER")}
 
     def roofline_bytes(self, kernel):
         # 16 B anchor in + 4 x 4 B outputs (SURVEY 8d: 16 in + 8 out + 8 with targets / peaks exported)
@@ -776,6 +824,8 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         # the host-buffer entry first, on quiet host cores (the CPU baseline runs OpenMP teams on all of them)
         if hasattr(work, "host_entry"):
             line["host_entry"] = work.host_entry()
+        if hasattr(work, "realistic"):
+            line["realistic"] = work.realistic(stream)
         line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
     return line
 

@@ -119,6 +119,7 @@ def _declare(L):
         L.gbx_abea_align_device.argtypes = [i64] + [vp] * 11 + [i64, i64, vp, vp, vp, sz, vp]
         L.gbx_abea_cells.argtypes = [vp, C.POINTER(C.c_int64), vp]
     if hasattr(L, "gbx_chain_host"):
+        L.gbx_chain_job_stats.argtypes = [vp, i64, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
         L.gbx_chain_workspace_bytes.argtypes = [i64, i64]
         L.gbx_chain_workspace_bytes.restype = sz
         L.gbx_chain_host.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp]

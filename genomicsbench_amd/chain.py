@@ -68,6 +68,12 @@ class DeviceChainBatch:
         k = self.n_anchors
         return tuple(a[:k].cpu().numpy() for a in (self.score, self.parent, self.target, self.peak))
 
+    def job_stats(self, stream=None):
+        """(jobs, anchors of the longest job) of the last run(): calls are cut into independent pieces on the device."""
+        j, m = C.c_int64(0), C.c_int64(0)
+        N.check(N.lib().gbx_chain_job_stats(self.work.data_ptr(), self.n_calls, self.n_anchors, C.byref(j), C.byref(m), stream))
+        return j.value, m.value
+
     def evaluated_pairs(self, stream=None):
         """Predecessor pairs visited by the last run() (device-side counter)."""
         v = C.c_int64(0)

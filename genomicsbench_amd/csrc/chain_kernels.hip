@@ -19,14 +19,22 @@
 //            prefix-max for "sc > max_f", and n_skip as a walk reflected at 0
 //            (prefix sum + prefix min); first lane with n_skip > max_skip breaks;
 //   phase 4  targets[parents[j]] = i for the lanes before the break (:89).
-// Calls are handed out longest-first, round-robin over the resident wavefronts
-// (the longest call bounds the kernel's makespan).
+// Work unit = a *job*: a call, or a piece of one.  For sorted x the first predecessor st(i) is non-decreasing, so
+// an anchor c with st(c) == c (it looks back at nobody, :56) is a point no later anchor looks across either: the
+// anchors [c, next such point) only ever read, mark (targets[parents[j]], :89) and point at (parents) anchors of
+// their own piece, and the piece is an independent chain_dp over a slice of the call whose parent / target values
+// are offset by c.  Real minimap2 calls (both strands and many reference ids packed into x, repeat hits far from
+// the true locus) are full of such points; chain_st_kernel finds them, chain_jobs_kernel turns them into jobs (at
+// most one cut per 64 anchors, so the job list is bounded), and a piece whose anchors share one upper x word and
+// one segment id takes the narrow 32-bit path even when its call as a whole could not.
+// Jobs are handed out longest-first from a cursor (the longest job bounds the kernel's makespan).
 #include "gbx_internal.h"
 
 namespace gbx {
 namespace {
 
 constexpr int NBUCKET = 32;
+constexpr int CHAIN_MAX_DEVICES = 64;
 typedef __attribute__((address_space(3))) int lds_int;
 
 template <int CTRL, int ROWMASK = 0xf>
@@ -64,14 +72,23 @@ __device__ inline int wave_scan_add(int x)                     // identity 0
 constexpr unsigned UBIAS = 1u << 30;                           // scores and skip counters are far inside +-2^30
 
 struct ChainWork {
-    int32_t *counts;    // [NBUCKET] calls per size bucket
+    int32_t *counts;    // [NBUCKET] jobs per size bucket
     int32_t *cursors;   // [NBUCKET]
-    int32_t *next;      // work cursor
-    int32_t *order;     // [n_calls] calls, longest bucket first
+    int32_t *next;      // [0] the DP kernel's job cursor, [4] ring choice, [5] number of jobs
+    int32_t *order;     // [max_jobs] jobs, longest bucket first
     unsigned long long *evaluated;   // predecessor pairs visited (the benchmark's "cell")
     int32_t *st;        // [n_anchors] first predecessor of every anchor (chain_st_kernel)
-    int32_t *unsorted;  // [n_calls] bit 0: the call's x are not sorted (the DP kernel walks st itself); bit 1: several
-                        // segment ids or upper x words in the call (the DP kernel's general 64-bit path)
+    int32_t *unsorted;  // [n_calls] bit 0: the call's x are not sorted (one job, the DP kernel walks st itself); bit 1:
+                        // preset by GBX_CHAIN_WIDE (every job of the call on the general 64-bit path)
+    // per aligned block of 64 anchors of a call (index ((off + 64 w) >> 6) + call: unique and increasing)
+    int8_t *blk_cut;    // position of the block's first anchor with st(i) == i, i > 0 (a cut), or -1
+    unsigned long long *blk_diff;   // lanes whose upper x word or segment id differs from the preceding anchor's
+    // jobs (chain_jobs_kernel)
+    int64_t *job_start; // [max_jobs] first anchor (index into the concatenated arrays)
+    int32_t *job_n;     // [max_jobs] anchors
+    int32_t *job_call;  // [max_jobs]
+    int32_t *job_flag;  // [max_jobs] bit 1: several segment ids or upper x words inside the job (general 64-bit path)
+    int32_t max_jobs;
 };
 
 __device__ inline int bucket_of(int64_t n)
@@ -81,11 +98,11 @@ __device__ inline int bucket_of(int64_t n)
     return NBUCKET - 1 - min(lg, NBUCKET - 1);
 }
 
-__global__ void __launch_bounds__(256) chain_order_kernel(int64_t n_calls, const int64_t *off, ChainWork W, int pass)
+__global__ void __launch_bounds__(256) chain_order_kernel(ChainWork W, int pass)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_calls) return;
-    const int b = bucket_of(off[c + 1] - off[c]);
+    if (c >= W.next[5]) return;
+    const int b = bucket_of(W.job_n[c]);
     if (pass == 0) { atomicAdd(&W.counts[b], 1); return; }
     int base = 0;
     for (int k = 0; k < b; ++k) base += W.counts[k];
@@ -148,7 +165,8 @@ __device__ inline uint64_t readlane64(uint64_t v, int k)
 __global__ void __launch_bounds__(256) chain_st_kernel(int n_calls, const int64_t *__restrict__ off, const uint64_t *__restrict__ ax,
                                                        const uint64_t *__restrict__ ay,
                                                        const gbx_chain_call *__restrict__ hdr, int32_t *__restrict__ st_out,
-                                                       int32_t *__restrict__ unsorted)
+                                                       int32_t *__restrict__ unsorted, int8_t *__restrict__ blk_cut,
+                                                       unsigned long long *__restrict__ blk_diff)
 {
     const int call = blockIdx.x;
     if (call >= n_calls) return;
@@ -156,34 +174,110 @@ __global__ void __launch_bounds__(256) chain_st_kernel(int n_calls, const int64_
     const int n = (int)(off[call + 1] - o);
     const uint64_t *x = ax + o, *y = ay + o;
     const uint64_t mdx = (uint64_t)(int64_t)hdr[call].max_dist_x;
-    bool bad = false, wide = false;
-    const uint64_t x0 = n ? x[0] : 0, y0 = n ? y[0] : 0;
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
-        const uint64_t ri = x[i];
-        if (i > 0 && x[i - 1] > ri) bad = true;
-        // the DP kernel's narrow path needs one segment id (y bits 48-55) and one upper x word (strand + reference id,
-        // host_data.h) in the whole call: true of every minimap2 call on one reference sequence
-        if ((ri ^ x0) >> 32 || ((y[i] ^ y0) >> 48 & 0xff)) wide = true;
-        // gallop backwards from i, then bisect: lo = last known far index (or -1), hi = known not-far index
-        int hi = i, lo = -1, step = 32;
-        const int floor_ = i - GBX_CHAIN_MAX_ITER > 0 ? i - GBX_CHAIN_MAX_ITER : 0;
-        while (hi > floor_) {
-            int probe = hi - step;
-            if (probe < floor_) probe = floor_;
-            if (ri > x[probe] + mdx) { lo = probe; break; }
-            hi = probe;
-            step <<= 1;
+    bool bad = false;
+    const int lane = threadIdx.x & 63;
+    // a wavefront takes an aligned block of 64 anchors of the call at a time (i0 is wave-uniform)
+    for (int i0 = blockIdx.y * 256 + (threadIdx.x & ~63); i0 < n; i0 += gridDim.y * 256) {
+        const int i = i0 + lane;
+        bool cut = false, diff = false;
+        if (i < n) {
+            const uint64_t ri = x[i];
+            if (i > 0) {
+                const uint64_t rp = x[i - 1];
+                if (rp > ri) bad = true;
+                // the DP kernel's narrow path needs one segment id (y bits 48-55) and one upper x word (strand + reference
+                // id, host_data.h) in the whole job
+                diff = ((ri ^ rp) >> 32) || ((y[i] ^ y[i - 1]) >> 48 & 0xff);
+            }
+            // gallop backwards from i, then bisect: lo = last known far index (or -1), hi = known not-far index
+            int hi = i, lo = -1, step = 32;
+            const int floor_ = i - GBX_CHAIN_MAX_ITER > 0 ? i - GBX_CHAIN_MAX_ITER : 0;
+            while (hi > floor_) {
+                int probe = hi - step;
+                if (probe < floor_) probe = floor_;
+                if (ri > x[probe] + mdx) { lo = probe; break; }
+                hi = probe;
+                step <<= 1;
+            }
+            if (lo < 0) lo = floor_ - 1;                      // everything down to the floor is near
+            while (hi - lo > 1) {
+                const int mid = (hi + lo) >> 1;
+                if (ri > x[mid] + mdx) lo = mid; else hi = mid;
+            }
+            st_out[o + i] = hi;                               // first not-far index >= floor (hi == i when all are far)
+            cut = hi == i && i > 0;                           // nobody to look back at: no later anchor looks across i
         }
-        if (lo < 0) lo = floor_ - 1;                      // everything down to the floor is near
-        while (hi - lo > 1) {
-            const int mid = (hi + lo) >> 1;
-            if (ri > x[mid] + mdx) lo = mid; else hi = mid;
+        const unsigned long long cm = __ballot(cut), dm = __ballot(diff);
+        if (lane == 0) {
+            const int64_t blk = ((o + i0) >> 6) + call;
+            blk_cut[blk] = cm ? (int8_t)__builtin_ctzll(cm) : (int8_t)-1;
+            blk_diff[blk] = dm;
         }
-        st_out[o + i] = hi;                               // first not-far index >= floor (hi == i when all are far)
     }
-    const int any_bad = __syncthreads_or(bad), any_wide = __syncthreads_or(wide);
-    const int fl = any_bad ? 3 : (any_wide ? 2 : 0);                                // unsorted calls take the wide path too
-    if (fl && threadIdx.x == 0) atomicOr(&unsorted[call], fl);
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&unsorted[call], 3);    // unsorted calls take the wide path too
+}
+
+// Jobs of a call: [0, c1), [c1, c2) ... at the cuts chain_st_kernel recorded (one per block of 64 anchors at most); an
+// unsorted call is one job.  One block per call; the job slots of a call are contiguous (one atomic per call), the
+// order kernel sorts the jobs by size afterwards.  job_flag is zero on entry.
+__global__ void __launch_bounds__(256) chain_jobs_kernel(int n_calls, const int64_t *__restrict__ off, ChainWork W, int split_on)
+{
+    const int call = blockIdx.x;
+    if (call >= n_calls) return;
+    const int64_t o = off[call];
+    const int n = (int)(off[call + 1] - o);
+    const int nb = (n + 63) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cflags = W.unsorted[call];
+    const bool split = split_on && !(cflags & 1);
+    const int64_t blk0 = (o >> 6) + call;                    // ((o + 64 b) >> 6) + call == blk0 + b
+    __shared__ int s_w[4];
+    __shared__ int s_base;
+    int cnt = 0;
+    if (split)
+        for (int b = tid; b < nb; b += 256) cnt += W.blk_cut[blk0 + b] >= 0;
+    for (int d = 32; d; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane == 0) s_w[wv] = cnt;
+    __syncthreads();
+    const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];      // cuts = jobs - 1
+    if (tid == 0) {
+        const int base = atomicAdd(&W.next[5], total + 1);
+        s_base = base;
+        W.job_start[base] = o;
+        W.job_call[base] = call;
+    }
+    __syncthreads();
+    const int base = s_base;
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + tid;
+        const int p = (split && b < nb) ? W.blk_cut[blk0 + b] : -1;
+        const unsigned long long dm = b < nb ? W.blk_diff[blk0 + b] : 0ull;
+        const unsigned long long m = __ballot(p >= 0);
+        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        __syncthreads();
+        if (lane == 0) s_w[wv] = (int)__builtin_popcountll(m);
+        __syncthreads();
+        int before = carry + below;
+        for (int k = 0; k < wv; ++k) before += s_w[k];
+        // the job open at the start of this block is base + before; a cut at position p opens base + before + 1
+        if (p >= 0) {
+            W.job_start[base + before + 1] = o + 64ll * b + p;
+            W.job_call[base + before + 1] = call;
+            if (dm & ((1ull << p) - 1)) atomicOr(&W.job_flag[base + before], 2);
+            if (p < 63 && (dm >> (p + 1))) atomicOr(&W.job_flag[base + before + 1], 2);
+        } else if (dm) {
+            atomicOr(&W.job_flag[base + before], 2);
+        }
+        carry += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int j = tid; j <= total; j += 256) {
+        const int64_t s0 = W.job_start[base + j];
+        const int64_t s1 = j < total ? W.job_start[base + j + 1] : o + n;
+        W.job_n[base + j] = (int)(s1 - s0);
+    }
 }
 
 // which of the two instances of chain_kernel runs this job (W.next[4]: 0 = the short ring, 1 = the long one).  The job is
@@ -219,16 +313,24 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     const int max_iter = GBX_CHAIN_MAX_ITER, max_skip = GBX_CHAIN_MAX_SKIP;
     const unsigned long long lane_bit = 1ull << lane;
 
-    // one call per block when the grid allows it (chain_launch), else a stride over the longest-first list;
-    // everything derived from `slot` stays wave-uniform
-    for (int slot = blockIdx.x; slot < n_calls; slot += gridDim.x) {
-        const int call = W.order[slot];
-        const int64_t o = off[call];
-        const int n = (int)(off[call + 1] - o);
+    // the resident blocks draw jobs from the longest-first list through a cursor: a dynamic LPT schedule.  Everything
+    // derived from `slot` stays wave-uniform
+    const int n_jobs = W.next[5];
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&W.next[0], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= n_jobs) break;
+        const int job = W.order[slot];
+        const int call = W.job_call[job];
+        const int64_t o = W.job_start[job];                   // the job's anchors are [o, o + n) of the concatenated arrays
+        const int n = W.job_n[job];
+        const int cbase = (int)(o - off[call]);               // ... and [cbase, cbase + n) of their call: indices below are
+                                                              // job-relative, parents and targets leave with cbase added
         const uint64_t *x = ax + o, *y = ay + o;
         int32_t *f = score + o, *p = parent + o, *t = target + o, *pk = peak + o;
         const int32_t *stp = W.st + o;
-        const int flags = W.unsorted[call];
+        const int flags = W.unsorted[call] | W.job_flag[job];
         const bool sorted = (flags & 1) == 0;
         unsigned long long visited = 0;
         // NARROW: one segment id and one upper x word in the whole call (and sorted x): `same` is always true and the
@@ -251,7 +353,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 // this block's anchors, one per lane
                 const int ia = min(ib + lane, n - 1);
                 const uint64_t xa = settle(x[ia]), ya = settle(y[ia]);
-                const int stv = settle(stp[ia]);
+                const int stv = settle(stp[ia]) - cbase;          // st(i) >= cbase for every anchor of the job
                 const int kmax = min(64, n - ib);
                 const int live0 = ib - RING_LIVE;                 // anchors >= live0 are addressed in the ring during this block
                 // the slab this block fills holds the anchors [ib-320, ib-256): their targets are final (no anchor of this
@@ -261,6 +363,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                 int of_ = 0, op_ = 0, ok_ = 0;                    // outputs of the block's anchors, anchor ib+k in lane k
                 for (int k = 0; k < kmax; ++k) {
                     const int i = ib + k, si = sib + k;           // si = i mod RING_PHYS
+                    const int iabs = i + cbase;                   // the reference's i: what targets[] holds (:89)
                     STAMP_RESET();
                     const uint64_t ri = readlane64(xa, k), yi = readlane64(ya, k);
                     const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
@@ -359,7 +462,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         { unsigned a_ = (unsigned)sc, b_ = skip; asm volatile("" :: "v"(a_), "v"(b_)); }
     #endif
                         STAMP(2);
-                        const bool hit = (marked != 0) | (tj == i);
+                        const bool hit = (marked != 0) | (tj == iabs);
 #ifdef GBX_CHAIN_STAMPS
                         { unsigned b_ = hit; asm volatile("" :: "v"(b_)); }
     #endif
@@ -422,9 +525,9 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         // the parent's block is live, straight to the output (already flushed there) when it is older
                         {
                             const bool wr = !skip && pj >= 0 && lane < bl;
-                            rst[wr && pj >= live0 ? slot_of(pj) : RING_PHYS + lane].z = i;      // non-writers: their dump entry
+                            rst[wr && pj >= live0 ? slot_of(pj) : RING_PHYS + lane].z = iabs;   // non-writers: their dump entry
                             if (__ballot(wr && pj < live0))                                     // rare: the parent left the ring
-                                if (wr && pj < live0) t[pj] = i;
+                                if (wr && pj < live0) t[pj] = iabs;
                         }
                         n_skip = __builtin_amdgcn_readlane(nl, 63);
                         STAMP(6);
@@ -456,6 +559,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                                 xj = ((uint64_t)wxy.y << 32) | wxy.x; yj = ((uint64_t)wxy.w << 32) | wxy.z; fj = wst.x; pj = wst.y; tj = wst.z; kj = wst.w;
                             } else {
                                 xj = settle(x[jj]); yj = settle(y[jj]); fj = settle(f[jj]); pj = settle(p[jj]); tj = settle(t[jj]); kj = settle(pk[jj]);
+                                pj = pj >= 0 ? pj - cbase : pj;   // the output holds call-relative parents
                             }
                             if (chunk(jhi, valid, xj, yj, fj, pj, tj, kj)) break;
                         }
@@ -471,7 +575,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                     if (lane == 0) rst[si] = make_int4(max_f, max_j, 0, pki);
                     STAMP(8);
                 }
-                if (lane < kmax) { f[ib + lane] = of_; p[ib + lane] = op_; pk[ib + lane] = ok_; }
+                if (lane < kmax) { f[ib + lane] = of_; p[ib + lane] = op_ >= 0 ? op_ + cbase : op_; pk[ib + lane] = ok_; }
             }
             // targets still in the ring: the anchors of the last five blocks
             if (n > 0) {
@@ -491,6 +595,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     #endif
         };
         if (flags == 0) run_call(std::true_type{}); else run_call(std::false_type{});
+        (void)n_calls;
         if (lane == 0) atomicAdd(W.evaluated, visited);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
@@ -498,11 +603,37 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
 
 }  // namespace
 
-size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors)
+// Workspace, in 8-byte words first: [header 3*NBUCKET ints | blk_diff[n_blk] u64 | job_start[max_jobs] i64 |
+// order[max_jobs] | job_n | job_call | job_flag | spare target / peak planes 2 x n_anchors | st[n_anchors] |
+// unsorted[n_calls] | blk_cut[n_blk] bytes]
+struct ChainLayout {
+    int64_t n_blk, max_jobs;
+    size_t o_diff, o_jstart, o_order, o_jn, o_jcall, o_jflag, o_spare, o_st, o_unsorted, o_cut, total;
+};
+static ChainLayout chain_layout(int64_t n_calls, int64_t n_anchors)
 {
-    // counters (3*NBUCKET ints) + order[n_calls] + optional target/peak planes + st[n_anchors] + unsorted[n_calls]
-    return (size_t)(3 * NBUCKET + 2 * (n_calls > 0 ? n_calls : 0) + 3 * (n_anchors > 0 ? n_anchors : 0) + 24) * sizeof(int32_t);
+    ChainLayout L;
+    if (n_calls < 0) n_calls = 0;
+    if (n_anchors < 0) n_anchors = 0;
+    L.n_blk = n_anchors / 64 + n_calls + 2;                  // block index ((off + 64 w) >> 6) + call
+    L.max_jobs = L.n_blk + n_calls;                          // a job per call + a cut per block at most
+    size_t at = 3 * NBUCKET * sizeof(int32_t);               // 384 bytes: the 64-bit arrays that follow stay 8-byte aligned
+    auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 7) & ~(size_t)7; return o; };
+    L.o_diff = take((size_t)L.n_blk * 8);
+    L.o_jstart = take((size_t)L.max_jobs * 8);
+    L.o_order = take((size_t)L.max_jobs * 4);
+    L.o_jn = take((size_t)L.max_jobs * 4);
+    L.o_jcall = take((size_t)L.max_jobs * 4);
+    L.o_jflag = take((size_t)L.max_jobs * 4);
+    L.o_spare = take((size_t)n_anchors * 8);
+    L.o_st = take((size_t)n_anchors * 4);
+    L.o_unsorted = take((size_t)n_calls * 4);
+    L.o_cut = take((size_t)L.n_blk);
+    L.total = at + 64;
+    return L;
 }
+
+size_t chain_workspace_bytes(int64_t n_calls, int64_t n_anchors) { return chain_layout(n_calls, n_anchors).total; }
 
 #ifdef GBX_CHAIN_STAMPS
 extern "C" int gbx_debug_chain_stamps(unsigned long long *out16)
@@ -521,6 +652,25 @@ int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s)
     return GBX_OK;
 }
 
+int chain_read_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors, int64_t *jobs, int64_t *longest, hipStream_t s)
+{
+    const ChainLayout L = chain_layout(n_calls, n_anchors);
+    int32_t nj = 0;
+    GBX_HIP(hipMemcpyAsync(&nj, (const char *)d_work + (2 * NBUCKET + 5) * sizeof(int32_t), sizeof(nj), hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    *jobs = nj; *longest = 0;
+    if (nj > 0) {
+        int32_t first = 0, n = 0;                              // order[0] is a job of the fullest size bucket: the longest within 2x;
+        std::vector<int32_t> jn((size_t)nj);                   // the exact maximum is read from the lengths (a diagnostic, not a hot path)
+        GBX_HIP(hipMemcpyAsync(jn.data(), (const char *)d_work + L.o_jn, sizeof(int32_t) * (size_t)nj, hipMemcpyDeviceToHost, s));
+        GBX_HIP(hipStreamSynchronize(s));
+        for (int32_t v : jn) n = v > n ? v : n;
+        (void)first;
+        *longest = n;
+    }
+    return GBX_OK;
+}
+
 int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
                  int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
@@ -529,47 +679,70 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     if (n_calls == 0) return GBX_OK;
     if (n_calls > 0x7fffffffLL - 1024) { set_error("chain: more than 2^31 calls"); return GBX_ERR_UNSUPPORTED; }
     if (work_bytes < chain_workspace_bytes(n_calls, n_anchors)) { set_error("chain: workspace too small"); return GBX_ERR_ARG; }
+    if (n_anchors > 0x7fffffffLL * 32) { set_error("chain: too many anchors"); return GBX_ERR_UNSUPPORTED; }
+    const ChainLayout L = chain_layout(n_calls, n_anchors);
+    char *wb = (char *)d_work;
     int32_t *wi = (int32_t *)d_work;
-    // [counts | cursors | next, evaluated(u64 at +2) | order[n_calls] | spare planes]
-    int32_t *spare = wi + 3 * NBUCKET + n_calls + 8;
-    ChainWork W = {wi, wi + NBUCKET, wi + 2 * NBUCKET, wi + 3 * NBUCKET, (unsigned long long *)(wi + 2 * NBUCKET + 2),
-                   spare + 2 * n_anchors, spare + 3 * n_anchors + 8};
+    // header: [counts | cursors | next: job cursor, evaluated (u64 at +2), ring choice (+4), number of jobs (+5)]
+    int32_t *spare = (int32_t *)(wb + L.o_spare);
+    ChainWork W;
+    W.counts = wi; W.cursors = wi + NBUCKET; W.next = wi + 2 * NBUCKET; W.order = (int32_t *)(wb + L.o_order);
+    W.evaluated = (unsigned long long *)(wi + 2 * NBUCKET + 2);
+    W.st = (int32_t *)(wb + L.o_st); W.unsorted = (int32_t *)(wb + L.o_unsorted);
+    W.blk_cut = (int8_t *)(wb + L.o_cut); W.blk_diff = (unsigned long long *)(wb + L.o_diff);
+    W.job_start = (int64_t *)(wb + L.o_jstart); W.job_n = (int32_t *)(wb + L.o_jn); W.job_call = (int32_t *)(wb + L.o_jcall);
+    W.job_flag = (int32_t *)(wb + L.o_jflag); W.max_jobs = (int32_t)L.max_jobs;
     if (!d_target) d_target = spare;
     if (!d_peak) d_peak = spare + n_anchors;
     GBX_HIP(hipMemsetAsync(d_work, 0, 3 * NBUCKET * sizeof(int32_t), s));
-    // GBX_CHAIN_WIDE=1 (test aid): every call takes the general 64-bit / multi-segment path (flag bit 1 preset)
+    GBX_HIP(hipMemsetAsync(W.job_flag, 0, (size_t)L.max_jobs * sizeof(int32_t), s));
+    // GBX_CHAIN_WIDE=1 (test aid): every job takes the general 64-bit / multi-segment path (flag bit 1 preset);
+    // GBX_CHAIN_NOSPLIT=1 (test aid): a call is one job, as before the cuts existed
     const char *wide_env = getenv("GBX_CHAIN_WIDE");
+    const char *nosplit_env = getenv("GBX_CHAIN_NOSPLIT");
     GBX_HIP(hipMemsetAsync(W.unsorted, wide_env && atoi(wide_env) ? 2 : 0, (size_t)n_calls * sizeof(int32_t), s));
-    const int ob = (int)((n_calls + 255) / 256);
-    {
-        Stage st("chain_order", s);
-        hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, n_calls, d_off, W, 0);
-        hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, n_calls, d_off, W, 1);
-    }
     {
         // up to 8 slices of a call side by side: long calls are not left to one block (the longest has 60 000 anchors)
         Stage st("chain_st", s);
-        hipLaunchKernelGGL(chain_st_kernel, dim3((unsigned)n_calls, 8), dim3(256), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr, W.st, W.unsorted);
+        hipLaunchKernelGGL(chain_st_kernel, dim3((unsigned)n_calls, 8), dim3(256), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr, W.st, W.unsorted,
+                           W.blk_cut, W.blk_diff);
+    }
+    {
+        Stage st("chain_order", s);
+        hipLaunchKernelGGL(chain_jobs_kernel, dim3((unsigned)n_calls), dim3(256), 0, s, (int)n_calls, d_off, W,
+                           nosplit_env && atoi(nosplit_env) ? 0 : 1);
+        const int ob = (int)((L.max_jobs + 255) / 256);
+        hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, W, 0);
+        hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, W, 1);
     }
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    // One call per block, in the longest-first order of the list: the hardware dispatcher hands the next call to
-    // whichever slot frees up, i.e. a dynamic LPT schedule (a persistent grid with a static stride over the list
-    // was 102 ms on the 'large' job, this is 97 ms; calls in flight per CU: 4: 149 ms, 8: 117, 16: 103, 19 =
-    // what the 8.4 KB LDS ring admits).  GBX_CHAIN_WAVES_PER_CU caps the grid at that many blocks per CU instead.
+    // A persistent grid of as many blocks as the chip holds (per instance: its LDS ring decides), each drawing the next
+    // job of the longest-first list from a cursor - a dynamic LPT schedule, as one block per call was, for a job count
+    // only the device knows (a static stride over the list was 102 ms on the 'large' job against 97; calls in flight per
+    // CU: 4: 149 ms, 8: 117, 16: 103).  GBX_CHAIN_WAVES_PER_CU caps the grid at that many blocks per CU instead.
+    static int occ_short[CHAIN_MAX_DEVICES], occ_long[CHAIN_MAX_DEVICES];
+    if (dev_id >= 0 && dev_id < CHAIN_MAX_DEVICES && occ_short[dev_id] == 0) {
+        int a_ = 0, b_ = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a_, chain_kernel<GBX_CHAIN_RING_LIVE>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b_, chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, 64, 0);
+        occ_short[dev_id] = a_ > 0 ? a_ : 8; occ_long[dev_id] = b_ > 0 ? b_ : 6;
+    }
     const char *wenv = getenv("GBX_CHAIN_WAVES_PER_CU");
-    const int64_t cap = wenv && atoi(wenv) > 0 ? (int64_t)cus * atoi(wenv) : (int64_t)1 << 20;
-    const int blocks = (int)(n_calls < cap ? n_calls : cap);
+    const int wcap = wenv && atoi(wenv) > 0 ? atoi(wenv) : 1 << 20;
+    const int di = dev_id >= 0 && dev_id < CHAIN_MAX_DEVICES ? dev_id : 0;
+    const int64_t blocks_s = std::min<int64_t>(L.max_jobs, (int64_t)cus * std::min(wcap, occ_short[di]));
+    const int64_t blocks_l = std::min<int64_t>(L.max_jobs, (int64_t)cus * std::min(wcap, occ_long[di]));
     {
         Stage st("chain_dp", s);
         // both instances are queued; the one the job did not pick returns at once (no host round trip for the choice)
         const char *renv = getenv("GBX_CHAIN_RING");         // test / tuning aid: "short" or "long" for every job
         const int force = renv ? (renv[0] == 'l' ? 1 : renv[0] == 's' ? 0 : -1) : -1;
         hipLaunchKernelGGL(chain_pick_kernel, dim3(1), dim3(64), 0, s, W, (long long)n_anchors, cus, force);
-        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3(blocks), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
+        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3((unsigned)blocks_s), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
                            d_score, d_parent, d_target, d_peak, W);
-        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3(blocks), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
+        hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3((unsigned)blocks_l), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
                            d_score, d_parent, d_target, d_peak, W);
     }
     GBX_HIP(hipGetLastError());

@@ -832,6 +832,12 @@ int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream)
     return chain_read_evaluated(d_work, pairs, (hipStream_t)stream);
 }
 
+int gbx_chain_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors, int64_t *jobs, int64_t *longest_job, void *stream)
+{
+    if (!d_work || !jobs || !longest_job) { set_error("gbx_chain_job_stats: null pointer"); return GBX_ERR_ARG; }
+    return chain_read_job_stats(d_work, n_calls, n_anchors, jobs, longest_job, (hipStream_t)stream);
+}
+
 int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows,
                              const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
                              const char *d_arena, char *d_cons, int32_t *d_cons_len, int32_t *d_status,

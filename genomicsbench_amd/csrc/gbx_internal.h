@@ -77,6 +77,7 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  void *d_work, size_t work_bytes, hipStream_t s);
 
 int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s);
+int chain_read_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors, int64_t *jobs, int64_t *longest, hipStream_t s);
 int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s);
 
 // ---- phmm (phmm_kernels.hip)

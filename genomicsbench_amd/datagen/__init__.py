@@ -30,6 +30,7 @@ def _L():
         _lib.gbx_gen_poa_window.restype = None
         _lib.gbx_gen_chain_counts_many.argtypes = [u64, i64, i64, vp]
         _lib.gbx_gen_chain_fill_many.argtypes = [u64, i64, i64, vp, vp, vp]
+        _lib.gbx_gen_chain_fill_real_many.argtypes = [u64, i64, i64, vp, vp, vp]
         _lib.gbx_gen_phmm_counts_many.argtypes = [u64, i64, i64, vp, vp]
         _lib.gbx_gen_phmm_lengths_many.argtypes = [u64, i64, i64, vp, vp, vp, vp]
         _lib.gbx_gen_phmm_fill_many.argtypes = [u64, i64, i64] + [vp] * 10
@@ -40,7 +41,7 @@ def _L():
         _lib.gbx_gen_abea_fill_many.argtypes = [u64, i64, i64] + [vp] * 8
         for f in ("abea_model", "abea_counts_many", "abea_fill_many"):
             getattr(_lib, "gbx_gen_" + f).restype = None
-        for f in ("chain_counts_many", "chain_fill_many", "phmm_counts_many", "phmm_lengths_many", "phmm_fill_many",
+        for f in ("chain_counts_many", "chain_fill_many", "chain_fill_real_many", "phmm_counts_many", "phmm_lengths_many", "phmm_fill_many",
                   "poa_counts_many", "poa_many"):
             getattr(_lib, "gbx_gen_" + f).restype = None
     return _lib
@@ -68,8 +69,10 @@ def gen_bsw(n_pairs, seed, first=0):
     return BswBatch(ref, qer, idr, idq, len1, len2, h0)
 
 
-def gen_chain(n_calls, seed, first=0, n_override=None):
-    """chain 'large' = (10_000, seed 2001).  Returns (anchor_off, ax, ay, hdr)."""
+def gen_chain(n_calls, seed, first=0, n_override=None, realistic=False):
+    """chain 'large' = (10_000, seed 2001).  Returns (anchor_off, ax, ay, hdr).  realistic=True: the same call sizes with
+    minimap2's structure inside a call (both strands, six reference ids in the upper x word, repeat copies, isolated
+    hits: datagen.c gbx_gen_chain_fill_real)."""
     from .._native import CHAIN_CALL_DTYPE
     L = _L()
     if n_override is None:
@@ -81,7 +84,7 @@ def gen_chain(n_calls, seed, first=0, n_override=None):
     np.cumsum(counts, out=off[1:])
     ax = np.zeros(int(off[-1]), dtype=np.uint64)
     ay = np.zeros(int(off[-1]), dtype=np.uint64)
-    L.gbx_gen_chain_fill_many(seed, first, n_calls, _p(off), _p(ax), _p(ay))
+    (L.gbx_gen_chain_fill_real_many if realistic else L.gbx_gen_chain_fill_many)(seed, first, n_calls, _p(off), _p(ax), _p(ay))
     hdr = np.zeros(n_calls, dtype=CHAIN_CALL_DTYPE)
     hdr["avg_qspan"] = 15.0
     hdr["max_dist_x"] = 5000

@@ -147,6 +147,65 @@ void gbx_gen_chain_fill(uint64_t seed, int64_t call, int64_t n, uint64_t *ax, ui
     free(tmp);
 }
 
+/* chain, "realistic" structure (beside the SURVEY 8d workload above, which keeps one strand and one reference id
+ * and therefore has one dense run of anchors per call): what minimap2 hands mm_chain_dp for a long read against a
+ * genome - x = strand << 63 | rid << 32 | rpos (host_data.h; compared as one 64-bit word, host_kernel.cpp:56,59) with
+ * six reference sequences of 14-21 Mbp on both strands; 55 % of a call's anchors lie on the read's true locus (1-2
+ * colinear diagonals with the jitter of the plain generator), 25 % on 2-6 partial repeat copies elsewhere (shorter
+ * colinear runs on random strands / references), 20 % are isolated minimizer hits spread over the whole genome.
+ * Sorted by x the call falls apart into pieces further than max_dist_x from each other. */
+void gbx_gen_chain_fill_real(uint64_t seed, int64_t call, int64_t n, uint64_t *ax, uint64_t *ay)
+{
+    static const int64_t REF_LEN[6] = {15072434, 15279421, 13783801, 17493829, 20924180, 17718942};   /* C. elegans I-V, X */
+    rng_t r;
+    rng_seed(&r, seed, (uint64_t)call * 2 + 1);
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)n);
+    const int64_t n_noise = n / 5, n_rep = n / 4, n_true = n - n_noise - n_rep;
+    const int64_t qspan_total = n_true * 30 + 1000;      /* the read's extent in query coordinates */
+    int64_t o = 0;
+    /* a colinear run of cnt anchors starting at (strand, rid, x0, y0) */
+#define RUN(cnt_, key_, x0_, y0_) do { int64_t x_ = (x0_), y_ = (y0_); \
+        for (int64_t k_ = 0; k_ < (cnt_); ++k_) { \
+            int64_t dx_ = (int64_t)rng_below(&r, 61), dy_ = dx_ + (int64_t)llround(8.0 * rng_norm(&r)); \
+            if (dy_ < 0) dy_ = 0; \
+            x_ += dx_; y_ += dy_; \
+            tmp[2 * o] = (key_) | (uint64_t)(x_ & 0x7fffffff); \
+            tmp[2 * o + 1] = ((uint64_t)15 << 32) | (uint64_t)(uint32_t)(y_ & 0x7fffffff); \
+            ++o; } } while (0)
+    {
+        const int rid = (int)rng_below(&r, 6), strand = (int)rng_below(&r, 2);
+        const uint64_t key = ((uint64_t)strand << 63) | ((uint64_t)rid << 32);
+        const int64_t room = REF_LEN[rid] - qspan_total - 20000;
+        const int64_t pos = 1000 + (int64_t)(rng_unif(&r) * (double)(room > 1 ? room : 1));
+        const int ndiag = 1 + (int)rng_below(&r, 2);
+        for (int d = 0; d < ndiag; ++d) {
+            const int64_t cnt = n_true / ndiag + (d < n_true % ndiag ? 1 : 0);
+            RUN(cnt, key, pos + (int64_t)rng_below(&r, 2000) + (int64_t)d * 7919, 100 + (int64_t)rng_below(&r, 500));
+        }
+    }
+    {
+        const int ncopy = 2 + (int)rng_below(&r, 5);
+        for (int c = 0; c < ncopy; ++c) {
+            const int64_t cnt = n_rep / ncopy + (c < n_rep % ncopy ? 1 : 0);
+            const int rid = (int)rng_below(&r, 6), strand = (int)rng_below(&r, 2);
+            const uint64_t key = ((uint64_t)strand << 63) | ((uint64_t)rid << 32);
+            const int64_t room = REF_LEN[rid] - cnt * 30 - 20000;
+            const int64_t pos = 1000 + (int64_t)(rng_unif(&r) * (double)(room > 1 ? room : 1));
+            RUN(cnt, key, pos, 100 + (int64_t)(rng_unif(&r) * (double)qspan_total));
+        }
+    }
+    for (int64_t k = 0; k < n_noise; ++k) {
+        const int rid = (int)rng_below(&r, 6), strand = (int)rng_below(&r, 2);
+        tmp[2 * o] = ((uint64_t)strand << 63) | ((uint64_t)rid << 32) | (uint64_t)(1000 + (int64_t)(rng_unif(&r) * (double)(REF_LEN[rid] - 2000)));
+        tmp[2 * o + 1] = ((uint64_t)15 << 32) | (uint64_t)(uint32_t)(100 + (int64_t)(rng_unif(&r) * (double)qspan_total));
+        ++o;
+    }
+#undef RUN
+    qsort(tmp, (size_t)n, 2 * sizeof(uint64_t), cmp_anchor);
+    for (int64_t k = 0; k < n; ++k) { ax[k] = tmp[2 * k]; ay[k] = tmp[2 * k + 1]; }
+    free(tmp);
+}
+
 /* ------------------------------------------------------------------ phmm
  * batch b: num_reads ~ U[1,120], num_haps ~ U[2,16]; a backbone of U[150,450]
  * bases; every haplotype = backbone with 1 % SNPs and 0.5 % single-base indels;
@@ -246,6 +305,13 @@ void gbx_gen_chain_fill_many(uint64_t seed, int64_t first, int64_t n_calls, cons
 #pragma omp parallel for schedule(dynamic, 8)
     for (int64_t c = 0; c < n_calls; ++c)
         gbx_gen_chain_fill(seed, first + c, off[c + 1] - off[c], ax + off[c], ay + off[c]);
+}
+
+void gbx_gen_chain_fill_real_many(uint64_t seed, int64_t first, int64_t n_calls, const int64_t *off, uint64_t *ax, uint64_t *ay)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t c = 0; c < n_calls; ++c)
+        gbx_gen_chain_fill_real(seed, first + c, off[c + 1] - off[c], ax + off[c], ay + off[c]);
 }
 
 void gbx_gen_phmm_counts_many(uint64_t seed, int64_t first, int64_t n_batches, int32_t *n_reads, int32_t *n_haps)

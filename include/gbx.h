@@ -181,6 +181,12 @@ int gbx_chain_device(int64_t n_calls, int64_t n_anchors, const int64_t *d_anchor
  * `continue`d ones included, those after the max_skip break excluded (the benchmark's "cell"). */
 int gbx_chain_evaluated_pairs(const void *d_work, int64_t *pairs, void *stream);
 
+/* How the last gbx_chain_device call on this workspace was scheduled: a call whose anchors are sorted by x falls apart
+ * at every anchor that lies further than max_dist_x behind its predecessor (it looks back at nobody and nothing later
+ * looks across it, host_kernel.cpp:56) into pieces that are chained independently (`jobs` >= calls; at most one cut per
+ * 64 anchors); `longest_job` = anchors of the longest piece, what bounds the kernel's makespan. */
+int gbx_chain_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors, int64_t *jobs, int64_t *longest_job, void *stream);
+
 /* -------------------------------------------------------------------- phmm
  * GATK/GKL Pair-HMM forward log10-likelihoods.
  * Replaces  void initPairHMM()                                     R/benchmarks/phmm/PairHMMUnitTest.cpp:84,193

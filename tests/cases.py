@@ -131,4 +131,54 @@ def chain_cases(seed=99):
     cases["multiseg"] = chain_pack([_chain_call(rng, 800, n_segs=2, dup_x=True),
                                     _chain_call(rng, 1500, n_segs=3, dup_x=True, avg_qspan=17.5),
                                     _chain_call(rng, 400, n_segs=1, dup_x=True)])
+    cases.update(chain_cut_cases(seed + 1000))
     return cases
+
+
+def _chain_clusters(rng, sizes, gap, keys=None, n_segs=1, max_dist=5000, bw=500, avg_qspan=15.0):
+    """One call made of clusters of the given sizes: colinear runs `gap` reference bases apart (> max_dist: the chain
+    kernel cuts the call there), optionally under different upper x words (strand / reference id) and segment ids."""
+    xs, ys = [], []
+    x = 1000
+    for c, n in enumerate(sizes):
+        key = int(keys[c % len(keys)]) if keys is not None else 0
+        y = int(rng.integers(100, 4000))
+        for _ in range(n):
+            dx = int(rng.integers(0, 61))
+            x += dx
+            y += max(dx + int(round(rng.normal(0, 8))), 0)
+            seg = int(rng.integers(0, n_segs))
+            xs.append((key << 32) | x)
+            ys.append((seg << 48) | (int(rng.integers(10, 20)) << 32) | (y & 0x7fffffff))
+        x += gap + int(rng.integers(0, 50))
+    ax, ay = np.array(xs, dtype=np.uint64), np.array(ys, dtype=np.uint64)
+    order = np.lexsort((ay, ax))
+    return ax[order], ay[order], (np.float32(avg_qspan), max_dist, max_dist if n_segs == 1 else 800, bw, n_segs)
+
+
+def chain_cut_cases(seed=1099):
+    """Calls that fall apart into independent pieces (an anchor further than max_dist_x from its predecessor looks back
+    at nobody, host_kernel.cpp:56, and nothing after it looks across it): pieces of 1 anchor, pieces ending and starting
+    on the 64-anchor block boundaries the kernel records its cuts by, several cuts inside one block, pieces under
+    different strands / reference ids and with several segment ids, a gap of exactly max_dist_x (no cut) and one more
+    (a cut), pieces long enough to leave the LDS ring, and the realistic generator of the bench."""
+    from genomicsbench_amd.datagen import gen_chain
+    rng = np.random.default_rng(seed)
+    calls = [
+        _chain_clusters(rng, [1, 1, 1, 5, 56, 64, 64, 1, 63, 65, 1, 200, 3, 700], 6000),
+        _chain_clusters(rng, [30, 1, 1, 1, 1, 30, 2, 2, 2, 700, 1], 5001),
+        _chain_clusters(rng, [64] * 6 + [128, 1, 127, 1], 9000),
+        _chain_clusters(rng, [40, 300, 17, 1, 90, 1200, 2, 64], 7000, keys=[0, 0, 1, 1, 5, (1 << 31) | 2, (1 << 31) | 2, (1 << 31) | 4]),
+        _chain_clusters(rng, [100, 50, 1, 400, 64, 20], 7000, keys=[3, 3, 4], n_segs=2),
+        _chain_clusters(rng, [1500, 900, 1, 2000], 5200),
+    ]
+    # a gap of exactly max_dist_x is still looked across; one base more is not
+    x = np.uint64(1000) + np.arange(300, dtype=np.uint64) * np.uint64(10)
+    x[100:] += np.uint64(5000 - 10)
+    x[200:] += np.uint64(5001 - 10)
+    y = (np.uint64(15) << np.uint64(32)) | (np.uint64(100) + np.arange(300, dtype=np.uint64) * np.uint64(10))
+    calls.append((x, y, (np.float32(15.0), 5000, 5000, 500, 1)))
+    off, ax, ay, hdr = gen_chain(12, 7001, realistic=True,
+                                 n_override=[50, 64, 65, 129, 400, 1000, 2000, 3000, 3000, 5000, 7000, 9000])
+    real = [(ax[off[c]:off[c + 1]], ay[off[c]:off[c + 1]], tuple(hdr[c])) for c in range(12)]
+    return {"cuts": chain_pack(calls), "realistic": chain_pack(real)}

@@ -54,8 +54,11 @@ def chain_fixture(name, off, ax, ay, hdr):
 
 if __name__ == "__main__":
     assert O.ref_lib("bsw") is not None and O.ref_lib("chain") is not None, "run oracle/build_ref.sh first"
-    bsw_fixture("realistic", gen_bsw(3000, 1001))
-    bsw_fixture("adversarial", adversarial_bsw(3000, 4242))
-    bsw_fixture("edge", edge_bsw())
+    only = sys.argv[1:]                       # e.g. `make_golden.py chain_cuts chain_realistic`: just these fixtures
+    for name, make in (("realistic", lambda: gen_bsw(3000, 1001)), ("adversarial", lambda: adversarial_bsw(3000, 4242)),
+                       ("edge", edge_bsw)):
+        if not only or "bsw_" + name in only:
+            bsw_fixture(name, make())
     for name, case in chain_cases().items():
-        chain_fixture(name, *case)
+        if not only or "chain_" + name in only:
+            chain_fixture(name, *case)

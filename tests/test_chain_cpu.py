@@ -9,7 +9,7 @@ from oracle import oracle_py as O
 from util import load_chain_golden
 
 
-@pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg"])
+@pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg", "cuts", "realistic"])
 def test_oracle_matches_reference_goldens(name):
     case, g = load_chain_golden(name)
     s, p, t, k = O.chain_oracle(*case)
@@ -19,7 +19,7 @@ def test_oracle_matches_reference_goldens(name):
 
 @pytest.mark.skipif(O.ref_lib("chain") is None, reason="compiled reference only exists in the build container")
 def test_oracle_matches_live_reference():
-    for case in list(chain_cases(seed=5).values()) + [gen_chain(40, 2001)]:
+    for case in list(chain_cases(seed=5).values()) + [gen_chain(40, 2001), gen_chain(40, 2001, realistic=True)]:
         for a, b in zip(O.chain_oracle(*case), O.chain_ref(*case)):
             assert np.array_equal(a, b)
 

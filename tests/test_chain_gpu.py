@@ -21,7 +21,7 @@ def assert_same(got, want):
 
 
 @pytest.mark.parametrize("ring", ["auto", "short", "long"])
-@pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg"])
+@pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg", "cuts", "realistic"])
 def test_goldens(name, ring, monkeypatch):
     """Both instances of the DP kernel (512- and 768-anchor ring; a job picks one on the device) against the goldens."""
     if ring != "auto":
@@ -41,6 +41,29 @@ def test_many_short_calls_take_the_short_ring_and_long_jobs_the_long_one(monkeyp
         else:
             monkeypatch.delenv("GBX_CHAIN_RING", raising=False)
         assert_same(chain_host(*case), want)
+
+
+@pytest.mark.parametrize("mode", ["GBX_CHAIN_NOSPLIT", "GBX_CHAIN_WIDE"])
+@pytest.mark.parametrize("name", ["cuts", "realistic", "multiseg"])
+def test_goldens_without_cuts_and_on_the_general_path(name, mode, monkeypatch):
+    """The same goldens with every call as one job (the cuts are an optimisation, not a semantic), and with every job on
+    the general 64-bit / multi-segment path (a piece under one strand / reference id normally takes the narrow one)."""
+    monkeypatch.setenv(mode, "1")
+    case, g = load_chain_golden(name)
+    assert_same(chain_host(*case), [g[:, 0], g[:, 1], g[:, 2], g[:, 3]])
+
+
+def test_realistic_calls_are_cut_into_jobs_and_equal_the_oracle():
+    """400 calls of the realistic generator (20 % isolated hits, repeat copies on other strands / references): identical
+    to the oracle, and the evaluated-pair count (the benchmark's work unit) equals the oracle's too."""
+    import torch
+    case = gen_chain(400, 4242, realistic=True)
+    want = O.chain_oracle(*case, nthreads=8, return_pairs=True)
+    d = DeviceChainBatch(*case, torch.device("cuda:0"))
+    d.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_same(d.results(), want[:4])
+    assert d.evaluated_pairs() == int(want[4])
 
 
 @pytest.mark.parametrize("seed", [1, 2])

@@ -35,12 +35,15 @@ def test_bsw_large_all_fields():
     print("bsw large: field sums", got.astype(np.int64).sum(axis=0).tolist())
 
 
-def test_chain_large_all_calls():
+@pytest.mark.parametrize("realistic", [False, True])
+def test_chain_large_all_calls(realistic):
+    """All 10 000 calls / 41 M anchors of chain 'large', and of the same call sizes with minimap2's structure inside a
+    call (both strands, six reference ids: the calls are cut into independent jobs on the device)."""
     import torch
     from genomicsbench_amd.chain import DeviceChainBatch
     from genomicsbench_amd.datagen import gen_chain
     from oracle import oracle_py as O
-    case = gen_chain(10_000, 2001)
+    case = gen_chain(10_000, 2001, realistic=realistic)
     d = DeviceChainBatch(*case, torch.device("cuda:0"))
     d.run(_stream())
     torch.cuda.synchronize()
