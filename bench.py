@@ -635,10 +635,139 @@ class AbeaWork:
                 "verified": "device pairs and QC verdicts of these %d reads %s the CPU run's" % (sub.n_reads, "identical to" if same else "DIFFER from")}
 
 
-WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork, "abea": AbeaWork}
+class FmiWork:
+    """SURVEY 8f rank 4, second half: bwa-mem2 SMEM seeding on the FM-index (R/benchmarks/fmi/fmi.cpp:180-286).  The genome
+    and its index are the same on every rank (built there on the GPU: the job of `bwa-mem2 index`, outside the timed
+    region as in the reference, fmi.cpp:79-80); the reads are what is sharded."""
+    metric, unit, dtype = "fmi_large_gext_per_s", "G backwardExt/s", "int64"
+    large, seed = 10_000_000, 6001                      # the reference's large input is 10 M reads of 151 bases (R/scripts/run-cpu.sh:27)
+    genome = 256 << 20                                  # 256 Mbp: the index covers both strands, 512 MB of checkpoints
+
+    def __init__(self, args):
+        self.n = args.size or self.large
+        self.glen = int(os.environ.get("GBX_FMI_GENOME", self.genome))
+        self.workload = ("fmi large: %d synthetic 151-bp reads per GPU (seed 6001) against the FM-index of a synthetic %d-Mbp genome "
+                         "and its reverse complement (%d MB of checkpoints; 4 %% repeat families), minSeedLen 19, index and reads "
+                         "resident in HBM, unit = backwardExt call (two checkpoint look-ups)" % (self.n, self.glen >> 20, (2 * self.glen + 1) >> 20))
+        self._g = None
+
+    def genome_codes(self):
+        if self._g is None:
+            from genomicsbench_amd.datagen import gen_fmi_genome
+            self._g = gen_fmi_genome(self.glen, self.seed)
+        return self._g
+
+    def generate(self, first, n_units):
+        from genomicsbench_amd.datagen import gen_fmi_reads
+        return gen_fmi_reads(self.genome_codes(), n_units, self.seed + 1, first=first)
+
+    def shards(self, full, parts):
+        return S.fmi_shards(full, parts)
+
+    to_arrays = staticmethod(lambda sh: S.fmi_to_arrays(sh))
+    n_units = staticmethod(lambda sh: sh.n_reads)
+
+    def attach(self, tensors, dev, host_shard):
+        import torch
+        from genomicsbench_amd.fmi import DeviceFmi, build_index
+        t0 = time.perf_counter()
+        self.index = build_index(self.genome_codes(), device=dev)
+        torch.cuda.synchronize()
+        self.index_build_s = time.perf_counter() - t0
+        self.d = DeviceFmi.from_tensors(self.index, (tensors["enc"], tensors["read_off"], tensors["read_len"]), dev)
+        self.rs = host_shard
+        self.units = None                                   # backwardExt calls: device counter
+        self.extra = {"reads_this_gpu": self.d.n_reads, "index_mb": round(self.d.dindex.numel() / 1e6, 1),
+                      "index_build_s_outside_timed_region": round(self.index_build_s, 2),
+                      "workspace_gb": round(self.d.work_bytes / 1e9, 2)}
+
+    def run(self, stream):
+        self.d.run(stream)
+
+    def finish(self, stream):
+        self.units = float(self.d.extensions(stream))
+        self.extra["extensions_this_gpu"] = int(self.units)
+        self.extra["smems_this_gpu"] = int(self.d.n_out.item())
+
+    def output_tensor(self):
+        """Variable-length result: [total | per-read offsets | records] as bytes."""
+        import torch
+        d = self.d
+        n = min(int(d.n_out.item()), d.out_cap)
+        return torch.cat([d.n_out.view(torch.uint8), d.smem_off.view(torch.uint8), d.out[:n * 40]])
+
+    def check_gathered(self, full, ranges, parts, sample):
+        from genomicsbench_amd.fmi import SMEM_DTYPE
+        from oracle import oracle_py as O
+        hidx = self.index.host()
+        bad = checked = 0
+        for (lo, hi), got in zip(ranges, parts):
+            m = min(hi - lo, sample)
+            if m:
+                g = got.cpu().numpy()
+                nrd = hi - lo
+                off = g[8:8 + 8 * (nrd + 1)].view(np.int64)
+                rec = g[8 + 8 * (nrd + 1):].view(SMEM_DTYPE)
+                sub = full.take(lo, lo + m)
+                wo, woff = O.fmi_oracle(hidx, sub, nthreads=min(os.cpu_count() or 1, 32))
+                ok = np.array_equal(off[:m + 1], woff) and all(np.array_equal(rec[f][:len(wo)], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+                bad += int(not ok)
+                checked += m
+        return "%d reads (front of every shard) vs oracle, every field of every SMEM: %s" % (checked, "identical" if not bad else "DIFFER")
+
+    def roofline_bytes(self, kernel):
+        # a backwardExt reads two checkpoints of 64 bytes (rows k and k + s; often the same line late in a match, counted
+        # twice here as the reference's GET_OCC pair does); a read's bases once; 40 bytes per SMEM written
+        d = self.d
+        if not kernel.startswith("fmi_smem"):
+            return 0, 0.0
+        return int((self.units or 0.0) * 128 + d.enc.numel() + int(d.n_out.item()) * 40), self.units
+
+    def host_entry(self):
+        """PCIe-inclusive rate through gbx_fmi_smem_host (pageable reads in, SMEM records out; the index is uploaded by
+        the first call and kept on the device, as a caller that seeds batch after batch against one index needs it)."""
+        from genomicsbench_amd import _native as N
+        from genomicsbench_amd.fmi import smem_host
+        N.check(N.lib().gbx_host_prepare())
+        hidx = self.index.host()
+        rs = self.rs.take(0, min(self.rs.n_reads, 1_000_000))
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            got, goff = smem_host(hidx, rs, self.d.params)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        dev, doff = self.d.results()
+        k = int(doff[rs.n_reads])
+        same = np.array_equal(goff, doff[:rs.n_reads + 1]) and all(np.array_equal(got[f], dev[f][:k]) for f in ("rid", "m", "n", "k", "l", "s"))
+        frac = rs.n_reads / max(self.rs.n_reads, 1)
+        return {"first_call_ms": ms[0], "best_ms": min(ms), "value": float(self.units or 0.0) * frac / (min(ms) * 1e-3) / 1e9, "unit": self.unit,
+                "what": "gbx_fmi_smem_host on the first %d reads of the rank-0 shard: H2D of the reads + kernels + D2H of the records "
+                        "from pageable memory; the first call also uploads the %d MB index" % (rs.n_reads, self.d.dindex.numel() >> 20),
+                "same_as_device_entry": bool(same)}
+
+    def cpu_baseline(self, max_units):
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        sub = self.rs.take(0, min(self.rs.n_reads, max_units or 1_000_000))
+        hidx = self.index.host()
+        t0 = time.perf_counter()
+        wo, woff, ext, rounds = O.fmi_oracle(hidx, sub, nthreads=cores, return_stats=True)
+        dt = time.perf_counter() - t0
+        dev, doff = self.d.results()
+        k = int(doff[sub.n_reads])
+        same = np.array_equal(woff, doff[:sub.n_reads + 1]) and all(np.array_equal(wo[f], dev[f][:k]) for f in ("rid", "m", "n", "k", "l", "s"))
+        return {"value": ext / dt / 1e9, "unit": self.unit, "cores": cores, "kind": "port", "reads_per_s": sub.n_reads / dt,
+                "sample": "first %d reads (%d backwardExt calls, %d / %d / %d SMEMs from the three rounds), oracle/fmi_oracle.c restating "
+                          "bwa-mem2's FMI_search, OpenMP dynamic, %.2f s (tools/bwa-mem2 is an empty submodule: no reference build)"
+                          % (sub.n_reads, ext, rounds[0], rounds[1], rounds[2], dt),
+                "verified": "device SMEMs of these %d reads %s the CPU run's (every field)" % (sub.n_reads, "identical to" if same else "DIFFER from")}
+
+
+WORKLOADS = {"bsw": BswWork, "chain": ChainWork, "phmm": PhmmWork, "poa": PoaWork, "abea": AbeaWork, "fmi": FmiWork}
 _PROFILE_FILES = {"traffic": ("profiles/hbm_traffic.json", "bytes_per_launch"), "valu_busy": ("profiles/valu_busy.json", "valu_busy"),
                   "valu_insts": ("profiles/valu_insts.json", "valu_insts")}
-_KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip"}
+_KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip",
+                "fmi": "fmi_kernels.hip"}
 
 
 def _hip_sha16(kind):
@@ -818,7 +947,7 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     if args.mode != "local":
         line["dataset_gen_s"] = gen_s
         line["gather_verified"] = work.check_gathered(full, ranges, parts, args.verify_units or
-                                                      {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8}[kind])
+                                                      {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8, "fmi": 20000}[kind])
         line["shard_units"] = [hi - lo for lo, hi in ranges]
     if not args.no_cpu and world == 1:                      # the CPU baseline is an N=1 figure (rank 0's host cores)
         # the host-buffer entry first, on quiet host cores (the CPU baseline runs OpenMP teams on all of them)

@@ -1180,4 +1180,162 @@ int gbx_abea_align_host(int64_t n_reads, const int64_t *seq_off, const int32_t *
     return rc;
 }
 
+// -------------------------------------------------------------------- fmi
+void gbx_fmi_default_params(gbx_fmi_params *p, int32_t min_seed_len)
+{
+    if (!p) return;
+    p->min_seed_len = min_seed_len;                                 // fmi.cpp:135
+    p->split_width = 10;                                            // :138
+    p->max_mem_intv = 20;                                           // :139
+    p->split_len = (int32_t)(min_seed_len * 1.5 + .499);            // :140,178
+}
+
+size_t gbx_fmi_index_bytes(int64_t ref_seq_len) { return fmi_index_bytes(ref_seq_len); }
+
+int gbx_fmi_index_build(const gbx_fmi_index *idx, void *d_index, size_t index_bytes, void *stream)
+{
+    if (!idx || !idx->cp_occ || !d_index) { set_error("gbx_fmi_index_build: null pointer"); return GBX_ERR_ARG; }
+    int rc = require_device();
+    if (rc) return rc;
+    return fmi_index_build(idx, d_index, index_bytes, (hipStream_t)stream);
+}
+
+size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len) { return fmi_workspace_bytes(n_reads, max_read_len); }
+
+static int fmi_check(const gbx_fmi_index *idx, const gbx_fmi_params *p, const char *who)
+{
+    if (!idx || !p) { set_error("%s: null pointer", who); return GBX_ERR_ARG; }
+    if (p->min_seed_len < 1 || p->split_width < 0 || p->max_mem_intv < 0) { set_error("%s: bad parameters", who); return GBX_ERR_ARG; }
+    if (idx->ref_seq_len < 2 || idx->count[0] != 1 || idx->count[4] != idx->ref_seq_len || idx->sentinel_index < 0 ||
+        idx->sentinel_index >= idx->ref_seq_len) {
+        set_error("%s: inconsistent index (count[0] must be 1, count[4] the reference length incl. the sentinel)", who);
+        return GBX_ERR_ARG;
+    }
+    for (int c = 0; c < 4; ++c)
+        if (idx->count[c] > idx->count[c + 1]) { set_error("%s: count[] not monotone", who); return GBX_ERR_ARG; }
+    return GBX_OK;
+}
+
+int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads,
+                        int32_t max_read_len, const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len,
+                        gbx_fmi_smem *d_out, int64_t out_cap, int64_t *d_smem_off, int64_t *d_n_out,
+                        void *d_work, size_t work_bytes, void *stream)
+{
+    int rc = fmi_check(idx, p, "gbx_fmi_smem_device");
+    if (rc) return rc;
+    if (n_reads < 0 || out_cap < 0) { set_error("gbx_fmi_smem_device: bad argument"); return GBX_ERR_ARG; }
+    if (!d_index || !d_smem_off || !d_n_out || !d_work || (n_reads > 0 && (!d_enc || !d_read_off || !d_read_len)) || (out_cap > 0 && !d_out)) {
+        set_error("gbx_fmi_smem_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    if ((rc = require_device())) return rc;
+    return fmi_launch(idx, d_index, p, n_reads, max_read_len, d_enc, d_read_off, d_read_len, d_out, out_cap, d_smem_off, d_n_out,
+                      d_work, work_bytes, (hipStream_t)stream);
+}
+
+int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream)
+{
+    if (!d_work || !ext) { set_error("gbx_fmi_extensions: null pointer"); return GBX_ERR_ARG; }
+    return fmi_read_extensions(d_work, ext, (hipStream_t)stream);
+}
+
+// The host entry keeps the device copy of an index between calls (a reference-side caller hands over the same
+// FMI_search tables for every batch of reads, fmi.cpp:218): keyed by the table's address and its scalars, one per device.
+namespace {
+struct FmiCached { int dev; const void *host_cp; int64_t len, sentinel, count1; void *d_index; size_t bytes; };
+std::mutex g_fmi_mu;
+std::vector<FmiCached> g_fmi_cache;
+}
+
+int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t n_reads, const uint8_t *enc, int64_t enc_bytes,
+                      const int64_t *read_off, const int32_t *read_len, gbx_fmi_smem *out, int64_t out_cap,
+                      int64_t *smem_off, int64_t *n_out)
+{
+    RoctxRange range_("gbx_fmi_smem_host");
+    int rc = fmi_check(idx, p, "gbx_fmi_smem_host");
+    if (rc) return rc;
+    if (n_reads < 0 || out_cap < 0 || enc_bytes < 0) { set_error("gbx_fmi_smem_host: bad argument"); return GBX_ERR_ARG; }
+    if (!idx->cp_occ || !n_out || (n_reads > 0 && (!enc || !read_off || !read_len)) || (out_cap > 0 && !out)) {
+        set_error("gbx_fmi_smem_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int32_t max_len = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        if (read_len[r] < 0 || read_off[r] < 0 || read_off[r] + read_len[r] > enc_bytes) {
+            set_error("gbx_fmi_smem_host: read %lld lies outside the base buffer", (long long)r);
+            return GBX_ERR_ARG;
+        }
+        if (read_len[r] > max_len) max_len = read_len[r];
+    }
+    if ((rc = require_device())) return rc;
+    int dev = 0;
+    GBX_HIP(hipGetDevice(&dev));
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    hipStream_t s = L->compute;
+    // the device index: cached, or uploaded in the reference's layout and re-laid on the device
+    void *d_index = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_fmi_mu);
+        for (const FmiCached &c : g_fmi_cache)
+            if (c.dev == dev && c.host_cp == idx->cp_occ && c.len == idx->ref_seq_len && c.sentinel == idx->sentinel_index && c.count1 == idx->count[1])
+                d_index = c.d_index;
+        if (!d_index) {
+            const size_t bytes = fmi_index_bytes(idx->ref_seq_len);
+            void *d_src = nullptr;
+            GBX_HIP(hipMalloc(&d_index, bytes));
+            hipError_t e = hipMalloc(&d_src, bytes);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_src, idx->cp_occ, bytes, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { (void)hipFree(d_index); if (d_src) (void)hipFree(d_src); return hip_fail(e, "fmi index upload"); }
+            gbx_fmi_index di = *idx;
+            di.cp_occ = (const gbx_fmi_cp_occ *)d_src;
+            rc = fmi_index_build(&di, d_index, bytes, s);
+            hipError_t e2 = hipStreamSynchronize(s);
+            (void)hipFree(d_src);
+            if (rc || e2 != hipSuccess) { (void)hipFree(d_index); return rc ? rc : hip_fail(e2, "fmi index build"); }
+            g_fmi_cache.push_back(FmiCached{dev, idx->cp_occ, idx->ref_seq_len, idx->sentinel_index, idx->count[1], d_index, bytes});
+        }
+    }
+    DevBuf denc(L), doff(L), dlen(L), dout(L), dso(L), dn(L), dw(L);
+    const size_t wb = fmi_workspace_bytes(n_reads, max_len);
+    if ((rc = denc.alloc((size_t)enc_bytes)) || (rc = doff.alloc((size_t)n_reads * 8)) || (rc = dlen.alloc((size_t)n_reads * 4)) ||
+        (rc = dout.alloc((size_t)out_cap * sizeof(gbx_fmi_smem))) || (rc = dso.alloc((size_t)(n_reads + 1) * 8)) || (rc = dn.alloc(8)) ||
+        (rc = dw.alloc(wb)))
+        return rc;
+    if (n_reads > 0) {
+        GBX_HIP(hipMemcpyAsync(denc.p, enc, (size_t)enc_bytes, hipMemcpyHostToDevice, s));
+        GBX_HIP(hipMemcpyAsync(doff.p, read_off, (size_t)n_reads * 8, hipMemcpyHostToDevice, s));
+        GBX_HIP(hipMemcpyAsync(dlen.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = fmi_launch(idx, d_index, p, n_reads, max_len, denc.as<uint8_t>(), doff.as<int64_t>(), dlen.as<int32_t>(),
+                         dout.as<gbx_fmi_smem>(), out_cap, dso.as<int64_t>(), dn.as<int64_t>(), dw.p, wb, s)))
+        return rc;
+    int64_t total = 0;
+    GBX_HIP(hipMemcpyAsync(&total, dn.p, 8, hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    *n_out = total;
+    int64_t worst = 0;
+    if ((rc = fmi_read_overflow(dw.p, &worst, s))) return rc;
+    if (worst > 0) { set_error("gbx_fmi_smem_host: a read has %lld SMEMs, more than the kernel's per-read capacity", (long long)worst); return GBX_ERR_UNSUPPORTED; }
+    if (smem_off) GBX_HIP(hipMemcpyAsync(smem_off, dso.p, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (total > out_cap) {
+        GBX_HIP(hipStreamSynchronize(s));
+        set_error("gbx_fmi_smem_host: %lld SMEMs do not fit out_cap = %lld", (long long)total, (long long)out_cap);
+        return GBX_ERR_ARG;
+    }
+    if (total > 0) GBX_HIP(hipMemcpyAsync(out, dout.p, (size_t)total * sizeof(gbx_fmi_smem), hipMemcpyDeviceToHost, s));
+    GBX_HIP(hipStreamSynchronize(s));
+    return GBX_OK;
+}
+
+// frees the device copies of the indexes gbx_fmi_smem_host keeps between calls
+int gbx_fmi_host_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_fmi_mu);
+    for (FmiCached &c : g_fmi_cache) (void)hipFree(c.d_index);
+    g_fmi_cache.clear();
+    return GBX_OK;
+}
+
 }  // extern "C"

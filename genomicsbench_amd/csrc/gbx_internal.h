@@ -80,6 +80,16 @@ int chain_read_evaluated(const void *d_work, int64_t *pairs, hipStream_t s);
 int chain_read_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors, int64_t *jobs, int64_t *longest, hipStream_t s);
 int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipStream_t s);
 
+// ---- fmi (fmi_kernels.hip)
+size_t fmi_index_bytes(int64_t ref_seq_len);
+int fmi_index_build(const gbx_fmi_index *idx, void *d_index, size_t index_bytes, hipStream_t s);
+size_t fmi_workspace_bytes(int64_t n_reads, int32_t max_len);
+int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads, int32_t max_len,
+               const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len, gbx_fmi_smem *d_out, int64_t out_cap,
+               int64_t *d_smem_off, int64_t *d_n_out, void *d_work, size_t work_bytes, hipStream_t s);
+int fmi_read_extensions(const void *d_work, int64_t *ext, hipStream_t s);
+int fmi_read_overflow(const void *d_work, int64_t *worst, hipStream_t s);
+
 // ---- phmm (phmm_kernels.hip)
 size_t phmm_workspace_bytes(int64_t n_pairs, int64_t n_reads, int max_hap_len, int64_t stream_syms = -1);
 int phmm_init_tables();

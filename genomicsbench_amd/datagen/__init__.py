@@ -39,7 +39,9 @@ def _L():
         _lib.gbx_gen_abea_model.argtypes = [u64, vp, vp]
         _lib.gbx_gen_abea_counts_many.argtypes = [u64, i64, i64, vp, vp]
         _lib.gbx_gen_abea_fill_many.argtypes = [u64, i64, i64] + [vp] * 8
-        for f in ("abea_model", "abea_counts_many", "abea_fill_many"):
+        _lib.gbx_gen_fmi_genome.argtypes = [u64, i64, vp]
+        _lib.gbx_gen_fmi_reads.argtypes = [u64, i64, i64, vp, i64, C.c_int32, vp]
+        for f in ("abea_model", "abea_counts_many", "abea_fill_many", "fmi_genome", "fmi_reads"):
             getattr(_lib, "gbx_gen_" + f).restype = None
         for f in ("chain_counts_many", "chain_fill_many", "chain_fill_real_many", "phmm_counts_many", "phmm_lengths_many", "phmm_fill_many",
                   "poa_counts_many", "poa_many"):
@@ -147,3 +149,20 @@ def gen_abea(n_reads, seed, first=0):
     scale, shift = np.zeros(n_reads, np.float32), np.zeros(n_reads, np.float32)
     L.gbx_gen_abea_fill_many(seed, first, n_reads, _p(lm), _p(ls), _p(seq_off), _p(event_off), _p(seq), _p(ev), _p(scale), _p(shift))
     return AbeaReadSet(seq_off[:-1].copy(), seq_len, seq, event_off, ev[:int(event_off[-1])], scale, shift, make_model(lm, ls))
+
+
+def gen_fmi_genome(length, seed):
+    """Synthetic genome (one strand, base codes 0..3) with repeat families and low-complexity runs."""
+    L = _L()
+    ref = np.zeros(int(length), dtype=np.uint8)
+    L.gbx_gen_fmi_genome(seed, int(length), _p(ref))
+    return ref
+
+
+def gen_fmi_reads(ref, n_reads, seed, first=0, read_len=151):
+    """fmi reads: 151-bp samples of the genome (either strand, 1 % errors, a few N), the reference's fixed-stride layout."""
+    from ..fmi import FmiReadSet
+    L = _L()
+    enc = np.zeros((int(n_reads), int(read_len)), dtype=np.uint8)
+    L.gbx_gen_fmi_reads(seed, first, int(n_reads), _p(ref), len(ref), int(read_len), _p(enc))
+    return FmiReadSet.fixed(enc)

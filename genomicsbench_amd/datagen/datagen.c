@@ -436,3 +436,89 @@ void gbx_gen_abea_fill_many(uint64_t seed, int64_t first, int64_t n_reads, const
         abea_read(seed, first + k, 1, level_mean, level_stdv, &l, &ne, seq + seq_off[k], ev + event_off[k], scale + k, shift + k);
     }
 }
+
+/* ------------------------------------------------------------------- fmi
+ * A synthetic genome and short reads for the FM-index seeding benchmark (the reference runs 151-bp reads of
+ * SRR7733443 against the index of a human reference, R/scripts/run-cpu.sh:27,58; neither is in the image).
+ * Genome: uniform bases, then `n_fam` repeat families: a family is a random element of 150-3000 bases copied to
+ * 3-30 random places (either strand) with 0-8 % divergence per copy - the source of SMEMs with more than one hit
+ * and of the re-seeding round; 0.2 % of the genome is low-complexity (dinucleotide runs of 30-200 bases).
+ * Reads: `read_len` bases from a uniform position and strand, 1 % substitutions, 0.02 % of the bases read 'N' (4),
+ * 2 % of the reads carry one 1-3 base deletion; 1 % of the reads are random sequence (unmappable).
+ * Deterministic per (seed, read index).
+ */
+void gbx_gen_fmi_genome(uint64_t seed, int64_t len, uint8_t *ref)
+{
+    const int64_t chunk = 1 << 20;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < (len + chunk - 1) / chunk; ++c) {
+        rng_t r;
+        rng_seed(&r, seed, 0xf31000000ULL + (uint64_t)c);
+        const int64_t hi = (c + 1) * chunk < len ? (c + 1) * chunk : len;
+        for (int64_t i = c * chunk; i < hi;) {
+            uint64_t w = rng_u64(&r);
+            for (int k = 0; k < 32 && i < hi; ++k, ++i, w >>= 2) ref[i] = (uint8_t)(w & 3);
+        }
+    }
+    rng_t r;
+    rng_seed(&r, seed, 0xf32ULL);
+    const int64_t n_fam = len / 40000 + 1;                 /* ~ 4 % of the genome in repeats */
+    uint8_t elem[3000];
+    for (int64_t f = 0; f < n_fam; ++f) {
+        const int el = 150 + (int)rng_below(&r, 2851);
+        if (el + 16 >= len) break;
+        for (int k = 0; k < el; ++k) elem[k] = (uint8_t)rng_below(&r, 4);
+        const int copies = 3 + (int)rng_below(&r, 28);
+        for (int c = 0; c < copies; ++c) {
+            const int64_t pos = (int64_t)(rng_unif(&r) * (double)(len - el));
+            const double div = 0.08 * rng_unif(&r) * rng_unif(&r);
+            const int rev = (int)rng_below(&r, 2);
+            for (int k = 0; k < el; ++k) {
+                uint8_t b = rev ? (uint8_t)(3 - elem[el - 1 - k]) : elem[k];
+                if (rng_unif(&r) < div) b = (uint8_t)((b + 1 + rng_below(&r, 3)) & 3);
+                ref[pos + k] = b;
+            }
+        }
+    }
+    const int64_t n_low = len / 50000;
+    for (int64_t f = 0; f < n_low; ++f) {
+        const int el = 30 + (int)rng_below(&r, 171);
+        if (el + 16 >= len) break;
+        const int64_t pos = (int64_t)(rng_unif(&r) * (double)(len - el));
+        const uint8_t a = (uint8_t)rng_below(&r, 4), b = (uint8_t)rng_below(&r, 4);
+        for (int k = 0; k < el; ++k) ref[pos + k] = (k & 1) ? b : a;
+    }
+}
+
+void gbx_gen_fmi_reads(uint64_t seed, int64_t first, int64_t n_reads, const uint8_t *ref, int64_t len, int32_t read_len, uint8_t *enc)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n_reads; ++i) {
+        rng_t r;
+        rng_seed(&r, seed, 0xf33000000000ULL + (uint64_t)(first + i));
+        uint8_t *q = enc + i * (int64_t)read_len;
+        if (rng_below(&r, 100) == 0 || len < read_len + 8) {
+            for (int k = 0; k < read_len; ++k) q[k] = (uint8_t)rng_below(&r, 4);
+            continue;
+        }
+        const int64_t pos = (int64_t)(rng_unif(&r) * (double)(len - read_len - 4));
+        const int rev = (int)rng_below(&r, 2);
+        const int del_at = rng_below(&r, 50) == 0 ? 10 + (int)rng_below(&r, (uint32_t)(read_len - 20)) : -1;
+        const int del_len = 1 + (int)rng_below(&r, 3);
+        int64_t src = pos;
+        for (int k = 0; k < read_len; ++k, ++src) {
+            if (k == del_at) src += del_len;
+            uint8_t b = ref[src < len ? src : len - 1];
+            const double u = rng_unif(&r);
+            if (u < 0.01) b = (uint8_t)((b + 1 + rng_below(&r, 3)) & 3);
+            else if (u < 0.0102) b = 4;
+            q[k] = b;
+        }
+        if (rev)
+            for (int a = 0, b = read_len - 1; a <= b; ++a, --b) {
+                const uint8_t x = q[a], y = q[b];
+                q[a] = y > 3 ? y : (uint8_t)(3 - y);
+                q[b] = x > 3 ? x : (uint8_t)(3 - x);
+            }
+    }
+}

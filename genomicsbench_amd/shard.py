@@ -321,3 +321,29 @@ def abea_from_arrays(d):
                        np.asarray(d["event_mean"])[:int(eo[-1] - eo[0])] if len(eo) else np.zeros(0, np.float32),
                        np.asarray(d["scale"]), np.asarray(d["shift"]),
                        np.ascontiguousarray(d["model"]).view(np.uint8).view(MODEL_DTYPE))
+
+
+def fmi_cost(rs):
+    """A read costs about five backwardExt calls per base, whatever its content (fmi.cpp:193-282 hands the reads out in
+    batches of equal count)."""
+    return rs.read_len.astype(np.int64) + 1
+
+
+def fmi_shards(rs, parts, ranges=None):
+    """`parts` FmiReadSet objects over contiguous read ranges (reads are independent; a batch of the reference is a
+    contiguous rid range, fmi.cpp:193-197).  The index is not part of a shard: every rank holds all of it."""
+    from .fmi import FmiReadSet
+    out = []
+    for lo, hi in (ranges or split_by_cost(fmi_cost(rs), parts)):
+        enc, off = _cut_arena(rs.enc, rs.read_off[lo:hi], rs.read_len[lo:hi])
+        out.append(FmiReadSet(enc, off, rs.read_len[lo:hi]))
+    return out
+
+
+def fmi_to_arrays(rs):
+    return dict(enc=np.concatenate([rs.enc, np.zeros(8, np.uint8)]), read_off=rs.read_off, read_len=rs.read_len)
+
+
+def fmi_from_arrays(d):
+    from .fmi import FmiReadSet
+    return FmiReadSet(np.asarray(d["enc"]), np.asarray(d["read_off"]), np.asarray(d["read_len"]))

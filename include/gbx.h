@@ -338,6 +338,69 @@ int gbx_abea_align_device(int64_t n_reads, const int64_t *d_seq_off, const int32
 /* DP cells filled by the last gbx_abea_align_device call on this workspace (the reference's `fills`, align.c:280,401). */
 int gbx_abea_cells(const void *d_work, int64_t *cells, void *stream);
 
+/* --------------------------------------------------------------------- fmi
+ * SMEM seeding on the FM-index of reference + reverse complement (second half): the three
+ * seeding rounds bwa-mem2 runs per batch of reads and the driver times,
+ *   R/benchmarks/fmi/fmi.cpp:218-228  FMI_search::getSMEMsAllPosOneThread   SMEMs from every start position
+ *   R/benchmarks/fmi/fmi.cpp:230-254  re-seeding: getSMEMsOnePosOneThread from the middle of every SMEM of at least
+ *                                     split_len bases with at most split_width hits, min_intv = hits + 1
+ *   R/benchmarks/fmi/fmi.cpp:255-266  FMI_search::bwtSeedStrategyAllPosOneThread (max_intv, minSeedLen + 1)
+ *   R/benchmarks/fmi/fmi.cpp:270-278  rid += batch offset, FMI_search::sortSMEMs
+ * FMI_search lives in tools/bwa-mem2 (an empty submodule here): the arithmetic follows bwa-mem2's published
+ * src/FMI_search.cpp (backwardExt over the CP_OCC checkpoints of 64 BWT symbols) - parity UNPINNED by a compiled
+ * reference, see oracle/fmi_oracle.c.
+ * The three rounds and the sort only ever combine SMEMs of one read, and batches are contiguous rid ranges sorted by
+ * rid first, so the job's result is independent of the batch size: for every read, in rid order, its SMEMs of all
+ * three rounds sorted by (m ascending, n descending).  Records equal in (rid, m, n) are equal in every field.
+ */
+typedef struct gbx_fmi_cp_occ {      /* bwa-mem2 CP_OCC (FMI_search.h): one checkpoint per 64 BWT symbols, 64 bytes */
+    int64_t  cp_count[4];            /* occurrences of A, C, G, T in bwt[0, 64 i) */
+    uint64_t one_hot_bwt_str[4];     /* bit 63 - j set iff bwt[64 i + j] is that base */
+} gbx_fmi_cp_occ;
+typedef struct gbx_fmi_index {       /* the fields of FMI_search the search reads (load_index) */
+    int64_t ref_seq_len;             /* reference_seq_len: 2 x genome length + 1 (the sentinel) */
+    int64_t count[5];                /* first SA row of every base, sentinel row included: count[0] = 1, count[4] = ref_seq_len */
+    int64_t sentinel_index;          /* SA row whose BWT symbol is the sentinel */
+    const gbx_fmi_cp_occ *cp_occ;    /* (ref_seq_len >> 6) + 1 checkpoints; host pointer for *_host, device pointer for *_device */
+} gbx_fmi_index;
+typedef struct gbx_fmi_smem {        /* bwa-mem2 SMEM (FMI_search.h), 40 bytes */
+    uint32_t rid;                    /* read */
+    uint32_t m, n;                   /* query interval [m, n], both inclusive (the driver prints [m, n + 1)) */
+    uint32_t pad_;
+    int64_t  k, l, s;                /* SA interval of the match, of its reverse complement, and their size */
+} gbx_fmi_smem;
+typedef struct gbx_fmi_params {      /* fmi.cpp:135-140,178 */
+    int32_t min_seed_len;            /* argv[4]; the benchmark scripts pass 19 */
+    int32_t split_width;             /* 10 */
+    int32_t split_len;               /* (int)(min_seed_len * 1.5 + .499) */
+    int32_t max_mem_intv;            /* 20 */
+} gbx_fmi_params;
+void gbx_fmi_default_params(gbx_fmi_params *p, int32_t min_seed_len);
+
+/* Host-buffer entry: reads as base codes 0..3 (4 = ambiguous, fmi.cpp:113-124), read r = enc[read_off[r] ..+ read_len[r]).
+ * out receives the SMEMs (out_cap records; GBX_ERR_ARG with the needed count in gbx_last_error() when it is too small),
+ * smem_off[n_reads + 1] (nullable) where each read's run starts, *n_out the total. */
+int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t n_reads, const uint8_t *enc, int64_t enc_bytes,
+                      const int64_t *read_off, const int32_t *read_len, gbx_fmi_smem *out, int64_t out_cap,
+                      int64_t *smem_off, int64_t *n_out);
+
+/* Device path.  The checkpoints are re-laid for the device once per index (gbx_fmi_index_bytes / gbx_fmi_index_build:
+ * the count and the one-hot word of a base side by side, so that the four lanes of a read fetch a checkpoint as one
+ * 64-byte line).  d_smem_off[n_reads + 1] and d_n_out (one int64) are written on the device; *d_n_out greater than
+ * out_cap means the output did not fit (nothing beyond out_cap is written). */
+size_t gbx_fmi_index_bytes(int64_t ref_seq_len);
+int gbx_fmi_index_build(const gbx_fmi_index *idx_with_device_cp_occ, void *d_index, size_t index_bytes, void *stream);
+size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len);
+int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads,
+                        int32_t max_read_len, const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len,
+                        gbx_fmi_smem *d_out, int64_t out_cap, int64_t *d_smem_off, int64_t *d_n_out,
+                        void *d_work, size_t work_bytes, void *stream);
+/* backwardExt calls (checkpoint look-ups: two 64-byte lines each) of the last gbx_fmi_smem_device call on this workspace. */
+int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream);
+/* gbx_fmi_smem_host keeps the device copy of an index between calls (keyed by the cp_occ address and the index scalars:
+ * a caller hands over the same tables for every batch of reads, fmi.cpp:218); this frees them. */
+int gbx_fmi_host_release(void);
+
 #ifdef __cplusplus
 }
 #endif

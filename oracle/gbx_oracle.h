@@ -66,6 +66,16 @@ void oracle_abea_align(int64_t n_reads, const int64_t *seq_off, const int32_t *s
                        const float *scale, const float *shift, gbx_abea_pair *out, int32_t *n_pairs,
                        int nthreads, int64_t *cells);
 
+/* fmi: bwa-mem2 FMI_search SMEM seeding as R/benchmarks/fmi/fmi.cpp:180-286 drives it (parity UNPINNED: tools/bwa-mem2 is
+ * an empty submodule; see fmi_oracle.c) */
+int64_t oracle_fmi_read(const gbx_fmi_index *X, const gbx_fmi_params *P, const uint8_t *q, int32_t readlength, uint32_t rid,
+                        gbx_fmi_smem *out, gbx_fmi_smem *prev, int64_t *n_ext, int32_t *round_counts);
+int64_t oracle_fmi_smem(const gbx_fmi_index *X, const gbx_fmi_params *P, int64_t n_reads, const uint8_t *enc,
+                        const int64_t *read_off, const int32_t *read_len, gbx_fmi_smem *out, int64_t out_cap,
+                        int64_t *smem_off, int nthreads, int64_t *n_ext_total, int64_t *round_totals);
+void oracle_fmi_build_index(const uint8_t *text, int64_t n, const int64_t *sa, gbx_fmi_cp_occ *cp_occ, int64_t *count5,
+                            int64_t *sentinel_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,41 @@ def abea_oracle(rs, nthreads=1, return_cells=False):
       _p(rs.scale), _p(rs.shift), _p(out), _p(n_pairs), C.c_int(nthreads), C.byref(cells))
     r = (out, n_pairs[:rs.n_reads])
     return r + (cells.value,) if return_cells else r
+
+
+def fmi_oracle(index, reads, params=None, nthreads=1, return_stats=False):
+    """oracle_fmi_smem over an FmiIndex (host) + FmiReadSet -> (SMEM array, smem_off[, backwardExt calls, per-round counts])."""
+    from genomicsbench_amd.fmi import SMEM_DTYPE, default_params
+    params = params or default_params()
+    idx = index.host()
+    st = idx.struct(idx.cp_occ.ctypes.data)
+    off = np.zeros(reads.n_reads + 1, dtype=np.int64)
+    ext, rounds = C.c_int64(0), (C.c_int64 * 3)()
+    f = oracle_lib().oracle_fmi_smem
+    f.restype = C.c_int64
+    args = [C.byref(st), C.byref(params), C.c_int64(reads.n_reads), _p(reads.enc), _p(reads.read_off), _p(reads.read_len)]
+    cap = max(64, 24 * reads.n_reads)
+    while True:
+        out = np.zeros(cap, dtype=SMEM_DTYPE)
+        total = f(*args, _p(out), C.c_int64(cap), _p(off), C.c_int(nthreads), C.byref(ext), rounds)
+        if total <= cap:
+            break
+        cap = int(total)
+    r = (out[:total], off)
+    return r + (ext.value, [int(v) for v in rounds]) if return_stats else r
+
+
+def fmi_build_index_plain(text, sa):
+    """oracle_fmi_build_index: the tables from a text (codes 0..3, already reference + reverse complement) and its
+    suffix array incl. the sentinel row - the plain loop the tensor builder of genomicsbench_amd.fmi is checked against."""
+    from genomicsbench_amd.fmi import CP_OCC_DTYPE, FmiIndex
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    sa = np.ascontiguousarray(sa, dtype=np.int64)
+    n = len(text)
+    cp = np.zeros(((n + 1) >> 6) + 1, dtype=CP_OCC_DTYPE)
+    count = np.zeros(5, dtype=np.int64)
+    sent = C.c_int64(-1)
+    f = oracle_lib().oracle_fmi_build_index
+    f.restype = None
+    f(_p(text), C.c_int64(n), _p(sa), _p(cp), _p(count), C.byref(sent))
+    return FmiIndex(n + 1, count, sent.value, cp)

@@ -1,0 +1,141 @@
+"""GPU parity tests for fmi: the HIP SMEM kernels (through the C-ABI) vs oracle/fmi_oracle.c, bit-exact on every field of every
+record (rid, m, n, k, l, s) and on the per-read offsets."""
+import numpy as np
+import pytest
+
+from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+from genomicsbench_amd.fmi import DeviceFmi, FmiReadSet, build_index, default_params, smem_host
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("rid", "m", "n", "k", "l", "s")
+
+
+def assert_same(got, want):
+    (g, goff), (w, woff) = got, want
+    assert np.array_equal(goff, woff), "per-read offsets differ, first at read %d" % int(np.nonzero(goff != woff)[0][0] - 1)
+    assert len(g) == len(w)
+    for f in FIELDS:
+        if not np.array_equal(g[f], w[f]):
+            k = int(np.nonzero(g[f] != w[f])[0][0])
+            raise AssertionError("%s differs in %d records; first at %d (read %d): got %d want %d"
+                                 % (f, int((g[f] != w[f]).sum()), k, int(w["rid"][k]), g[f][k], w[f][k]))
+
+
+@pytest.fixture(scope="module")
+def small():
+    g = gen_fmi_genome(300_000, 6001)
+    return g, build_index(g)
+
+
+def test_reads_of_the_bench_generator(small):
+    g, idx = small
+    rs = gen_fmi_reads(g, 3000, 6002)
+    P = default_params(19)
+    assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P, nthreads=8))
+
+
+@pytest.mark.parametrize("min_seed_len", [10, 19, 30])
+def test_seed_lengths_and_split_parameters(small, min_seed_len):
+    g, idx = small
+    rs = gen_fmi_reads(g, 1000, 77 + min_seed_len)
+    P = default_params(min_seed_len)
+    assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P, nthreads=8))
+    P.split_width, P.max_mem_intv = 3, 5
+    assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P, nthreads=8))
+
+
+def test_repetitive_genome_many_hits_and_reseeding():
+    """a genome made of diverged copies of one element: intervals with hundreds of hits, long prev[] arrays, the
+    re-seeding round busy."""
+    rng = np.random.default_rng(5)
+    elem = rng.integers(0, 4, 700).astype(np.uint8)
+    parts = []
+    for _ in range(60):
+        c = elem.copy()
+        hit = rng.random(700) < 0.02
+        c[hit] = (c[hit] + 1) % 4
+        parts += [c, rng.integers(0, 4, int(rng.integers(5, 60))).astype(np.uint8)]
+    g = np.concatenate(parts)
+    idx = build_index(g)
+    reads = []
+    for _ in range(600):
+        p = int(rng.integers(0, len(g) - 151))
+        r = g[p:p + 151].copy()
+        if rng.random() < 0.5:
+            r = 3 - r[::-1]
+        hit = rng.random(151) < 0.015
+        r[hit] = (r[hit] + 1) % 4
+        reads.append(r)
+    rs = FmiReadSet.fixed(np.array(reads))
+    P = default_params(19)
+    want = O.fmi_oracle(idx, rs, P, nthreads=8, return_stats=True)
+    assert want[3][1] > 0, "the re-seeding round must be exercised"
+    assert_same(smem_host(idx, rs, P), want[:2])
+
+
+def test_ragged_reads_ambiguous_bases_and_empty_reads(small):
+    g, idx = small
+    rng = np.random.default_rng(9)
+    lens = [0, 1, 2, 18, 19, 20, 21, 40, 151, 152, 255, 256, 300, 0, 151]
+    chunks, off = [], []
+    at = 0
+    for L in lens * 8:
+        p = int(rng.integers(0, len(g) - max(L, 1)))
+        r = g[p:p + L].copy()
+        if L and rng.random() < 0.5:
+            r[rng.integers(0, L, max(1, L // 30))] = 4
+        chunks.append(r)
+        off.append(at)
+        at += L + int(rng.integers(0, 3))                    # gaps between reads: any offset layout
+        chunks.append(np.full(at - off[-1] - L, 4, dtype=np.uint8))
+    chunks.append(np.full(200, 4, dtype=np.uint8))           # reads made of N only
+    off.append(at)
+    rs = FmiReadSet(np.concatenate(chunks), np.array(off), np.array(lens * 8 + [200]))
+    P = default_params(19)
+    assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P))
+
+
+def test_long_reads_take_the_lds_and_the_in_place_paths(small):
+    g, idx = small
+    rng = np.random.default_rng(10)
+    for L in (700, 2500):
+        reads = []
+        for _ in range(40):
+            p = int(rng.integers(0, len(g) - L))
+            r = g[p:p + L].copy()
+            hit = rng.random(L) < 0.02
+            r[hit] = (r[hit] + 1) % 4
+            reads.append(r)
+        rs = FmiReadSet.fixed(np.array(reads))
+        P = default_params(19)
+        assert_same(smem_host(idx, rs, P, out_cap=40 * 400), O.fmi_oracle(idx, rs, P))
+
+
+def test_device_entry_rerun_and_extension_count(small):
+    import torch
+    g, idx = small
+    rs = gen_fmi_reads(g, 5000, 6003)
+    P = default_params(19)
+    want = O.fmi_oracle(idx, rs, P, nthreads=8, return_stats=True)
+    d = DeviceFmi(idx, rs, torch.device("cuda:0"), P)
+    for _ in range(2):                                        # a second run on the same workspace gives the same
+        d.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_same(d.results(), want[:2])
+        assert d.extensions() == want[2]
+
+
+def test_output_capacity_too_small_is_reported(small):
+    g, idx = small
+    rs = gen_fmi_reads(g, 200, 6004)
+    with pytest.raises(RuntimeError, match="do not fit"):
+        smem_host(idx, rs, default_params(19), out_cap=100)
+
+
+def test_index_built_on_the_gpu_equals_the_cpu_build():
+    import torch
+    g = gen_fmi_genome(200_000, 11)
+    a, b = build_index(g), build_index(g, device="cuda:0").host()
+    assert a.count == b.count and a.sentinel_index == b.sentinel_index and a.ref_seq_len == b.ref_seq_len
+    assert np.array_equal(a.cp_occ.view(np.uint8), b.cp_occ.view(np.uint8))
