@@ -641,7 +641,7 @@ class FmiWork:
     region as in the reference, fmi.cpp:79-80); the reads are what is sharded."""
     metric, unit, dtype = "fmi_large_gext_per_s", "G backwardExt/s", "int64"
     large, seed = 10_000_000, 6001                      # the reference's large input is 10 M reads of 151 bases (R/scripts/run-cpu.sh:27)
-    genome = 256 << 20                                  # 256 Mbp: the index covers both strands, 512 MB of checkpoints
+    genome = 512 << 20                                  # 512 Mbp: the index covers both strands, 1 GB of checkpoints
 
     def __init__(self, args):
         self.n = args.size or self.large
@@ -1013,7 +1013,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--kernel", choices=sorted(WORKLOADS), default=None,
-                    help="one kernel only (default: bsw headline + chain, phmm, poa, abea under 'kernels')")
+                    help="one kernel only (default: bsw headline + chain, phmm, poa, abea, fmi under 'kernels')")
     ap.add_argument("--mode", choices=["scatter", "local"], default="scatter")
     ap.add_argument("--size", type=int, default=0, help="units per GPU (pairs / calls / batches / windows / reads); 0 = 'large'")
     ap.add_argument("--pairs", type=int, default=0, help="alias of --size for bsw")
@@ -1089,7 +1089,7 @@ def main():
     else:
         line = run_kernel("bsw", args, ctx, args.steps, args.warmup)
         others = {}
-        for kind in ("chain", "phmm", "poa", "abea"):
+        for kind in ("chain", "phmm", "poa", "abea", "fmi"):
             torch.cuda.empty_cache()
             sub = argparse.Namespace(**vars(args))
             sub.size, sub.cpu_units = 0, 0                   # --size / --cpu-units speak about the headline kernel

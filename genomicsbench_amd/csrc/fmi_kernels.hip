@@ -5,23 +5,28 @@
 // sortSMEMs), restated in oracle/fmi_oracle.c from bwa-mem2's published FMI_search.cpp; bit-exact on every field.
 //
 // What bounds it: one backwardExt is two dependent look-ups in the checkpoint table (rows k and k + s), each a
-// random 64-byte line of a table far larger than the caches, and a read is a chain of ~700 of them.  Nothing to
-// compute, everything to wait for: the design keeps as many independent line requests in flight as the chip holds
-// wavefronts.
+// random 64-byte line of a table far larger than the caches, and a read is a chain of ~800 of them.  Two limits were
+// measured: instruction issue (the bookkeeping of a read is wave-uniform-per-read code that is paid per
+// wavefront trip, however few lanes take a branch) and the rate at which a CU's vector memory path takes lane
+// requests that do not share a line (one read per lane: a third of the instructions and yet slower at every occupancy).
 //   * four lanes per read, lane b = base b: the device index stores a checkpoint as four {count, one-hot word}
-//     pairs, so a look-up is ONE 16-byte load per lane and the quad's four loads are one 64-byte line.  16 reads per
-//     wavefront, 8 wavefronts per SIMD.
+//     pairs, so a look-up is ONE 16-byte load per lane and the quad's four loads are one 64-byte line: two line
+//     requests per extension, the minimum.  16 reads per wavefront.
+//   * SA rows and interval sizes in 32 bits when the reference has fewer than 2^32 rows, in 64 otherwise (two
+//     instances): arithmetic, selects and cross-lane moves of 64-bit values are two instructions each.
 //   * the rounds of a read are a state machine with a single extension site: every trip of the main loop each
 //     read of the wavefront performs exactly one backwardExt (forward extension = backward extension of the reverse
 //     complement), whatever round and phase it is in, so the wavefront's 32 line requests are always issued together;
-//     the bookkeeping between two extensions (start a position, close a forward sweep, output an SMEM, next read)
-//     is scalar-per-quad code that runs without memory waits.
-//   * the prev[] array of the backward sweep lives in a per-quad slab in HBM, 32 bytes per entry = one 8-byte word per
-//     lane of the quad (k, l, s, n); it is short (the interval size changes ~15 times along a forward sweep) and
-//     stays in L2.  Vector memory operations of one wavefront are performed in order, so a quad reads back what it
-//     wrote without a fence.
-//   * reads are drawn from a cursor; SMEMs go to a fixed-capacity slot per read, a second kernel sorts each read's
-//     few records by (m ascending, n descending) and packs them behind a prefix sum of the counts.
+//     the usual successor of an extension (next base of the sweep, next record of the backward pass) is decided
+//     inline, the rarer transitions (close a forward sweep, next position, next round, next read) go through one
+//     dispatch that is skipped when no quad needs it.
+//   * the prev[] array of the backward sweep lives in a per-quad slab in HBM, one word per lane of the quad (k, l, s,
+//     n); the next entry is requested together with the checkpoint look-ups of the current one and entry 0 is
+//     forwarded in registers, so the sweep never waits for its own array.  Vector memory operations of one wavefront
+//     are performed in order, so a quad reads back what it wrote without a fence.
+//   * the read's bases sit in LDS, four bits each; reads are drawn from a cursor; SMEMs go to a fixed-capacity slot
+//     per read, a second kernel sorts each read's few records by (m ascending, n descending) and packs them behind a
+//     prefix sum of the counts.
 #include <algorithm>
 #include "gbx_internal.h"
 
@@ -46,262 +51,323 @@ struct FmiArgs {
     int max_len, raw_cap;
     uint2 *raw;                        // [chunk reads][raw_cap][5] 8-byte words: {rid, m} {n, 0} k l s
     int32_t *raw_count;                // [chunk reads]
-    uint2 *prev;                       // [resident quads][max_len + 1][4] 8-byte words
+    uint2 *prev;                       // [resident quads][max_len + 1][4 lanes] words of 4 or 8 bytes: k, l, s, n of a backward-sweep record
     unsigned long long *counters;      // [0] read cursor, [1] extensions, [2] overflow flag, [3] running output total
 };
 
-template <int SEL> __device__ inline unsigned quad_bcast(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, SEL * 0x55, 0xf, 0xf, true);      // quad_perm:[SEL,SEL,SEL,SEL]
-}
-template <int SEL> __device__ inline long long quad_bcast64(long long v)
-{
-    const unsigned lo = quad_bcast<SEL>((unsigned)v), hi = quad_bcast<SEL>((unsigned)((unsigned long long)v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ inline long long pick4(int a, long long v0, long long v1, long long v2, long long v3)
-{
-    return a == 0 ? v0 : a == 1 ? v1 : a == 2 ? v2 : v3;
-}
 __device__ inline long long u2ll(uint2 v) { return (long long)(((unsigned long long)v.y << 32) | v.x); }
 __device__ inline uint2 ll2u(long long v) { return make_uint2((unsigned)v, (unsigned)((unsigned long long)v >> 32)); }
 
+// quad_perm:[SEL,SEL,SEL,SEL]: the value of lane SEL of every quad in all four lanes of the quad
+template <int SEL> __device__ inline unsigned quad_bcast(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, SEL * 0x55, 0xf, 0xf, true);
+}
+template <int SEL> __device__ inline unsigned long long quad_bcast(unsigned long long v)
+{
+    const unsigned lo = quad_bcast<SEL>((unsigned)v), hi = quad_bcast<SEL>((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline unsigned shfl_iv(unsigned v, int src) { return (unsigned)__shfl((int)v, src); }
+__device__ inline unsigned long long shfl_iv(unsigned long long v, int src)
+{
+    return ((unsigned long long)(unsigned)__shfl((int)(v >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)v, src);
+}
+template <class IV> __device__ inline IV pick4(int a, IV v0, IV v1, IV v2, IV v3) { return a == 0 ? v0 : a == 1 ? v1 : a == 2 ? v2 : v3; }
+
 enum : int { ST_FWD = 0, ST_BWD = 1, ST_SEED = 2 };
 // transitions between two extensions (T_EXT: the read needs one now; T_IDLE: no reads left for this quad)
-enum : int { T_EXT, T_IDLE, T_NEXT_READ, T_ONEPOS_INIT, T_FWD_CHECK, T_FWD_END, T_BWD_J, T_BWD_P, T_BWD_JEND, T_BWD_END, T_ONEPOS_DONE,
-             T_P2_NEXT, T_SEED_INIT, T_SEED_CHECK, T_READ_DONE };
+enum : int { T_EXT, T_IDLE, T_NEXT_READ, T_ONEPOS_INIT, T_FWD_END, T_BWD_JEND, T_BWD_END, T_ONEPOS_DONE, T_P2_NEXT, T_SEED_INIT, T_READ_DONE };
 
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
-// LDSQ: the quad's read is staged in LDS (qstride bytes per quad) so that the base behind every decision is a
-// ds_read_u8 instead of a global load on the dependent chain; reads too long for that are read in place.
-template <bool LDSQ>
-__global__ void __launch_bounds__(64, 8) fmi_smem_kernel(FmiArgs A, int qstride)
+#ifndef GBX_FMI_WAVES
+#define GBX_FMI_WAVES 6              // wavefronts per SIMD the register budget of the 64-bit instance is cut for (80 VGPRs)
+#endif
+#ifndef GBX_FMI_WAVES32
+#define GBX_FMI_WAVES32 7            // ... and of the 32-bit instance (72 VGPRs; at 64 it spills: 134 ms instead of 107 for 3 M reads)
+#endif
+// IV: the type SA rows and interval sizes are held in - unsigned when the reference (both strands + sentinel) has
+// fewer than 2^32 rows, else unsigned long long (a human genome: 6.2 G rows): the kernel is bound by instruction issue
+// and 64-bit arithmetic, selects and cross-lane moves are two instructions each.
+// LDSQ: the quad's read is staged in LDS, four bits per base, so that the base behind every decision is a ds_read_b32
+// instead of a global load on the dependent chain; reads too long for that are read in place.
+template <bool LDSQ, class IV>
+__global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FMI_WAVES) fmi_smem_kernel(FmiArgs A, int qwords)
 {
-    extern __shared__ unsigned char q_lds[];
+    extern __shared__ unsigned q_lds[];
+    __shared__ IV cnt_lds[8];                         // count[] by a run-time base (a chain of selects becomes a table in scratch memory)
     const int lane = threadIdx.x, b = lane & 3;
-    const long long quad_id = (long long)blockIdx.x * 16 + (lane >> 2);
-    uint2 *const prev = A.prev + (size_t)quad_id * (size_t)(A.max_len + 1) * 4 + b;        // entry e: prev[4 e]
-    unsigned char *const ql = q_lds + (size_t)(lane >> 2) * (size_t)qstride;
-    const long long c0 = A.count[0], c1 = A.count[1], c2 = A.count[2], c3 = A.count[3], c4 = A.count[4];
-    const long long count_b = b == 0 ? c0 : b == 1 ? c1 : b == 2 ? c2 : c3;
-    auto cnt_of = [&](int c) -> long long { return c == 0 ? c0 : c == 1 ? c1 : c == 2 ? c2 : c == 3 ? c3 : c4; };
-    unsigned long long n_ext = 0;
+    if (lane < 5) cnt_lds[lane] = (IV)A.count[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    // prev[] of this quad: entry e = one IV word per lane (k, l, s, n) at (quad * (max_len + 1) + e) * 4 + b
+    IV *const prev = (IV *)A.prev + ((size_t)blockIdx.x * 16 + (lane >> 2)) * (size_t)(A.max_len + 1) * 4 + b;
+    unsigned *const ql = q_lds + (size_t)(lane >> 2) * (size_t)qwords;
+    typedef __attribute__((address_space(3))) const IV lds_iv;        // typed LDS pointer: ds_read, not a FLAT load
+    auto cnt_of = [&](int c) -> IV { return ((lds_iv *)cnt_lds)[c]; };
+    const IV sentinel = (IV)A.sentinel;
+    unsigned n_ext = 0;
     const int RAW_CAP = A.raw_cap;
 
     // quad-uniform state
     int t = T_NEXT_READ, state = ST_FWD;
-    long long rid_local = 0;                 // read of this chunk
+    int rid_local = 0;                       // read of this chunk
     const uint8_t *q = nullptr;
     int len = 0, n_out = 0;
     int phase = 0;                           // 0: every start position, 1: re-seeding, 2: LAST round
     int x = 0, j = 0, next_x = 0, min_intv = 1;
-    long long k = 0, l = 0, s = 0;           // the match being extended forwards, [x, n]
+    IV k = 0, l = 0, s = 0;                  // the match being extended forwards, [x, n]
     int n = 0;
     int num_prev = 0, vbase = 0, p = 0, num_curr = 0, curr_s = -1, m_cur = 0, a = 0;
     bool first = true;
-    long long pk = 0, pl = 0, ps = 0;        // prev[p] of the backward sweep
+    IV pk = 0, pl = 0, ps = 0;               // prev[p] of the backward sweep
     int pn = 0;
+    // the backward sweep never waits for its own array: entry p + 1 is requested together with the checkpoint look-ups
+    // of entry p (nxt, one word per lane), and entry 0 of a position - the last record of the forward sweep, later the
+    // first record the previous position kept - is still in registers: (k, l, s, n), which the forward sweep no longer needs
+    IV nxt = 0;
     int idx2 = 0, n1 = 0;
-    uint2 *raw = nullptr;
 
-    auto base_at = [&](int i) -> int { return LDSQ ? (int)((const volatile lds_u8 *)ql)[i] : (int)q[i]; };
-    auto emit = [&](int m_, int n_, long long k_, long long l_, long long s_) {
+    auto raw_of = [&]() -> uint2 * { return A.raw + (size_t)rid_local * (size_t)(RAW_CAP * 5); };
+    auto base_at = [&](int i) -> int {
+        if (LDSQ) return (int)((((const lds_u32 *)ql)[i >> 3] >> ((i & 7) << 2)) & 15u);
+        return (int)q[i];
+    };
+    auto emit = [&](int m_, int n_, IV k_, IV l_, IV s_) {
         if (n_out < RAW_CAP) {
-            uint2 *e = raw + (size_t)n_out * 5;
-            const long long rid = A.read_base + rid_local;
+            uint2 *e = raw_of() + (size_t)n_out * 5;
             // the quad writes the record's five words: lanes 0..3 the first four, lane 0 the fifth
-            const uint2 w = b == 0 ? make_uint2((unsigned)rid, (unsigned)m_) : b == 1 ? make_uint2((unsigned)n_, 0u) : b == 2 ? ll2u(k_) : ll2u(l_);
+            const uint2 w = b == 0 ? make_uint2((unsigned)(A.read_base + rid_local), (unsigned)m_) : b == 1 ? make_uint2((unsigned)n_, 0u)
+                          : b == 2 ? ll2u((long long)k_) : ll2u((long long)l_);
             e[b] = w;
-            if (b == 0) e[4] = ll2u(s_);
+            if (b == 0) e[4] = ll2u((long long)s_);
         }
         ++n_out;
     };
-    auto load_prev = [&](int view) {          // view[p] = arr[vbase - p]: the forward sweep's array read backwards
-        const uint2 w = prev[(size_t)(vbase - view) * 4];
-        const long long v = u2ll(w);
-        pk = quad_bcast64<0>(v); pl = quad_bcast64<1>(v); ps = quad_bcast64<2>(v); pn = (int)quad_bcast<3>(w.x);
+    auto take_prev = [&](IV w) {              // one word per lane -> the record in every lane
+        pk = quad_bcast<0>(w); pl = quad_bcast<1>(w); ps = quad_bcast<2>(w); pn = (int)quad_bcast<3>((unsigned)w);
     };
-    auto store_prev_arr = [&](int arr_index, long long k_, long long l_, long long s_, int n_) {
-        prev[(size_t)arr_index * 4] = b == 0 ? ll2u(k_) : b == 1 ? ll2u(l_) : b == 2 ? ll2u(s_) : make_uint2((unsigned)n_, 0u);
+    auto store_prev_arr = [&](int e, IV k_, IV l_, IV s_, int n_) {
+        prev[(size_t)e * 4] = b == 0 ? k_ : b == 1 ? l_ : b == 2 ? s_ : (IV)(unsigned)n_;
     };
     auto seed_interval = [&](int c) { k = cnt_of(c); l = cnt_of(3 - c); s = cnt_of(c + 1) - cnt_of(c); };
 
+    // steps that several transitions share (a transition is paid by the whole wavefront whenever one quad takes it, so the
+    // usual successions are taken in one go instead of one trip through the dispatch each)
+    // the next base of a forward sweep (getSMEMsOnePosOneThread's j loop head, the LAST round's alike): true = extend
+    auto fwd_next = [&]() -> bool {
+        if (j >= len) return false;
+        a = base_at(j);
+        next_x = j + 1;
+        return a < 4;
+    };
+    // one start position (getSMEMsOnePosOneThread for (read, x, min_intv)) up to its first forward extension
+    auto onepos_init = [&]() {
+        a = base_at(x);
+        next_x = x + 1;
+        if (a >= 4) { t = T_ONEPOS_DONE; return; }
+        seed_interval(a);
+        n = x; num_prev = 0; j = x + 1;
+        if (fwd_next()) { state = ST_FWD; t = T_EXT; } else t = T_FWD_END;
+    };
+    // the backward sweep moves on to position j: its first record is (k, l, s, n)
+    auto bwd_enter = [&]() {
+        if (j < 0) { t = T_BWD_END; return; }
+        a = base_at(j);
+        if (a > 3) { t = T_BWD_END; return; }
+        num_curr = 0; curr_s = -1; p = 0; first = true;
+        if (num_prev == 0) { t = T_BWD_JEND; return; }
+        pk = k; pl = l; ps = s; pn = n;
+        state = ST_BWD; t = T_EXT;
+    };
+    // the LAST round from start position x (bwtSeedStrategyAllPosOneThread): skips ambiguous bases
+    auto seed_init = [&]() {
+        for (;;) {
+            if (x >= len) { t = T_READ_DONE; return; }
+            a = base_at(x);
+            next_x = x + 1;
+            if (a >= 4) { x = next_x; continue; }
+            seed_interval(a);
+            n = x; j = x + 1;
+            if (fwd_next()) { state = ST_SEED; t = T_EXT; return; }
+            x = next_x;
+        }
+    };
+
     for (;;) {
         // ---- bookkeeping until this read needs an extension (or there is nothing left to do)
-        while (t != T_EXT && t != T_IDLE) {
-            switch (t) {
-            case T_NEXT_READ: {
-                long long r = 0;
-                if (b == 0) r = (long long)atomicAdd(&A.counters[0], 1ull);
-                r = quad_bcast64<0>(r);
-                if (r >= A.n_reads) { t = T_IDLE; break; }
-                rid_local = r;
-                len = A.read_len[A.read_base + r];
-                q = A.enc + A.read_off[A.read_base + r];
-                raw = A.raw + (size_t)r * RAW_CAP * 5;
-                n_out = 0;
-                if (len <= 0) { t = T_READ_DONE; break; }
-                if (LDSQ)
-                    for (int i = b; i < len; i += 4) ql[i] = q[i];
-                phase = 0; x = 0; min_intv = 1;
-                t = T_ONEPOS_INIT;
-                break;
-            }
-            case T_ONEPOS_INIT:                                   // getSMEMsOnePosOneThread, one (read, x, min_intv)
-                a = base_at(x);
-                next_x = x + 1;
-                if (a >= 4) { t = T_ONEPOS_DONE; break; }
-                seed_interval(a);
-                n = x; num_prev = 0; j = x + 1;
-                t = T_FWD_CHECK;
-                break;
-            case T_FWD_CHECK:
-                if (j >= len) { t = T_FWD_END; break; }
-                a = base_at(j);
-                next_x = j + 1;
-                if (a >= 4) { t = T_FWD_END; break; }
-                state = ST_FWD; t = T_EXT;
-                break;
-            case T_FWD_END:
-                if (s >= min_intv) { store_prev_arr(num_prev, k, l, s, n); ++num_prev; }
-                vbase = num_prev - 1; j = x - 1; m_cur = x;
-                t = T_BWD_J;
-                break;
-            case T_BWD_J:
-                if (j < 0) { t = T_BWD_END; break; }
-                a = base_at(j);
-                if (a > 3) { t = T_BWD_END; break; }
-                num_curr = 0; curr_s = -1; p = 0; first = true;
-                t = T_BWD_P;
-                break;
-            case T_BWD_P:
-                if (p >= num_prev) { t = T_BWD_JEND; break; }
-                load_prev(p);
-                state = ST_BWD; t = T_EXT;
-                break;
-            case T_BWD_JEND:
-                num_prev = num_curr;
-                if (num_curr == 0) { t = T_ONEPOS_DONE; break; }
-                m_cur = j; --j;
-                t = T_BWD_J;
-                break;
-            case T_BWD_END:
-                if (num_prev != 0) {
-                    load_prev(0);
-                    if (pn - m_cur + 1 >= A.min_seed_len) emit(m_cur, pn, pk, pl, ps);
+        if (__ballot(t != T_EXT) != 0) {
+            while (t != T_EXT && t != T_IDLE) {
+                switch (t) {
+                case T_NEXT_READ: {
+                    unsigned long long r = 0;
+                    if (b == 0) r = atomicAdd(&A.counters[0], 1ull);
+                    r = quad_bcast<0>(r);
+                    if ((long long)r >= A.n_reads) { t = T_IDLE; break; }
+                    rid_local = (int)r;
+                    len = A.read_len[A.read_base + r];
+                    q = A.enc + A.read_off[A.read_base + r];
+                    n_out = 0;
+                    if (len <= 0) { t = T_READ_DONE; break; }
+                    if (LDSQ) {
+                        // eight bases per dword, the quad's lanes take turns; nothing is read behind the read (the last
+                        // group base by base)
+#pragma unroll 1
+                        for (int i = b * 8; i < len; i += 32) {
+                            unsigned w = 0;
+                            if (i + 8 <= len) {
+                                unsigned lo, hi;
+                                __builtin_memcpy(&lo, q + i, 4);
+                                __builtin_memcpy(&hi, q + i + 4, 4);
+                                lo = (lo & 0x0f0f0f0fu); lo = (lo | (lo >> 4)) & 0x00ff00ffu; lo = (lo | (lo >> 8)) & 0xffffu;
+                                hi = (hi & 0x0f0f0f0fu); hi = (hi | (hi >> 4)) & 0x00ff00ffu; hi = (hi | (hi >> 8)) & 0xffffu;
+                                w = lo | (hi << 16);
+                            } else {
+                                for (int c = 0; i + c < len; ++c) w |= (unsigned)(q[i + c] & 15) << (c << 2);
+                            }
+                            ql[i >> 3] = w;
+                        }
+                    }
+                    phase = 0; x = 0; min_intv = 1;
+                    onepos_init();
+                    break;
                 }
-                t = T_ONEPOS_DONE;
-                break;
-            case T_ONEPOS_DONE:
-                if (phase == 0) {
-                    x = next_x;                                   // getSMEMsAllPosOneThread: on to the next start position
-                    if (x < len) { t = T_ONEPOS_INIT; break; }
-                    n1 = n_out < RAW_CAP ? n_out : RAW_CAP; idx2 = 0; phase = 1;
+                case T_ONEPOS_INIT:
+                    onepos_init();
+                    break;
+                case T_FWD_END:
+                    if (s >= (IV)min_intv) {
+                        store_prev_arr(num_prev, k, l, s, n); ++num_prev;          // ... and (k, l, s, n) is entry 0 of the backward view
+                    } else if (num_prev > 0) {                                      // (a seed interval below min_intv: the last record pushed)
+                        take_prev(prev[(size_t)(num_prev - 1) * 4]);
+                        k = pk; l = pl; s = ps; n = pn;
+                    }
+                    vbase = num_prev - 1; j = x - 1; m_cur = x;
+                    bwd_enter();
+                    break;
+                case T_BWD_JEND:
+                    num_prev = num_curr;
+                    if (num_curr == 0) { t = T_ONEPOS_DONE; break; }
+                    m_cur = j; --j;
+                    bwd_enter();
+                    break;
+                case T_BWD_END:
+                    if (num_prev != 0 && n - m_cur + 1 >= A.min_seed_len) emit(m_cur, n, k, l, s);      // view[0]
+                    t = T_ONEPOS_DONE;
+                    break;
+                case T_ONEPOS_DONE:
+                    if (phase == 0) {
+                        x = next_x;                                   // getSMEMsAllPosOneThread: on to the next start position
+                        if (x < len) { onepos_init(); break; }
+                        n1 = n_out < RAW_CAP ? n_out : RAW_CAP; idx2 = 0; phase = 1;
+                    }
+                    t = T_P2_NEXT;
+                    break;
+                case T_P2_NEXT: {                                     // fmi.cpp:230-254: re-seed from the middle of long, rare SMEMs
+                    if (idx2 >= n1) { phase = 2; x = 0; seed_init(); break; }
+                    const uint2 *e = raw_of() + (size_t)idx2 * 5;
+                    const uint2 w = e[b == 0 ? 0 : b == 1 ? 1 : 4];
+                    const int m_ = (int)quad_bcast<0>(w.y), n_ = (int)quad_bcast<1>(w.x);
+                    const long long s_ = (long long)quad_bcast<2>((unsigned long long)u2ll(w));
+                    ++idx2;
+                    const int start = m_, end = n_ + 1;
+                    if (end - start < A.split_len || s_ > A.split_width) break;
+                    x = (end + start) >> 1; min_intv = (int)(s_ + 1);
+                    onepos_init();
+                    break;
                 }
-                t = T_P2_NEXT;
-                break;
-            case T_P2_NEXT: {                                     // fmi.cpp:230-254: re-seed from the middle of long, rare SMEMs
-                if (idx2 >= n1) { phase = 2; x = 0; t = T_SEED_INIT; break; }
-                const uint2 *e = raw + (size_t)idx2 * 5;
-                const uint2 w = e[b == 0 ? 0 : b == 1 ? 1 : 4];
-                const int m_ = (int)quad_bcast<0>(w.y), n_ = (int)quad_bcast<1>(w.x);
-                const long long s_ = quad_bcast64<2>(u2ll(w));
-                ++idx2;
-                const int start = m_, end = n_ + 1;
-                if (end - start < A.split_len || s_ > A.split_width) break;
-                x = (end + start) >> 1; min_intv = (int)(s_ + 1);
-                t = T_ONEPOS_INIT;
-                break;
-            }
-            case T_SEED_INIT:                                     // bwtSeedStrategyAllPosOneThread
-                if (x >= len) { t = T_READ_DONE; break; }
-                a = base_at(x);
-                next_x = x + 1;
-                if (a >= 4) { x = next_x; break; }
-                seed_interval(a);
-                n = x; j = x + 1;
-                t = T_SEED_CHECK;
-                break;
-            case T_SEED_CHECK:
-                if (j >= len) { x = next_x; t = T_SEED_INIT; break; }
-                next_x = j + 1;
-                a = base_at(j);
-                if (a >= 4) { x = next_x; t = T_SEED_INIT; break; }
-                state = ST_SEED; t = T_EXT;
-                break;
-            case T_READ_DONE:
-                if (b == 0) {
-                    A.raw_count[rid_local] = n_out < RAW_CAP ? n_out : RAW_CAP;
-                    if (n_out > RAW_CAP) atomicMax(&A.counters[2], (unsigned long long)n_out);
+                case T_SEED_INIT:
+                    seed_init();
+                    break;
+                case T_READ_DONE:
+                    if (b == 0) {
+                        A.raw_count[rid_local] = n_out < RAW_CAP ? n_out : RAW_CAP;
+                        if (n_out > RAW_CAP) atomicMax(&A.counters[2], (unsigned long long)n_out);
+                    }
+                    t = T_NEXT_READ;
+                    break;
                 }
-                t = T_NEXT_READ;
-                break;
             }
+            if (__ballot(t == T_EXT) == 0) break;
         }
-        if (__ballot(t == T_EXT) == 0) break;
 
-        // ---- one backwardExt per read (FMI_search.cpp): rows sp = k and ep = k + s of the checkpoint table
+        // ---- one backwardExt per read (FMI_search.cpp): rows sp = k and ep = k + s of the checkpoint table; lane b of the
+        // quad looks up base b: one 16-byte load per row and lane, one 64-byte line per row and quad
         const bool act = t == T_EXT;
-        long long ek = 0, el = 0, es = 0;
+        IV ek = 0, el = 0, es = 0;
         int ea = 0;
         if (act) {
             if (state == ST_BWD) { ek = pk; el = pl; es = ps; ea = a; }
             else { ek = l; el = k; es = s; ea = 3 - a; }            // forwards = backwards on the reverse complement
         }
-        const long long sp = ek, ep = ek + es;
-        const uint4 csp = A.index[(size_t)(sp >> 6) * 4 + b], cep = A.index[(size_t)(ep >> 6) * 4 + b];
+        const IV sp = ek, ep = ek + es;
+        uint4 csp = A.index[(size_t)(sp >> 6) * 4 + b], cep = A.index[(size_t)(ep >> 6) * 4 + b];
+        // one 16-byte request per row and lane also in the 32-bit instance, which has no use for the counts' upper words
+        // (left alone the compiler splits the load into a dword and a dwordx2: twice the requests on the vector memory path)
+        asm volatile("" : "+v"(csp.x), "+v"(csp.y), "+v"(csp.z), "+v"(csp.w));
+        asm volatile("" : "+v"(cep.x), "+v"(cep.y), "+v"(cep.z), "+v"(cep.w));
+        if (act && state == ST_BWD && p + 1 < num_prev) nxt = prev[(size_t)(vbase - (p + 1)) * 4];
         const int ysp = (int)(sp & 63), yep = (int)(ep & 63);
         const unsigned long long msp = ysp ? ~0ull << (64 - ysp) : 0ull, mep = yep ? ~0ull << (64 - yep) : 0ull;
-        const long long occ_sp = (long long)(((unsigned long long)csp.y << 32) | csp.x) +
-                                 __builtin_popcountll((((unsigned long long)csp.w << 32) | csp.z) & msp);
-        const long long occ_ep = (long long)(((unsigned long long)cep.y << 32) | cep.x) +
-                                 __builtin_popcountll((((unsigned long long)cep.w << 32) | cep.z) & mep);
-        const long long kb = count_b + occ_sp, sb = occ_ep - occ_sp;
-        const long long s1 = quad_bcast64<1>(sb), s2 = quad_bcast64<2>(sb), s3 = quad_bcast64<3>(sb), s0 = quad_bcast64<0>(sb);
-        const long long l3 = el + ((ek <= A.sentinel && ek + es > A.sentinel) ? 1 : 0);
-        const long long l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
-        const long long rl = pick4(ea, l0, l1, l2, l3), rs = pick4(ea, s0, s1, s2, s3);
-        const int src = (lane & ~3) | ea;
-        const long long rk = (long long)(((unsigned long long)(unsigned)__shfl((int)((unsigned long long)kb >> 32), src) << 32) |
-                                         (unsigned)__shfl((int)(unsigned)kb, src));
+        auto occ = [](uint4 c, unsigned long long m) -> IV {
+            const int pc = __builtin_popcountll((((unsigned long long)c.w << 32) | c.z) & m);
+            if (sizeof(IV) == 4) return (IV)(c.x + (unsigned)pc);
+            return (IV)((((unsigned long long)c.y << 32) | c.x) + (unsigned long long)pc);
+        };
+        const IV occ_sp = occ(csp, msp), occ_ep = occ(cep, mep);
+        const IV kb = cnt_of(b) + occ_sp, sb = occ_ep - occ_sp;
+        const IV s1 = quad_bcast<1>(sb), s2 = quad_bcast<2>(sb), s3 = quad_bcast<3>(sb), s0 = quad_bcast<0>(sb);
+        const IV l3 = el + ((ek <= sentinel && ek + es > sentinel) ? 1 : 0);
+        const IV l2 = l3 + s3, l1 = l2 + s2, l0 = l1 + s1;
+        const IV rl = pick4<IV>(ea, l0, l1, l2, l3), rs = pick4<IV>(ea, s0, s1, s2, s3);
+        const IV rk = shfl_iv(kb, (lane & ~3) | ea);
         if (act) {
             ++n_ext;
-            if (state == ST_FWD) {
-                const long long nk = rl, nl = rk, ns = rs;
-                if (ns != s) { store_prev_arr(num_prev, k, l, s, n); ++num_prev; }
-                if (ns < min_intv) { next_x = j; t = T_FWD_END; }
-                else { k = nk; l = nl; s = ns; n = j; ++j; t = T_FWD_CHECK; }
-            } else if (state == ST_BWD) {
-                const long long ns = rs;
-                if (first && ns < min_intv && pn - m_cur + 1 >= A.min_seed_len) {
+            if (state == ST_BWD) {
+                const IV ns = rs;
+                if (first && ns < (IV)min_intv && pn - m_cur + 1 >= A.min_seed_len) {
                     emit(m_cur, pn, pk, pl, ps);
                     first = false;
-                } else if (ns >= min_intv && ns != (long long)curr_s) {
+                } else if (ns >= (IV)min_intv && (long long)ns != (long long)curr_s) {
                     curr_s = (int)ns;
                     store_prev_arr(vbase - num_curr, rk, rl, ns, pn);
+                    if (num_curr == 0) { k = rk; l = rl; s = ns; n = pn; }        // entry 0 of the next position's view
                     ++num_curr;
                     first = false;
                 }
                 ++p;
-                t = T_BWD_P;
+                if (p < num_prev) take_prev(nxt);                                 // stays T_EXT / ST_BWD
+                else t = T_BWD_JEND;
             } else {
-                k = rl; l = rk; s = rs; n = j;
-                if (s < A.max_intv && n - x + 1 >= A.min_seed_len + 1) {
-                    if (s > 0) emit(x, n, k, l, s);
-                    x = next_x;
-                    t = T_SEED_INIT;
+                bool more;
+                if (state == ST_FWD) {
+                    const IV ns = rs;
+                    if (ns != s) { store_prev_arr(num_prev, k, l, s, n); ++num_prev; }
+                    more = ns >= (IV)min_intv;
+                    if (more) { k = rl; l = rk; s = ns; n = j; ++j; }
+                    else { next_x = j; t = T_FWD_END; }
                 } else {
-                    ++j;
-                    t = T_SEED_CHECK;
+                    k = rl; l = rk; s = rs; n = j;
+                    more = !(s < (IV)A.max_intv && n - x + 1 >= A.min_seed_len + 1);
+                    if (more) ++j;
+                    else {
+                        if (s > 0) emit(x, n, k, l, s);
+                        x = next_x;
+                        t = T_SEED_INIT;
+                    }
+                }
+                if (more && !fwd_next()) {                                        // end of the read or an ambiguous base
+                    if (state == ST_FWD) t = T_FWD_END;
+                    else { x = next_x; t = T_SEED_INIT; }
                 }
             }
         }
     }
     // extensions of the wavefront: one count per quad
-    if (b != 0) n_ext = 0;
-    for (int d = 32; d; d >>= 1) n_ext += __shfl_xor((unsigned long long)n_ext, d);
-    if (lane == 0 && n_ext) atomicAdd(&A.counters[1], n_ext);
+    unsigned long long tot = b == 0 ? n_ext : 0;
+    for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d);
+    if (lane == 0 && tot) atomicAdd(&A.counters[1], tot);
 }
 
 // ---- counts -> offsets -> sorted, packed records
@@ -397,9 +463,9 @@ __global__ void __launch_bounds__(256) fmi_index_kernel(const gbx_fmi_cp_occ *sr
 }
 
 constexpr long long FMI_CHUNK = 4ll << 20;         // reads per launch: bounds the raw slots (4 Mi x 48 x 40 B = 7.7 GB; fewer for long reads)
-constexpr long long FMI_MAX_QUADS = 256ll * 32 * 16;   // resident quads on 256 CUs at 8 wavefronts per SIMD
+constexpr long long FMI_MAX_BLOCKS = 256ll * 4 * (GBX_FMI_WAVES32 > GBX_FMI_WAVES ? GBX_FMI_WAVES32 : GBX_FMI_WAVES);   // resident wavefronts on 256 CUs (more CUs: the grid stays this size)
 
-struct FmiLayout { size_t o_raw, o_cnt, o_prev, o_bsum, total; long long chunk, quads; };
+struct FmiLayout { size_t o_raw, o_cnt, o_prev, o_bsum, total; long long chunk, blocks; };
 static FmiLayout fmi_layout(int64_t n_reads, int32_t max_len)
 {
     FmiLayout L;
@@ -407,13 +473,13 @@ static FmiLayout fmi_layout(int64_t n_reads, int32_t max_len)
     long long cap_chunk = FMI_CHUNK * 48 / RAW_CAP;
     if (cap_chunk < 16) cap_chunk = 16;
     L.chunk = n_reads < cap_chunk ? (n_reads > 0 ? n_reads : 1) : cap_chunk;
-    const long long want = (L.chunk + 15) / 16 * 16;
-    L.quads = want < FMI_MAX_QUADS ? want : FMI_MAX_QUADS;
+    const long long want = (L.chunk + 15) / 16;
+    L.blocks = want < FMI_MAX_BLOCKS ? want : FMI_MAX_BLOCKS;
     size_t at = 64;                                                        // counters: 8 x u64
     auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
     L.o_raw = take((size_t)L.chunk * RAW_CAP * 40);
     L.o_cnt = take((size_t)L.chunk * 4);
-    L.o_prev = take((size_t)L.quads * (size_t)(max_len + 1) * 32);
+    L.o_prev = take((size_t)L.blocks * 16 * (size_t)(max_len + 1) * 32);
     L.o_bsum = take((size_t)((L.chunk + SCAN_BLOCK - 1) / SCAN_BLOCK) * 8);
     L.total = at;
     return L;
@@ -469,19 +535,29 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
     A.raw = (uint2 *)(wb + L.o_raw); A.raw_count = (int32_t *)(wb + L.o_cnt); A.prev = (uint2 *)(wb + L.o_prev);
     A.counters = counters;
     long long *bsum = (long long *)(wb + L.o_bsum);
-    // reads of up to 320 bases are staged in LDS at full occupancy (16 quads x 320 B x 32 wavefronts = the CU's 160 KB);
-    // up to 2048 bases at lower occupancy, longer ones are read in place
-    const int qstride = (max_len + 3) & ~3;
-    const bool ldsq = qstride <= 2048;
+    // the read of a quad is staged in LDS, four bits per base (an odd dword count per quad: the copies start in different
+    // banks): 16 x 19 dwords per wavefront for 151-bp reads; reads of more than ~8000 bases are read in place
+    const int qwords = ((max_len + 7) / 8) | 1;
+    const bool ldsq = (size_t)qwords * 64 <= 65536 - 128;
+    const bool wide = idx->ref_seq_len >= (1ll << 32);                // SA rows and interval sizes need 64 bits
+    // GBX_FMI_LDS_PAD (tuning aid): extra dynamic LDS per wavefront, i.e. fewer wavefronts per CU; GBX_FMI_WIDE=1 (test aid):
+    // the 64-bit instance whatever the reference length
+    static const size_t pad = getenv("GBX_FMI_LDS_PAD") ? (size_t)atol(getenv("GBX_FMI_LDS_PAD")) : 0;
+    const char *wenv = getenv("GBX_FMI_WIDE");
+    const bool w64 = wide || (wenv && atoi(wenv));
     for (long long base = 0; base < n_reads; base += L.chunk) {
         const long long m = std::min<long long>(L.chunk, n_reads - base);
         A.n_reads = m; A.read_base = base;
         GBX_HIP(hipMemsetAsync(counters, 0, 8, s));                  // the read cursor
-        const long long quads = std::min<long long>((m + 15) / 16 * 16, L.quads);
+        const long long blocks = std::min<long long>((m + 15) / 16, L.blocks);
         {
             Stage st("fmi_smem", s);
-            if (ldsq) hipLaunchKernelGGL(fmi_smem_kernel<true>, dim3((unsigned)(quads / 16)), dim3(64), (size_t)qstride * 16, s, A, qstride);
-            else hipLaunchKernelGGL(fmi_smem_kernel<false>, dim3((unsigned)(quads / 16)), dim3(64), 0, s, A, 0);
+            const dim3 g((unsigned)blocks), tb(64);
+            const size_t lds = ldsq ? (size_t)qwords * 64 + pad : pad;
+            if (ldsq && !w64) hipLaunchKernelGGL((fmi_smem_kernel<true, unsigned>), g, tb, lds, s, A, qwords);
+            else if (ldsq) hipLaunchKernelGGL((fmi_smem_kernel<true, unsigned long long>), g, tb, lds, s, A, qwords);
+            else if (!w64) hipLaunchKernelGGL((fmi_smem_kernel<false, unsigned>), g, tb, lds, s, A, 0);
+            else hipLaunchKernelGGL((fmi_smem_kernel<false, unsigned long long>), g, tb, lds, s, A, 0);
         }
         const int nb = (int)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
         {

@@ -21,7 +21,8 @@ import hashlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "genomicsbench_amd", "csrc")
-KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip"}
+KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip",
+               "fmi": "fmi_kernels.hip"}
 
 
 def sha16(path):
@@ -52,6 +53,8 @@ def stage_name(kname):
     m = re.match(r"phmm_f32_kernel<(\d+)>", kname)
     if m:
         return "phmm_f32_rpl" + m.group(1)
+    if kname.startswith("fmi_smem_kernel<"):
+        return "fmi_smem"
     if kname.startswith("poa_kernel<"):
         return "poa_window" if "false" in kname else "poa_window_long"
     return {"poa_kernel": "poa_window", "chain_kernel": "chain_dp", "chain_st_kernel": "chain_st", "bsw_lds_kernel": "bsw_lds",
@@ -73,13 +76,13 @@ def main():
     traffic, busy, insts = committed("hbm_traffic.json", "detail"), committed("valu_busy.json", "valu_busy"), committed("valu_insts.json", "valu_insts")
     # which source the counters of a kind were collected on: bench.py drops a kind's figures when its .hip file has changed since
     stamps = committed("hbm_traffic.json", "hip_sha16")
-    for k in ("bsw", "chain", "phmm", "poa", "abea"):
+    for k in ("bsw", "chain", "phmm", "poa", "abea", "fmi"):
         path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
         if not os.path.exists(path):
             continue
         stamps[k] = sha16(os.path.join(CSRC, KIND_SOURCE[k]))
         for kname, v in json.load(open(path)).items():
-            if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_")):
+            if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_", "fmi_")):
                 continue
             name = stage_name(kname)
             if "FETCH_SIZE" in v and "WRITE_SIZE" in v:

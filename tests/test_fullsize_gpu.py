@@ -104,3 +104,26 @@ def test_abea_large_all_reads():
     for r in range(rs.n_reads):
         a = 2 * int(rs.event_off[r])
         assert np.array_equal(go[a:a + int(wn[r])], wo[a:a + int(wn[r])]), "read %d" % r
+
+
+def test_fmi_two_million_reads_of_large():
+    """The first 2 M of fmi 'large' (10 M reads of 151 bases) against the oracle, every field of every SMEM, on a
+    64-Mbp genome (128 MB of checkpoints: beyond the L2, the index build and the oracle stay within seconds)."""
+    import torch
+    from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+    from genomicsbench_amd.fmi import DeviceFmi, build_index
+    from oracle import oracle_py as O
+    dev = torch.device("cuda:0")
+    g = gen_fmi_genome(64 << 20, 6001)
+    idx = build_index(g, device=dev)
+    rs = gen_fmi_reads(g, 2_000_000, 6002)
+    d = DeviceFmi(idx, rs, dev)
+    d.run(_stream())
+    torch.cuda.synchronize()
+    got, goff = d.results()
+    wo, woff, ext, _ = O.fmi_oracle(idx.host(), rs, nthreads=CORES, return_stats=True)
+    assert np.array_equal(goff, woff)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        bad = np.nonzero(got[f] != wo[f])[0]
+        assert not len(bad), "fmi %s: %d of %d records differ, first at %d" % (f, len(bad), len(wo), bad[0])
+    assert d.extensions() == ext

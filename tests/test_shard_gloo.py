@@ -189,6 +189,33 @@ def _worker(rank, world, port, tmp, kernel):
         units = len(bs.n_reads)
         if rank == 0:
             ok = np.array_equal(torch.cat(parts).numpy(), O.phmm_oracle(full, 2))
+    elif kernel == "fmi":
+        from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+        from genomicsbench_amd.fmi import SMEM_DTYPE, build_index
+        idx = build_index(gen_fmi_genome(30000, 6001))        # every rank holds the whole index (built from the same seed)
+        if rank == 0:
+            full = gen_fmi_reads(gen_fmi_genome(30000, 6001), 300, 6002)
+            per_rank = [S.fmi_to_arrays(s) for s in S.fmi_shards(full, world)]
+        mine, _ = S.scatter_arrays(per_rank)
+        rs = S.fmi_from_arrays(np_of(mine))
+        out, off = O.fmi_oracle(idx, rs)
+        flat = np.concatenate([np.array([rs.n_reads], dtype=np.int64).view(np.uint8), off.view(np.uint8), out.view(np.uint8)])
+        parts = S.gather_array(torch.from_numpy(flat))      # variable-length records: [reads | offsets | records] as bytes
+        units = rs.n_reads
+        if rank == 0:
+            wo, woff = O.fmi_oracle(idx, full)
+            recs, first, ok_off = [], 0, True
+            for p in parts:
+                p = p.numpy()
+                nr = int(p[:8].view(np.int64)[0])
+                o = p[8:8 + 8 * (nr + 1)].view(np.int64)
+                r = p[8 + 8 * (nr + 1):].view(SMEM_DTYPE).copy()
+                r["rid"] += first                            # rid is shard-local, as it is batch-local in fmi.cpp:270-273
+                ok_off = ok_off and np.array_equal(o + woff[first], woff[first:first + nr + 1])
+                recs.append(r)
+                first += nr
+            got = np.concatenate(recs)
+            ok = ok_off and first == full.n_reads and all(np.array_equal(got[f], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
     elif kernel == "abea":
         from genomicsbench_amd.datagen import gen_abea
         if rank == 0:
@@ -239,10 +266,10 @@ def _worker(rank, world, port, tmp, kernel):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kernel,total", [("bsw", 3000), ("chain", 24), ("phmm", 24), ("poa", 10), ("abea", 8)])
+@pytest.mark.parametrize("kernel,total", [("bsw", 3000), ("chain", 24), ("phmm", 24), ("poa", 10), ("abea", 8), ("fmi", 300)])
 def test_scatter_compute_gather_world2(tmp_path, kernel, total):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000) + {"bsw": 0, "chain": 1, "phmm": 2, "poa": 3, "abea": 4}[kernel]
+    port = 29500 + (os.getpid() % 2000) + {"bsw": 0, "chain": 1, "phmm": 2, "poa": 3, "abea": 4, "fmi": 5}[kernel]
     mp.spawn(_worker, args=(2, port, str(tmp_path), kernel), nprocs=2, join=True)
     ok = np.load(str(tmp_path / "ok.npy"))
     assert ok[0] == 1 and ok[1] == 2 and 0 < ok[2] < total

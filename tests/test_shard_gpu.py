@@ -127,3 +127,33 @@ def test_abea_split_compute_concat(parts):
         torch.cuda.synchronize()
         got += sh.split_pairs(*d.results())
     assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_fmi_split_compute_concat(parts):
+    import torch
+    from genomicsbench_amd import shard as S
+    from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+    from genomicsbench_amd.fmi import DeviceFmi, build_index
+    from oracle import oracle_py as O
+    dev = torch.device("cuda:0")
+    g = gen_fmi_genome(100_000, 6001)
+    idx = build_index(g)
+    full = gen_fmi_reads(g, 2000, 6002, first=500)
+    wo, woff = O.fmi_oracle(idx, full, nthreads=8)
+    didx = idx.to(dev)
+    recs, offs, first = [], [np.zeros(1, np.int64)], 0
+    for sh in S.fmi_shards(full, parts):
+        t = _to_device(S.fmi_to_arrays(sh), dev)
+        d = DeviceFmi.from_tensors(didx, (t["enc"], t["read_off"], t["read_len"]), dev)
+        d.run(_sync_stream())
+        torch.cuda.synchronize()
+        r, o = d.results()
+        r["rid"] += first                                    # shard-local rids, like the batch-local ones of fmi.cpp:270-273
+        recs.append(r)
+        offs.append(o[1:] + offs[-1][-1])
+        first += sh.n_reads
+    got, goff = np.concatenate(recs), np.concatenate(offs)
+    assert np.array_equal(goff, woff)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        assert np.array_equal(got[f], wo[f]), f
