@@ -899,6 +899,10 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         if k_units:
             break
     k_ms = ms_sum / max(launches, 1)
+    # a job that runs as several launches of the same kernel per step (fmi: chunks of reads): bytes and units per launch
+    lps = launches / max(steps, 1)
+    if lps > 1.5:
+        alg_bytes, k_units = int(alg_bytes / lps), k_units / lps
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     default_size = not args.size and per_gpu_units is None and world == 1
     traffic, tsrc = _committed(kind, "traffic", name, default_size)
