@@ -1,0 +1,207 @@
+// pipe_tsan.cpp — the host-entry plumbing of libgbx.so (csrc/host_pipeline.h: lanes, upload workers, the downloader,
+// pinned slabs, device-block cache, events) compiled for the HOST against tests/sanitize/mock_hip and run under
+// -fsanitize=thread: several caller threads drive staged / unstaged / multi-chunk / scatter / failing calls at once.
+// TEST INFRASTRUCTURE ONLY.  The header under test is the product's own file, unmodified; what is mocked is the HIP
+// runtime below it (streams = in-order worker threads, events, "device" memory = host memory).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+#include "gbx_internal.h"
+
+namespace gbx {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
+int hip_fail(hipError_t e, const char *what) { set_error("%s: %s", what, hipGetErrorString(e)); return GBX_ERR_HIP; }
+RoctxRange::RoctxRange(const char *) : on_(false) {}
+RoctxRange::~RoctxRange() {}
+}  // namespace gbx
+
+#include "host_pipeline.h"
+
+using namespace gbx;
+
+static std::atomic<int> g_fail{0};
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "pipe_tsan: FAILED %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); \
+                                             fprintf(stderr, "\n"); ++g_fail; } } while (0)
+
+static std::vector<uint8_t> random_bytes(size_t n, uint64_t seed, int mod = 256)
+{
+    std::vector<uint8_t> v(n);
+    std::mt19937_64 r(seed);
+    for (size_t i = 0; i < n; ++i) v[i] = (uint8_t)(r() % (uint64_t)mod);
+    return v;
+}
+
+// one call shaped like gbx_chain_host: two input arrays, one "kernel", two result arrays, one chunk
+static int call_one_chunk(size_t n, uint64_t seed, bool expect_ok)
+{
+    std::vector<uint8_t> a = random_bytes(n, seed), b = random_bytes(n, seed + 1), sum(n, 0), dif(n, 0);
+    HostLane lane;
+    int rc = lane.acquire();
+    if (rc) return rc;
+    Lane *L = lane.l;
+    DevBuf da(L), db(L), ds(L), dd(L);
+    if ((rc = da.alloc(n)) || (rc = db.alloc(n)) || (rc = ds.alloc(n)) || (rc = dd.alloc(n))) return rc;
+    HostPipe pipe(L, 2 * n, false);
+    if ((rc = pipe.prepare(1))) return rc;
+    pipe.stage(0, da.p, a.data(), n);
+    pipe.stage(0, db.p, b.data(), n);
+    pipe.start();
+    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+    uint8_t *pa = da.as<uint8_t>(), *pb = db.as<uint8_t>(), *ps = ds.as<uint8_t>(), *pd = dd.as<uint8_t>();
+    mock_launch(L->compute, [=] { for (size_t i = 0; i < n; ++i) { ps[i] = (uint8_t)(pa[i] + pb[i]); pd[i] = (uint8_t)(pa[i] - pb[i]); } });
+    pipe.fetch(0, sum.data(), ds.p, n);
+    pipe.fetch(0, dif.data(), dd.p, n);
+    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    rc = pipe.finish();
+    if (rc == GBX_OK && expect_ok)
+        for (size_t i = 0; i < n; i += 1 + n / 4099) {
+            CHECK(sum[i] == (uint8_t)(a[i] + b[i]) && dif[i] == (uint8_t)(a[i] - b[i]), "one-chunk result differs at %zu of %zu", i, n);
+            if (g_fail) break;
+        }
+    return rc;
+}
+
+// shaped like gbx_bsw_extend_host: three chunks, transfers on the copy stream overlapping the kernels, bases packed two
+// per byte on the way up, a second kernel stream per chunk with its own join event
+static int call_three_chunks(size_t per, uint64_t seed)
+{
+    const int C = 3;
+    std::vector<uint8_t> base = random_bytes(per * C, seed, 5);
+    std::vector<uint32_t> out(per * C, 0);
+    HostLane lane;
+    int rc = lane.acquire();
+    if (rc) return rc;
+    Lane *L = lane.l;
+    DevBuf dpacked(L), dout(L);
+    if ((rc = dpacked.alloc(per * C / 2 + 8)) || (rc = dout.alloc(per * C * 4))) return rc;
+    HostPipe pipe(L, per * C, true);
+    if ((rc = pipe.prepare(C))) return rc;
+    for (int c = 0; c < C; ++c) pipe.stage_pack4(c, dpacked.as<uint8_t>() + (size_t)c * per / 2, base.data() + (size_t)c * per, per);
+    pipe.start();
+    for (int c = 0; c < C; ++c) {
+        if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
+        const uint8_t *pk = dpacked.as<uint8_t>() + (size_t)c * per / 2;
+        uint32_t *po = dout.as<uint32_t>() + (size_t)c * per;
+        mock_launch(L->compute, [=] { for (size_t i = 0; i < per; ++i) po[i] = 7u * ((pk[i >> 1] >> ((i & 1) * 4)) & 15u) + (uint32_t)i; });
+        hipEvent_t *ev = pipe.join_events(c);
+        if (hipEventRecord(ev[0], L->compute) != hipSuccess) return pipe.finish(GBX_ERR_HIP);
+        pipe.fetch(c, out.data() + (size_t)c * per, po, per * 4);
+        if ((rc = pipe.chunk_launched(c, 1))) return pipe.finish(rc);
+    }
+    rc = pipe.finish();
+    if (rc == GBX_OK)
+        for (size_t i = 0; i < per * C; i += 1 + per / 1021) {
+            CHECK(out[i] == 7u * base[i] + (uint32_t)(i % per), "three-chunk result differs at %zu", i);
+            if (g_fail) break;
+        }
+    return rc;
+}
+
+// shaped like gbx_abea_align_host: a 4-byte field gathered out of 24-byte records on the way up, a packed result
+// scattered to per-unit places on the way down
+static int call_field_and_scatter(size_t n_rec, uint64_t seed)
+{
+    struct Rec { uint64_t start; float length, mean, stdv; };
+    std::vector<Rec> recs(n_rec);
+    std::mt19937_64 r(seed);
+    for (size_t i = 0; i < n_rec; ++i) recs[i] = Rec{r(), 1.f, (float)(r() % 100000) * 0.25f, 2.f};
+    // units of 1..400 records; results of a unit go to its own place (stride 512 floats)
+    std::vector<size_t> first, cnt;
+    for (size_t at = 0; at < n_rec;) { const size_t k = std::min<size_t>(1 + r() % 400, n_rec - at); first.push_back(at); cnt.push_back(k); at += k; }
+    std::vector<float> out(first.size() * 512, -1.f);
+    std::vector<HostPipe::Seg> segs;
+    for (size_t u = 0; u < first.size(); ++u) segs.push_back(HostPipe::Seg{(char *)(out.data() + u * 512), cnt[u] * 4});
+    HostLane lane;
+    int rc = lane.acquire();
+    if (rc) return rc;
+    Lane *L = lane.l;
+    DevBuf dm(L), dr(L);
+    if ((rc = dm.alloc(n_rec * 4)) || (rc = dr.alloc(n_rec * 4))) return rc;
+    HostPipe pipe(L, n_rec * 24, false);
+    if ((rc = pipe.prepare(1))) return rc;
+    pipe.stage_field4(0, dm.p, &recs[0].mean, n_rec, (int)sizeof(Rec));
+    pipe.start();
+    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+    const float *pm = dm.as<float>();
+    float *pr = dr.as<float>();
+    mock_launch(L->compute, [=] { for (size_t i = 0; i < n_rec; ++i) pr[i] = pm[i] * 2.f + 1.f; });
+    if (pipe.staged) pipe.fetch_scatter(0, dr.p, n_rec * 4, &segs);
+    else for (size_t u = 0; u < first.size(); ++u) pipe.fetch(0, out.data() + u * 512, pr + first[u], cnt[u] * 4);
+    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    rc = pipe.finish();
+    if (rc == GBX_OK)
+        for (size_t u = 0; u < first.size(); ++u) {
+            bool ok = true;
+            for (size_t k = 0; k < cnt[u]; ++k) ok = ok && out[u * 512 + k] == recs[first[u] + k].mean * 2.f + 1.f;
+            ok = ok && (cnt[u] == 512 || out[u * 512 + cnt[u]] == -1.f);
+            CHECK(ok, "scattered result of unit %zu differs", u);
+            if (g_fail) break;
+        }
+    return rc;
+}
+
+// an error between start() and chunk_launched(): the call must come back (no downloader left waiting)
+static void call_abandoned(size_t n, uint64_t seed)
+{
+    std::vector<uint8_t> a = random_bytes(n, seed);
+    HostLane lane;
+    if (lane.acquire()) return;
+    Lane *L = lane.l;
+    DevBuf da(L);
+    if (da.alloc(n)) return;
+    HostPipe pipe(L, n, false);
+    if (pipe.prepare(1)) return;
+    pipe.stage(0, da.p, a.data(), n);
+    pipe.start();
+    (void)pipe.wait_stage(0);
+    // ... a launch fails here: the function returns without chunk_launched(); ~HostPipe cancels and joins
+}
+
+static int g_racy;
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "--selftest-race")) {     // the harness must see a race when there is one
+        std::thread a([] { for (int i = 0; i < 100000; ++i) g_racy += i; }), b([] { for (int i = 0; i < 100000; ++i) g_racy -= i; });
+        a.join(); b.join();
+        printf("selftest %d\n", g_racy);
+        return 0;
+    }
+    const int threads = argc > 1 ? atoi(argv[1]) : 4, rounds = argc > 2 ? atoi(argv[2]) : 3;
+    setenv("GBX_HOST_STAGE_MIN", "65536", 1);                 // calls of 64 KB and more are staged
+    setenv("GBX_HOST_DOWN_PIECE", "262144", 1);               // downloads span several half-slab pieces
+    // (a) every call shape from several caller threads at once, each on its own lane; lanes and their device-block caches
+    //     are reused round after round
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([=] {
+            for (int r = 0; r < rounds; ++r) {
+                const uint64_t seed = 1000u * (uint64_t)t + (uint64_t)r;
+                CHECK(call_one_chunk((size_t)3 << 20, seed, true) == GBX_OK, "staged one-chunk call: %s", g_err);
+                CHECK(call_one_chunk(5000 + 977 * (size_t)t, seed + 7, true) == GBX_OK, "small (unstaged / packed) call: %s", g_err);
+                CHECK(call_three_chunks(((size_t)1 << 20) + 64 * (size_t)t, seed + 13) == GBX_OK, "three-chunk call: %s", g_err);
+                CHECK(call_field_and_scatter(150000 + 1000 * (size_t)t, seed + 17) == GBX_OK, "field / scatter call: %s", g_err);
+                CHECK(call_field_and_scatter(300, seed + 19) == GBX_OK, "small field call: %s", g_err);
+                call_abandoned((size_t)1 << 20, seed + 23);
+            }
+        });
+    for (auto &x : th) x.join();
+    // (b) a transfer that fails in the middle of a staged call: an error comes back, nothing hangs, the next call works
+    for (int k : {0, 1, 3, 6}) {
+        mock_fail_after(k);
+        const int rc = call_one_chunk((size_t)24 << 20, 99 + (uint64_t)k, false);
+        mock_fail_after(-1);
+        CHECK(rc != GBX_OK, "a failing hipMemcpyAsync (the %d-th) must fail the call", k);
+        CHECK(call_one_chunk((size_t)1 << 20, 199 + (uint64_t)k, true) == GBX_OK, "call after a failed one: %s", g_err);
+    }
+    if (g_fail.load()) { fprintf(stderr, "pipe_tsan: %d check(s) failed\n", g_fail.load()); return 1; }
+    printf("pipe_tsan: ok (%d caller threads x %d rounds)\n", threads, rounds);
+    return 0;
+}
