@@ -124,7 +124,7 @@ def _declare(L):
         L.gbx_fmi_index_bytes.argtypes = [i64]
         L.gbx_fmi_index_bytes.restype = sz
         L.gbx_fmi_index_build.argtypes = [vp, vp, sz, vp]
-        L.gbx_fmi_workspace_bytes.argtypes = [i64, C.c_int32]
+        L.gbx_fmi_workspace_bytes.argtypes = [i64, C.c_int32, C.c_int32]
         L.gbx_fmi_workspace_bytes.restype = sz
         L.gbx_fmi_smem_host.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, C.POINTER(C.c_int64)]
         L.gbx_fmi_smem_device.argtypes = [vp, vp, vp, i64, C.c_int32, vp, vp, vp, vp, i64, vp, vp, vp, sz, vp]

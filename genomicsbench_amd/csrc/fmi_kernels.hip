@@ -33,9 +33,15 @@
 namespace gbx {
 namespace {
 
-// SMEMs of one read before the pack pass: 48 for short reads (the reference sizes its array at 20 per read and the
-// bench's 151-bp reads give 8.5 on average, 18 at most), 3/8 of the read length for long ones (a 700-base read: 56)
-__host__ __device__ inline int raw_cap_for(int max_len) { const int c = (max_len * 3 + 7) / 8; return c > 48 ? c : 48; }
+// SMEMs of one read before the pack pass: the LAST round reports up to one seed per minSeedLen + 1 bases and the first
+// two rounds about as many again: 48 for 151-bp reads at minSeedLen 19 (8.6 on average, 18 at most on the bench's reads;
+// the reference sizes its array at 20 per read), 4 per minSeedLen bases for long reads or short seeds
+__host__ __device__ inline int raw_cap_for(int max_len, int min_seed_len)
+{
+    const int msl = min_seed_len > 1 ? min_seed_len : 1;
+    const int c = (4 * max_len + msl - 1) / msl + 16;
+    return c > 48 ? c : 48;
+}
 constexpr int SCAN_BLOCK = 1024;       // reads per block of the count scan
 
 struct FmiArgs {
@@ -84,6 +90,9 @@ typedef __attribute__((address_space(3))) unsigned lds_u32;
 #ifndef GBX_FMI_WAVES
 #define GBX_FMI_WAVES 6              // wavefronts per SIMD the register budget of the 64-bit instance is cut for (80 VGPRs)
 #endif
+#ifndef GBX_FMI_LDS_PREV
+#define GBX_FMI_LDS_PREV 16          // records of a quad's prev[] array that live in LDS (32-bit instance; half as many in the 64-bit one)
+#endif
 #ifndef GBX_FMI_WAVES32
 #define GBX_FMI_WAVES32 7            // ... and of the 32-bit instance (72 VGPRs; at 64 it spills: 134 ms instead of 107 for 3 M reads)
 #endif
@@ -102,8 +111,13 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();
     // prev[] of this quad: entry e = one IV word per lane (k, l, s, n) at (quad * (max_len + 1) + e) * 4 + b
+    // its first EL records live in LDS (a forward sweep changes the interval size ~15 times for a 1-Gbase text, so the
+    // backward passes mostly stay there: the array was 30 of the 105 HBM bytes per extension), the rest in the HBM slab
     IV *const prev = (IV *)A.prev + ((size_t)blockIdx.x * 16 + (lane >> 2)) * (size_t)(A.max_len + 1) * 4 + b;
+    constexpr int EL = GBX_FMI_LDS_PREV * 4 / (int)sizeof(IV);
     unsigned *const ql = q_lds + (size_t)(lane >> 2) * (size_t)qwords;
+    IV *const lprev = (IV *)(q_lds + (LDSQ ? 16 * (size_t)qwords : 0)) + (size_t)(lane >> 2) * (EL * 4) + b;
+    auto prev_load = [&](int e) -> IV { return (EL > 0 && e < EL) ? lprev[e * 4] : prev[(size_t)e * 4]; };
     typedef __attribute__((address_space(3))) const IV lds_iv;        // typed LDS pointer: ds_read, not a FLAT load
     auto cnt_of = [&](int c) -> IV { return ((lds_iv *)cnt_lds)[c]; };
     const IV sentinel = (IV)A.sentinel;
@@ -149,7 +163,9 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
         pk = quad_bcast<0>(w); pl = quad_bcast<1>(w); ps = quad_bcast<2>(w); pn = (int)quad_bcast<3>((unsigned)w);
     };
     auto store_prev_arr = [&](int e, IV k_, IV l_, IV s_, int n_) {
-        prev[(size_t)e * 4] = b == 0 ? k_ : b == 1 ? l_ : b == 2 ? s_ : (IV)(unsigned)n_;
+        const IV v = b == 0 ? k_ : b == 1 ? l_ : b == 2 ? s_ : (IV)(unsigned)n_;
+        if (EL > 0 && e < EL) lprev[e * 4] = v;
+        else prev[(size_t)e * 4] = v;
     };
     auto seed_interval = [&](int c) { k = cnt_of(c); l = cnt_of(3 - c); s = cnt_of(c + 1) - cnt_of(c); };
 
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                     if (s >= (IV)min_intv) {
                         store_prev_arr(num_prev, k, l, s, n); ++num_prev;          // ... and (k, l, s, n) is entry 0 of the backward view
                     } else if (num_prev > 0) {                                      // (a seed interval below min_intv: the last record pushed)
-                        take_prev(prev[(size_t)(num_prev - 1) * 4]);
+                        take_prev(prev_load(num_prev - 1));
                         k = pk; l = pl; s = ps; n = pn;
                     }
                     vbase = num_prev - 1; j = x - 1; m_cur = x;
@@ -307,7 +323,7 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
         // (left alone the compiler splits the load into a dword and a dwordx2: twice the requests on the vector memory path)
         asm volatile("" : "+v"(csp.x), "+v"(csp.y), "+v"(csp.z), "+v"(csp.w));
         asm volatile("" : "+v"(cep.x), "+v"(cep.y), "+v"(cep.z), "+v"(cep.w));
-        if (act && state == ST_BWD && p + 1 < num_prev) nxt = prev[(size_t)(vbase - (p + 1)) * 4];
+        if (act && state == ST_BWD && p + 1 < num_prev) nxt = prev_load(vbase - (p + 1));
         const int ysp = (int)(sp & 63), yep = (int)(ep & 63);
         const unsigned long long msp = ysp ? ~0ull << (64 - ysp) : 0ull, mep = yep ? ~0ull << (64 - yep) : 0ull;
         auto occ = [](uint4 c, unsigned long long m) -> IV {
@@ -466,10 +482,9 @@ constexpr long long FMI_CHUNK = 4ll << 20;         // reads per launch: bounds t
 constexpr long long FMI_MAX_BLOCKS = 256ll * 4 * (GBX_FMI_WAVES32 > GBX_FMI_WAVES ? GBX_FMI_WAVES32 : GBX_FMI_WAVES);   // resident wavefronts on 256 CUs (more CUs: the grid stays this size)
 
 struct FmiLayout { size_t o_raw, o_cnt, o_prev, o_bsum, total; long long chunk, blocks; };
-static FmiLayout fmi_layout(int64_t n_reads, int32_t max_len)
+static FmiLayout fmi_layout(int64_t n_reads, int32_t max_len, int RAW_CAP)
 {
     FmiLayout L;
-    const int RAW_CAP = raw_cap_for(max_len);
     long long cap_chunk = FMI_CHUNK * 48 / RAW_CAP;
     if (cap_chunk < 16) cap_chunk = 16;
     L.chunk = n_reads < cap_chunk ? (n_reads > 0 ? n_reads : 1) : cap_chunk;
@@ -499,7 +514,11 @@ int fmi_index_build(const gbx_fmi_index *idx, void *d_index, size_t index_bytes,
     return GBX_OK;
 }
 
-size_t fmi_workspace_bytes(int64_t n_reads, int32_t max_len) { return fmi_layout(n_reads, max_len).total; }
+// raw_cap = records a read may produce before the pack pass; 0: the default for these parameters (raw_cap_for)
+size_t fmi_workspace_bytes(int64_t n_reads, int32_t max_len, int32_t min_seed_len, int raw_cap)
+{
+    return fmi_layout(n_reads, max_len, raw_cap > 0 ? raw_cap : raw_cap_for(max_len, min_seed_len)).total;
+}
 
 int fmi_read_extensions(const void *d_work, int64_t *ext, hipStream_t s)
 {
@@ -512,11 +531,12 @@ int fmi_read_extensions(const void *d_work, int64_t *ext, hipStream_t s)
 
 int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads, int32_t max_len,
                const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len, gbx_fmi_smem *d_out, int64_t out_cap,
-               int64_t *d_smem_off, int64_t *d_n_out, void *d_work, size_t work_bytes, hipStream_t s)
+               int64_t *d_smem_off, int64_t *d_n_out, void *d_work, size_t work_bytes, hipStream_t s, int raw_cap)
 {
+    if (raw_cap <= 0) raw_cap = raw_cap_for(max_len, p->min_seed_len);
     if (max_len < 0 || max_len > 65535) { set_error("fmi: reads of up to 65535 bases (the reference asserts 10000, fmi.cpp:93)"); return GBX_ERR_UNSUPPORTED; }
     if (idx->ref_seq_len < 2 || idx->ref_seq_len >= (1ll << 40)) { set_error("fmi: bad reference length"); return GBX_ERR_ARG; }
-    const FmiLayout L = fmi_layout(n_reads, max_len);
+    const FmiLayout L = fmi_layout(n_reads, max_len, raw_cap);
     if (work_bytes < L.total) { set_error("fmi: workspace too small"); return GBX_ERR_ARG; }
     char *wb = (char *)d_work;
     unsigned long long *counters = (unsigned long long *)wb;
@@ -531,7 +551,7 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
     for (int c = 0; c < 5; ++c) A.count[c] = idx->count[c];
     A.sentinel = idx->sentinel_index;
     A.min_seed_len = p->min_seed_len; A.split_width = p->split_width; A.split_len = p->split_len; A.max_intv = p->max_mem_intv;
-    A.enc = d_enc; A.read_off = d_read_off; A.read_len = d_read_len; A.max_len = max_len; A.raw_cap = raw_cap_for(max_len);
+    A.enc = d_enc; A.read_off = d_read_off; A.read_len = d_read_len; A.max_len = max_len; A.raw_cap = raw_cap;
     A.raw = (uint2 *)(wb + L.o_raw); A.raw_count = (int32_t *)(wb + L.o_cnt); A.prev = (uint2 *)(wb + L.o_prev);
     A.counters = counters;
     long long *bsum = (long long *)(wb + L.o_bsum);
@@ -553,7 +573,7 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
         {
             Stage st("fmi_smem", s);
             const dim3 g((unsigned)blocks), tb(64);
-            const size_t lds = ldsq ? (size_t)qwords * 64 + pad : pad;
+            const size_t lds = (ldsq ? (size_t)qwords * 64 : 0) + (size_t)GBX_FMI_LDS_PREV * 16 * 16 + pad;
             if (ldsq && !w64) hipLaunchKernelGGL((fmi_smem_kernel<true, unsigned>), g, tb, lds, s, A, qwords);
             else if (ldsq) hipLaunchKernelGGL((fmi_smem_kernel<true, unsigned long long>), g, tb, lds, s, A, qwords);
             else if (!w64) hipLaunchKernelGGL((fmi_smem_kernel<false, unsigned>), g, tb, lds, s, A, 0);

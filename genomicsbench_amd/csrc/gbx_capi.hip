@@ -1200,7 +1200,10 @@ int gbx_fmi_index_build(const gbx_fmi_index *idx, void *d_index, size_t index_by
     return fmi_index_build(idx, d_index, index_bytes, (hipStream_t)stream);
 }
 
-size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len) { return fmi_workspace_bytes(n_reads, max_read_len); }
+size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len, int32_t min_seed_len)
+{
+    return fmi_workspace_bytes(n_reads, max_read_len, min_seed_len);
+}
 
 static int fmi_check(const gbx_fmi_index *idx, const gbx_fmi_params *p, const char *who)
 {
@@ -1231,6 +1234,12 @@ int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx
     if ((rc = require_device())) return rc;
     return fmi_launch(idx, d_index, p, n_reads, max_read_len, d_enc, d_read_off, d_read_len, d_out, out_cap, d_smem_off, d_n_out,
                       d_work, work_bytes, (hipStream_t)stream);
+}
+
+int gbx_fmi_overflow(const void *d_work, int64_t *worst, void *stream)
+{
+    if (!d_work || !worst) { set_error("gbx_fmi_overflow: null pointer"); return GBX_ERR_ARG; }
+    return fmi_read_overflow(d_work, worst, (hipStream_t)stream);
 }
 
 int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream)
@@ -1298,35 +1307,66 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
         }
     }
     DevBuf denc(L), doff(L), dlen(L), dout(L), dso(L), dn(L), dw(L);
-    const size_t wb = fmi_workspace_bytes(n_reads, max_len);
+    const char *cap_env = getenv("GBX_FMI_RAW_CAP");          /* test aid: records per read slot of the first pass */
+    const int cap0 = cap_env && atoi(cap_env) > 0 ? atoi(cap_env) : 0;
+    size_t wb = fmi_workspace_bytes(n_reads, max_len, p->min_seed_len, cap0);
     if ((rc = denc.alloc((size_t)enc_bytes)) || (rc = doff.alloc((size_t)n_reads * 8)) || (rc = dlen.alloc((size_t)n_reads * 4)) ||
         (rc = dout.alloc((size_t)out_cap * sizeof(gbx_fmi_smem))) || (rc = dso.alloc((size_t)(n_reads + 1) * 8)) || (rc = dn.alloc(8)) ||
         (rc = dw.alloc(wb)))
         return rc;
+    // one pipeline chunk (host_pipeline.h): staged uploads of the reads, the kernels on the lane's compute stream, then -
+    // once the total is known - staged downloads of the records and the per-read offsets
+    HostPipe pipe(L, (size_t)enc_bytes + (size_t)n_reads * 12, false);
+    if ((rc = pipe.prepare(1))) return rc;
     if (n_reads > 0) {
-        GBX_HIP(hipMemcpyAsync(denc.p, enc, (size_t)enc_bytes, hipMemcpyHostToDevice, s));
-        GBX_HIP(hipMemcpyAsync(doff.p, read_off, (size_t)n_reads * 8, hipMemcpyHostToDevice, s));
-        GBX_HIP(hipMemcpyAsync(dlen.p, read_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        pipe.stage(0, denc.p, enc, (size_t)enc_bytes);
+        pipe.stage(0, doff.p, read_off, (size_t)n_reads * 8);
+        pipe.stage(0, dlen.p, read_len, (size_t)n_reads * 4);
     }
+    pipe.start();
+    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
     if ((rc = fmi_launch(idx, d_index, p, n_reads, max_len, denc.as<uint8_t>(), doff.as<int64_t>(), dlen.as<int32_t>(),
-                         dout.as<gbx_fmi_smem>(), out_cap, dso.as<int64_t>(), dn.as<int64_t>(), dw.p, wb, s)))
-        return rc;
-    int64_t total = 0;
-    GBX_HIP(hipMemcpyAsync(&total, dn.p, 8, hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipStreamSynchronize(s));
+                         dout.as<gbx_fmi_smem>(), out_cap, dso.as<int64_t>(), dn.as<int64_t>(), dw.p, wb, s, cap0)))
+        return pipe.finish(rc);
+    int64_t total = 0, worst = 0;
+    {
+        hipError_t e = hipMemcpyAsync(&total, dn.p, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return pipe.finish(hip_fail(e, "gbx_fmi_smem_host"));
+    }
     *n_out = total;
-    int64_t worst = 0;
-    if ((rc = fmi_read_overflow(dw.p, &worst, s))) return rc;
-    if (worst > 0) { set_error("gbx_fmi_smem_host: a read has %lld SMEMs, more than the kernel's per-read capacity", (long long)worst); return GBX_ERR_UNSUPPORTED; }
-    if (smem_off) GBX_HIP(hipMemcpyAsync(smem_off, dso.p, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (total > out_cap) {
-        GBX_HIP(hipStreamSynchronize(s));
+    if ((rc = fmi_read_overflow(dw.p, &worst, s))) return pipe.finish(rc);
+    // a read with more SMEMs than its slot holds (very repetitive text, long reads with short seeds): the job runs again
+    // with larger slots.  The count a pass reports for such a read is a lower bound (the re-seeding round only sees the
+    // records that were kept), so the size at least doubles and the pass is checked again.
+    int64_t cap_now = cap0;
+    for (int attempt = 0; worst > 0; ++attempt) {
+        cap_now = std::max<int64_t>(worst + 16, 2 * std::max<int64_t>(cap_now, 48));
+        wb = fmi_workspace_bytes(n_reads, max_len, p->min_seed_len, (int)cap_now);
+        DevBuf dw2(L);
+        if (attempt >= 6 || cap_now > (1 << 20) || (rc = dw2.alloc(wb))) {
+            set_error("gbx_fmi_smem_host: a read has more than %lld SMEMs and there is no workspace for slots of that size", (long long)worst);
+            return pipe.finish(rc ? rc : GBX_ERR_UNSUPPORTED);
+        }
+        if ((rc = fmi_launch(idx, d_index, p, n_reads, max_len, denc.as<uint8_t>(), doff.as<int64_t>(), dlen.as<int32_t>(),
+                             dout.as<gbx_fmi_smem>(), out_cap, dso.as<int64_t>(), dn.as<int64_t>(), dw2.p, wb, s, (int)cap_now)))
+            return pipe.finish(rc);
+        hipError_t e = hipMemcpyAsync(&total, dn.p, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return pipe.finish(hip_fail(e, "gbx_fmi_smem_host"));
+        *n_out = total;
+        if ((rc = fmi_read_overflow(dw2.p, &worst, s))) return pipe.finish(rc);
+    }
+    if (smem_off) pipe.fetch(0, smem_off, dso.p, (size_t)(n_reads + 1) * 8);
+    const bool fits = total <= out_cap;
+    if (fits && total > 0) pipe.fetch(0, out, dout.p, (size_t)total * sizeof(gbx_fmi_smem));
+    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    rc = pipe.finish();
+    if (!rc && !fits) {
         set_error("gbx_fmi_smem_host: %lld SMEMs do not fit out_cap = %lld", (long long)total, (long long)out_cap);
         return GBX_ERR_ARG;
     }
-    if (total > 0) GBX_HIP(hipMemcpyAsync(out, dout.p, (size_t)total * sizeof(gbx_fmi_smem), hipMemcpyDeviceToHost, s));
-    GBX_HIP(hipStreamSynchronize(s));
-    return GBX_OK;
+    return rc;
 }
 
 // frees the device copies of the indexes gbx_fmi_smem_host keeps between calls

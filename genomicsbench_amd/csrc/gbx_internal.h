@@ -83,10 +83,10 @@ int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipSt
 // ---- fmi (fmi_kernels.hip)
 size_t fmi_index_bytes(int64_t ref_seq_len);
 int fmi_index_build(const gbx_fmi_index *idx, void *d_index, size_t index_bytes, hipStream_t s);
-size_t fmi_workspace_bytes(int64_t n_reads, int32_t max_len);
+size_t fmi_workspace_bytes(int64_t n_reads, int32_t max_len, int32_t min_seed_len, int raw_cap = 0);
 int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads, int32_t max_len,
                const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len, gbx_fmi_smem *d_out, int64_t out_cap,
-               int64_t *d_smem_off, int64_t *d_n_out, void *d_work, size_t work_bytes, hipStream_t s);
+               int64_t *d_smem_off, int64_t *d_n_out, void *d_work, size_t work_bytes, hipStream_t s, int raw_cap = 0);
 int fmi_read_extensions(const void *d_work, int64_t *ext, hipStream_t s);
 int fmi_read_overflow(const void *d_work, int64_t *worst, hipStream_t s);
 

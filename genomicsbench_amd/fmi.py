@@ -131,6 +131,54 @@ def build_index(ref, device=None):
     return idx.host() if dev.type == "cpu" else idx
 
 
+def save_index(index, path):
+    """The tables FMI_search::load_index fills, in the file format of the fmi driver (csrc/drivers/fmi_main.cpp):
+    "GBXFMI01", int64 ref_seq_len, int64 count[5], int64 sentinel_index, then the CP_OCC records (bwa-mem2's layout)."""
+    idx = index.host()
+    with open(path, "wb") as f:
+        f.write(b"GBXFMI01")
+        f.write(np.array([idx.ref_seq_len] + idx.count + [idx.sentinel_index], dtype="<i8").tobytes())
+        f.write(idx.cp_occ.view(np.uint8).tobytes())
+
+
+def load_index(path):
+    with open(path, "rb") as f:
+        assert f.read(8) == b"GBXFMI01", "not an fmi index file"
+        head = np.frombuffer(f.read(56), dtype="<i8")
+        cp = np.frombuffer(f.read(), dtype=CP_OCC_DTYPE).copy()
+    assert len(cp) == (int(head[0]) >> 6) + 1
+    return FmiIndex(int(head[0]), head[1:6], int(head[6]), cp)
+
+
+def write_reads(path, reads, fastq=True, wrap=0):
+    """FASTQ (four lines per read) or FASTA (sequence lines wrapped at `wrap` bases when > 0) of an FmiReadSet."""
+    letters = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    with open(path, "wb") as f:
+        for r in range(reads.n_reads):
+            a = int(reads.read_off[r])
+            seq = letters[np.minimum(reads.enc[a:a + int(reads.read_len[r])], 4)].tobytes()
+            if fastq:
+                f.write(b"@r%d\n" % r + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+            else:
+                f.write(b">r%d\n" % r)
+                step = wrap if wrap > 0 else max(len(seq), 1)
+                for k in range(0, max(len(seq), 1), step):
+                    f.write(seq[k:k + step] + b"\n")
+
+
+def smems_text(smem):
+    """What the reference prints under PRINT_OUTPUT (fmi.cpp:312-343): "rid:" for every read up to the last one that has an
+    SMEM, "[m,n+1]" per SMEM."""
+    out, prev = [], -1
+    for s in smem:
+        rid = int(s["rid"])
+        if rid != prev:
+            out += ["%d:" % j for j in range(prev + 1, rid + 1)]
+        prev = rid
+        out.append("[%d,%d]" % (int(s["m"]), int(s["n"]) + 1))
+    return out
+
+
 class FmiReadSet:
     """Reads as base codes 0..3, 4 = ambiguous (fmi.cpp:113-124): read r = enc[read_off[r] ..+ read_len[r])."""
 
@@ -161,14 +209,19 @@ def smem_host(index, reads, params=None, out_cap=None):
     """gbx_fmi_smem_host -> (SMEM_DTYPE array, smem_off int64[n_reads + 1])."""
     params = params or default_params()
     idx = index.host()
-    cap = int(out_cap if out_cap is not None else max(64, 24 * reads.n_reads))
-    out = np.zeros(cap, dtype=SMEM_DTYPE)
+    cap = int(out_cap if out_cap is not None else max(64, 20 * reads.n_reads))     # the reference's quota: 20 per read (fmi.cpp:183)
     off = np.zeros(reads.n_reads + 1, dtype=np.int64)
     n_out = C.c_int64(0)
     st = idx.struct(idx.cp_occ.ctypes.data)
-    N.check(N.lib().gbx_fmi_smem_host(C.byref(st), C.byref(params), reads.n_reads, N.ptr(reads.enc), reads.enc.size,
-                                      N.ptr(reads.read_off), N.ptr(reads.read_len), N.ptr(out), cap, N.ptr(off), C.byref(n_out)))
-    return out[:n_out.value], off
+    while True:
+        out = np.empty(cap, dtype=SMEM_DTYPE)
+        rc = N.lib().gbx_fmi_smem_host(C.byref(st), C.byref(params), reads.n_reads, N.ptr(reads.enc), reads.enc.size,
+                                       N.ptr(reads.read_off), N.ptr(reads.read_len), N.ptr(out), cap, N.ptr(off), C.byref(n_out))
+        if rc == -1 and out_cap is None and n_out.value > cap:       # like the reference's "realloc" (fmi.cpp:207-216)
+            cap = int(n_out.value)
+            continue
+        N.check(rc)
+        return out[:n_out.value], off
 
 
 class DeviceFmi:
@@ -196,7 +249,7 @@ class DeviceFmi:
         self.out = torch.zeros(self.out_cap * SMEM_DTYPE.itemsize, dtype=torch.uint8, device=device)
         self.smem_off = torch.zeros(reads.n_reads + 1, dtype=torch.int64, device=device)
         self.n_out = torch.zeros(1, dtype=torch.int64, device=device)
-        self.work_bytes = N.lib().gbx_fmi_workspace_bytes(reads.n_reads, self.max_len)
+        self.work_bytes = N.lib().gbx_fmi_workspace_bytes(reads.n_reads, self.max_len, self.params.min_seed_len)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
 
     @classmethod
@@ -218,7 +271,7 @@ class DeviceFmi:
         self.out = torch.zeros(self.out_cap * SMEM_DTYPE.itemsize, dtype=torch.uint8, device=device)
         self.smem_off = torch.zeros(self.n_reads + 1, dtype=torch.int64, device=device)
         self.n_out = torch.zeros(1, dtype=torch.int64, device=device)
-        self.work_bytes = L.gbx_fmi_workspace_bytes(self.n_reads, self.max_len)
+        self.work_bytes = L.gbx_fmi_workspace_bytes(self.n_reads, self.max_len, self.params.min_seed_len)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=device)
         return self
 

@@ -390,11 +390,17 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
  * out_cap means the output did not fit (nothing beyond out_cap is written). */
 size_t gbx_fmi_index_bytes(int64_t ref_seq_len);
 int gbx_fmi_index_build(const gbx_fmi_index *idx_with_device_cp_occ, void *d_index, size_t index_bytes, void *stream);
-size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len);
+size_t gbx_fmi_workspace_bytes(int64_t n_reads, int32_t max_read_len, int32_t min_seed_len);
 int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_params *p, int64_t n_reads,
                         int32_t max_read_len, const uint8_t *d_enc, const int64_t *d_read_off, const int32_t *d_read_len,
                         gbx_fmi_smem *d_out, int64_t out_cap, int64_t *d_smem_off, int64_t *d_n_out,
                         void *d_work, size_t work_bytes, void *stream);
+/* A read's SMEMs wait in a slot of max(48, 4 * max_read_len / min_seed_len + 16) records for the pack pass.  *worst = 0, or
+ * a lower bound of the largest count a read of the last gbx_fmi_smem_device call on this workspace asked for when that was
+ * more (its surplus records, and what the re-seeding round would have made of them, are missing from the output then:
+ * very repetitive text, long reads with short seeds).  The host entry runs such a job again with larger slots until
+ * every read fits. */
+int gbx_fmi_overflow(const void *d_work, int64_t *worst, void *stream);
 /* backwardExt calls (checkpoint look-ups: two 64-byte lines each) of the last gbx_fmi_smem_device call on this workspace. */
 int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream);
 /* gbx_fmi_smem_host keeps the device copy of an index between calls (keyed by the cp_occ address and the index scalars:

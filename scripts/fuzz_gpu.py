@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity run on the GPU: host entries of the five kernels against the oracle on random jobs of random
+"""Randomised parity run on the GPU: host entries of the six kernels against the oracle on random jobs of random
 sizes (small-job modes, class modes, staged and packed transfers all get hit).  usage: fuzz_gpu.py [seconds] [seed]"""
 import os
 import sys
@@ -14,7 +14,8 @@ from genomicsbench_amd import _native as N  # noqa: E402
 from genomicsbench_amd.bsw import extend_host, fill_scmat, make_params as bsw_params  # noqa: E402
 from genomicsbench_amd.chain import chain_host  # noqa: E402
 from genomicsbench_amd.abea import align_host  # noqa: E402
-from genomicsbench_amd.datagen import gen_abea, gen_bsw, gen_chain, gen_phmm, gen_poa  # noqa: E402
+from genomicsbench_amd.datagen import gen_abea, gen_bsw, gen_chain, gen_fmi_genome, gen_fmi_reads, gen_phmm, gen_poa  # noqa: E402
+from genomicsbench_amd.fmi import FmiReadSet, build_index, default_params as fmi_params, smem_host  # noqa: E402
 from genomicsbench_amd.phmm import forward_host  # noqa: E402
 from genomicsbench_amd.poa import consensus_host, make_params as poa_params  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
@@ -23,9 +24,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N.check(N.lib().gbx_host_prepare())
 t_end = time.time() + budget
-count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0}
+count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0, "fmi": 0}
+fmi_idx = {}                                                    # genome length -> (genome, index): built once per size
 while time.time() < t_end:
-    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea"])
+    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea", "fmi"])
     seed = int(rng.integers(1, 1 << 30))
     if k == "bsw":
         n = int(rng.choice([1, 7, 64, 513, 4000, 16384, 16385, 40000, 260000]))
@@ -39,10 +41,34 @@ while time.time() < t_end:
         what = "n=%d adversarial=%s kw=%s" % (n, adv, kw)
     elif k == "chain":
         nc = int(rng.choice([1, 3, 40, 300]))
-        case = gen_chain(nc, seed)
+        real = bool(rng.random() < 0.5)                          # minimap2's strand / reference structure: calls cut into jobs
+        case = gen_chain(nc, seed, realistic=real)
+        if rng.random() < 0.3:                                   # several segment ids inside the calls
+            case[2][:] |= (rng.integers(0, 2, len(case[2])).astype(np.uint64) << np.uint64(48))
+            case[3]["n_segs"] = 2
+            case[3]["max_dist_y"] = 800
         got, want = chain_host(*case), O.chain_oracle(*case, nthreads=8)
         ok = all(np.array_equal(g, w) for g, w in zip(got, want))
-        what = "calls=%d" % nc
+        what = "calls=%d realistic=%s n_segs=%d" % (nc, real, int(case[3]["n_segs"][0]))
+    elif k == "fmi":
+        glen = int(rng.choice([3000, 200000, 3000000]))
+        if glen not in fmi_idx:
+            g = gen_fmi_genome(glen, 4242 + glen)
+            fmi_idx[glen] = (g, build_index(g))
+        g, idx = fmi_idx[glen]
+        nr = int(rng.choice([1, 17, 500, 6000]))
+        rl = int(rng.choice([30, 76, 151, 250, 400]))
+        rs = gen_fmi_reads(g, nr, seed, read_len=min(rl, glen // 4))
+        if rng.random() < 0.3:                                   # ragged lengths
+            keep = rng.integers(1, rs.read_len[0] + 1, nr).astype(np.int32)
+            rs = FmiReadSet(rs.enc, rs.read_off, keep)
+        P = fmi_params(int(rng.choice([8, 12, 19, 25])))
+        if rng.random() < 0.3:
+            P.split_width, P.max_mem_intv = int(rng.integers(1, 30)), int(rng.integers(0, 60))
+        os.environ["GBX_FMI_WIDE"] = "1" if rng.random() < 0.3 else "0"     # the 64-bit instance too
+        (go, goff), (wo, woff) = smem_host(idx, rs, P, out_cap=max(64, 200 * nr)), O.fmi_oracle(idx, rs, P, nthreads=8)
+        ok = np.array_equal(goff, woff) and all(np.array_equal(go[f], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+        what = "genome=%d reads=%d len=%d minseed=%d wide=%s" % (glen, nr, rl, P.min_seed_len, os.environ["GBX_FMI_WIDE"])
     elif k == "phmm":
         nb = int(rng.choice([1, 2, 9, 40, 90]))
         bs = gen_phmm(nb, seed)

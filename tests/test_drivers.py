@@ -36,8 +36,9 @@ def run(args):
 
 
 def test_drivers_exist_and_print_usage():
-    for name in ("bsw", "chain", "phmm", "poa"):
+    for name in ("bsw", "chain", "phmm", "poa", "fmi"):
         assert os.path.exists(os.path.join(BIN, name)), "driver %s not built" % name
+    assert "Need five arguments : ref_file query_set batch_size minSeedLen n_threads" in run([os.path.join(BIN, "fmi")]).stderr
     assert "usage: bsw -pairs" in run([os.path.join(BIN, "bsw")]).stderr
     assert run([os.path.join(BIN, "chain")]).returncode != 0
 
@@ -206,3 +207,54 @@ def test_config0_reference_cpu_driver_plumbing(tmp_path):
     assert r.returncode == 1                                  # by design, main_banded.cpp:352
     assert "Number of input pairs: 2000" in r.stdout and "Total Pairs processed: 2000" in r.stdout
     assert "Overall SW cycles" in r.stdout
+
+
+# ---- fmi: the reference CLI  fmi <ref_file> <query_set> <batch_size> <minSeedLen> <n_threads>  (fmi.cpp:54-58)
+@pytest.fixture(scope="module")
+def fmi_data(tmp_path_factory):
+    from genomicsbench_amd import fmi as FM
+    from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+    d = tmp_path_factory.mktemp("fmi")
+    g = gen_fmi_genome(60000, 6001)
+    idx = FM.build_index(g)
+    FM.save_index(idx, str(d / "genome.gbxfmi"))
+    rs = gen_fmi_reads(g, 500, 6002)
+    ragged = FM.FmiReadSet(rs.enc, rs.read_off, np.maximum(1, rs.read_len - (np.arange(500) % 7).astype(np.int32) * 9))
+    FM.write_reads(str(d / "reads.fastq"), ragged, fastq=True)
+    FM.write_reads(str(d / "reads.fasta"), ragged, fastq=False, wrap=60)
+    return d, idx, ragged
+
+
+def test_fmi_index_file_roundtrip_and_parallel_ingest(fmi_data):
+    """save_index / load_index keep every table; FASTQ and wrapped FASTA give the same encoded reads for 1 and 4 ingest
+    threads, equal to the bytes the Python side holds (reads padded to the longest with 4s, fmi.cpp:97-127)."""
+    from genomicsbench_amd import fmi as FM
+    d, idx, rs = fmi_data
+    back = FM.load_index(str(d / "genome.gbxfmi"))
+    assert back.ref_seq_len == idx.ref_seq_len and back.count == idx.count and back.sentinel_index == idx.sentinel_index
+    assert np.array_equal(back.cp_occ.view(np.uint8), idx.cp_occ.view(np.uint8))
+    L = rs.max_len
+    enc = np.full((rs.n_reads, L), 4, dtype=np.uint8)
+    for r in range(rs.n_reads):
+        a = int(rs.read_off[r])
+        enc[r, :rs.read_len[r]] = rs.enc[a:a + rs.read_len[r]]
+    want = "%016x" % _fnv1a([rs.read_len.astype("<i4").tobytes(), enc.tobytes()])
+    for name in ("reads.fastq", "reads.fasta"):
+        for t in ("1", "4"):
+            r = run([os.path.join(BIN, "fmi"), str(d / "genome.gbxfmi"), str(d / name), "512", "19", t, "--parse-only"])
+            assert r.returncode == 0, r.stderr
+            got = json.loads(r.stdout.strip().splitlines()[-1])
+            assert got["reads"] == rs.n_reads and got["max_readlength"] == L and got["fnv1a"] == want, (name, t)
+
+
+@pytest.mark.gpu
+def test_fmi_driver_prints_the_oracles_smems(fmi_data):
+    from genomicsbench_amd import fmi as FM
+    d, idx, rs = fmi_data
+    r = run([os.path.join(BIN, "fmi"), str(d / "genome.gbxfmi"), str(d / "reads.fastq"), "512", "19", "2", "--print"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    want, _ = O.fmi_oracle(idx, rs, FM.default_params(19))
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("totalSmems"))
+    assert lines[k] == "totalSmems = %d" % len(want)
+    assert lines[k + 1:] == FM.smems_text(want)

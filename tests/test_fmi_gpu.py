@@ -126,6 +126,34 @@ def test_device_entry_rerun_and_extension_count(small):
         assert d.extensions() == want[2]
 
 
+def test_reads_with_more_smems_than_a_slot_holds_run_again_with_larger_slots(small, monkeypatch):
+    """A read's SMEMs wait for the pack pass in a fixed-size slot (48 records for 151-bp reads at minSeedLen 19; the bench's
+    reads use 18 at most).  With slots of 6 records most reads overflow: the host entry must notice and run the job again
+    with slots of the size the worst read asked for."""
+    g, idx = small
+    rs = gen_fmi_reads(g, 1500, 6005)
+    P = default_params(19)
+    want = O.fmi_oracle(idx, rs, P, nthreads=8)
+    assert np.diff(want[1]).max() > 6
+    monkeypatch.setenv("GBX_FMI_RAW_CAP", "6")
+    assert_same(smem_host(idx, rs, P), want)
+
+
+def test_unmappable_long_reads_with_short_seeds_need_more_than_one_resize(monkeypatch):
+    """Found by scripts/fuzz_gpu.py: 400-base reads at minSeedLen 8 - a random (unmappable) read yields 286 SMEMs, more than
+    its default slot of 216; the count the overflowing pass reports is only a lower bound (its re-seeding round sees the
+    kept records only), so one resize to that count is not enough."""
+    g = gen_fmi_genome(200_000, 4242 + 200_000)
+    idx = build_index(g)
+    rs = gen_fmi_reads(g, 500, 803022771, read_len=400)
+    P = default_params(8)
+    want = O.fmi_oracle(idx, rs, P, nthreads=8)
+    assert np.diff(want[1]).max() > 216
+    assert_same(smem_host(idx, rs, P, out_cap=200 * 500), want)
+    monkeypatch.setenv("GBX_FMI_RAW_CAP", "40")
+    assert_same(smem_host(idx, rs, P, out_cap=200 * 500), want)
+
+
 def test_output_capacity_too_small_is_reported(small):
     g, idx = small
     rs = gen_fmi_reads(g, 200, 6004)

@@ -7,6 +7,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from genomicsbench_amd import io as gio
@@ -60,6 +61,22 @@ def test_driver_ingest_under_asan_ubsan(san_build, tmp_path):
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             sums.add(json.loads(line)["checksum"])
         assert len(sums) == 1, (k, sums)
+    # fmi: positional CLI (ref_file query_set batch_size minSeedLen n_threads), FASTQ and wrapped FASTA
+    from genomicsbench_amd import fmi as FM
+    from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+    g = gen_fmi_genome(20000, 9)
+    rs = gen_fmi_reads(g, 300, 10)
+    rs = FM.FmiReadSet(rs.enc, rs.read_off, np.maximum(1, rs.read_len - (np.arange(300) % 5).astype(np.int32) * 11))
+    FM.write_reads(str(tmp_path / "r.fastq"), rs, fastq=True)
+    FM.write_reads(str(tmp_path / "r.fasta"), rs, fastq=False, wrap=70)
+    sums = set()
+    for exe_dir, t, name in (("bin-san", "1", "r.fastq"), ("bin-san", "3", "r.fasta"), ("bin", "3", "r.fastq")):
+        exe = os.path.join(ROOT, "genomicsbench_amd", exe_dir, "fmi")
+        r = subprocess.run([exe, "unused", str(tmp_path / name), "512", "19", t, "--parse-only"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        _clean(r)
+        sums.add(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["fnv1a"])
+    assert len(sums) == 1, ("fmi", sums)
 
 
 def test_host_pipeline_under_thread_sanitizer(san_build):
