@@ -206,6 +206,67 @@ struct DevBuf {
     }
 };
 
+// A few helper threads that live as long as one staged call and copy pieces of the pinned download slab to the caller's
+// memory (one core moves about 10 GB/s, the DMA five times that).  They used to be created per delivered piece: five
+// thread creations for 8 MB, i.e. about as long as the piece's DMA.  run() hands a list of copy jobs to the helpers and
+// the calling thread and returns when all are done; only the downloader thread calls it.
+struct CopyPool {
+    struct Job { char *dst; const char *src; size_t n; };
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::vector<Job> *jobs = nullptr;
+    size_t next = 0, pending = 0;
+    uint64_t round = 0;
+    bool stop = false;
+    void start(int helpers)
+    {
+        for (int t = 0; t < helpers; ++t) th.emplace_back([this] { loop(); });
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || (round != seen && jobs && next < jobs->size()); });
+            if (stop) return;
+            seen = round;
+            work(lk);
+        }
+    }
+    // takes jobs until the list is empty; lk is held on entry and on exit
+    void work(std::unique_lock<std::mutex> &lk)
+    {
+        while (jobs && next < jobs->size()) {
+            const Job j = (*jobs)[next++];
+            lk.unlock();
+            memcpy(j.dst, j.src, j.n);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+    void run(const std::vector<Job> &list)
+    {
+        if (list.empty()) return;
+        if (th.empty()) { for (const Job &j : list) memcpy(j.dst, j.src, j.n); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        jobs = &list; next = 0; pending = list.size(); ++round;
+        cv.notify_all();
+        work(lk);
+        done_cv.wait(lk, [&] { return pending == 0; });
+        jobs = nullptr;
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : th) t.join();
+        th.clear();
+        stop = false;
+    }
+    ~CopyPool() { shutdown(); }
+};
+
 // One *_host call's transfers.  Usage:
 //   HostPipe P(lane, total_upload_bytes);  P.prepare(n_chunks);
 //   P.stage(c, dst, src, bytes) ... for every chunk c in order;  P.start();
@@ -235,6 +296,7 @@ struct HostPipe {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::thread> threads;
+    CopyPool pool;                         // the downloader's copy helpers (staged calls)
     bool started = false;
 
     static size_t stage_min()
@@ -353,51 +415,29 @@ struct HostPipe {
     // slab -> caller memory; large pieces with a few threads (one core moves about 10 GB/s, the DMA five times that)
     void copy_out(char *dst, const char *src, size_t len)
     {
-        const int T = workers < 6 ? workers : 6;
+        const int T = (int)pool.th.size() + 1;
         if (len < ((size_t)2 << 20) || T <= 1) { memcpy(dst, src, len); return; }
         const size_t per = (len / (size_t)T + 63) & ~(size_t)63;
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) {
-            const size_t a = per * (size_t)t;
-            if (a >= len) break;
-            const size_t n = t == T - 1 || a + per > len ? len - a : per;
-            th.emplace_back([=] { memcpy(dst + a, src + a, n); });
-        }
-        memcpy(dst, src, per < len ? per : len);
-        for (auto &x : th) x.join();
+        std::vector<CopyPool::Job> jobs;
+        for (size_t a = 0; a < len; a += per) jobs.push_back(CopyPool::Job{dst + a, src + a, a + per > len ? len - a : per});
+        pool.run(jobs);
     }
     // slab bytes [0, len) = bytes [pos, pos + len) of a packed stream -> the segments they belong to (cursor: first segment
     // not yet complete and the bytes of it already delivered)
     void copy_out_scatter(const char *slab, size_t len, const std::vector<Seg> &segs, size_t &si, size_t &so)
     {
-        struct Job { char *dst; const char *src; size_t n; };
-        std::vector<Job> jobs;
+        // jobs of at most 256 KB, so that a few long segments do not serialise the copy (the helpers take jobs one by one)
+        std::vector<CopyPool::Job> jobs;
         size_t off = 0;
         while (off < len && si < segs.size()) {
             const size_t n = segs[si].len - so < len - off ? segs[si].len - so : len - off;
-            if (n) jobs.push_back(Job{segs[si].dst + so, slab + off, n});
+            for (size_t d = 0; d < n; d += (size_t)256 << 10)
+                jobs.push_back(CopyPool::Job{segs[si].dst + so + d, slab + off + d, n - d < ((size_t)256 << 10) ? n - d : (size_t)256 << 10});
             off += n; so += n;
             if (so == segs[si].len) { ++si; so = 0; }
         }
-        const int T = workers < 6 ? workers : 6;
-        if (len < ((size_t)2 << 20) || T <= 1) { for (const Job &j : jobs) memcpy(j.dst, j.src, j.n); return; }
-        // shares of equal BYTES (a few long reads in one thread's share would serialise the copy): cut[t] = first job of share t
-        std::vector<std::thread> th;
-        std::vector<size_t> cut((size_t)T + 1, jobs.size());
-        cut[0] = 0;
-        size_t acc = 0;
-        int t_next = 1;
-        for (size_t k = 0; k < jobs.size() && t_next < T; ++k) {
-            if (acc >= len * (size_t)t_next / (size_t)T) cut[(size_t)t_next++] = k;
-            acc += jobs[k].n;
-        }
-        for (int t = 1; t < T; ++t) {
-            const size_t a = cut[(size_t)t], b = cut[(size_t)t + 1];
-            if (a >= b) continue;
-            th.emplace_back([&jobs, a, b] { for (size_t k = a; k < b; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n); });
-        }
-        for (size_t k = 0; k < cut[1]; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].n);
-        for (auto &x : th) x.join();
+        if (len < ((size_t)2 << 20)) { for (const CopyPool::Job &j : jobs) memcpy(j.dst, j.src, j.n); return; }
+        pool.run(jobs);
     }
     hipError_t fetch_chunk(int64_t c)
     {
@@ -482,6 +522,7 @@ struct HostPipe {
         started = true;
         if (!staged) return;
         for (int w = 0; w < workers; ++w) threads.emplace_back([this, w] { upload_worker(w); });
+        pool.start((workers < 6 ? workers : 6) - 1);
         threads.emplace_back([this] { download_worker(); });
     }
     // returns when every upload of chunk c is queued on the copy stream, and makes the compute stream wait for them
@@ -563,6 +604,7 @@ struct HostPipe {
         if (rc_in) cancel();
         for (auto &t : threads) t.join();
         threads.clear();
+        pool.shutdown();
         int rc = rc_in;
         if (!rc && hip_err.load()) rc = hip_fail((hipError_t)hip_err.load(), "host pipeline");
         if (!rc && !staged) {

@@ -201,6 +201,14 @@ int main(int argc, char **argv)
         CHECK(rc != GBX_OK, "a failing hipMemcpyAsync (the %d-th) must fail the call", k);
         CHECK(call_one_chunk((size_t)1 << 20, 199 + (uint64_t)k, true) == GBX_OK, "call after a failed one: %s", g_err);
     }
+    // (c) downloads in full-size pieces (8 MB halves of the pinned slab): the downloader's copy helpers (CopyPool) at work,
+    //     from two callers at once
+    unsetenv("GBX_HOST_DOWN_PIECE");
+    {
+        std::thread a([] { CHECK(call_one_chunk((size_t)20 << 20, 4001, true) == GBX_OK, "large one-chunk call: %s", g_err); });
+        std::thread b([] { CHECK(call_field_and_scatter(3000000, 4002) == GBX_OK, "large field / scatter call: %s", g_err); });
+        a.join(); b.join();
+    }
     if (g_fail.load()) { fprintf(stderr, "pipe_tsan: %d check(s) failed\n", g_fail.load()); return 1; }
     printf("pipe_tsan: ok (%d caller threads x %d rounds)\n", threads, rounds);
     return 0;
