@@ -83,7 +83,7 @@ template <class IV> __device__ inline IV pick4(int a, IV v0, IV v1, IV v2, IV v3
 
 enum : int { ST_FWD = 0, ST_BWD = 1, ST_SEED = 2 };
 // transitions between two extensions (T_EXT: the read needs one now; T_IDLE: no reads left for this quad)
-enum : int { T_EXT, T_IDLE, T_NEXT_READ, T_ONEPOS_INIT, T_FWD_END, T_BWD_JEND, T_BWD_END, T_ONEPOS_DONE, T_P2_NEXT, T_SEED_INIT, T_READ_DONE };
+enum : int { T_EXT, T_IDLE, T_FWD_END, T_BWD_JEND, T_BWD_END, T_ONEPOS_DONE, /* the rare ones: */ T_NEXT_READ, T_ONEPOS_INIT, T_P2_NEXT, T_SEED_INIT, T_READ_DONE };
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
@@ -214,8 +214,36 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
     for (;;) {
         // ---- bookkeeping until this read needs an extension (or there is nothing left to do)
         if (__ballot(t != T_EXT) != 0) {
-            while (t != T_EXT && t != T_IDLE) {
-                switch (t) {
+            // the three transitions of the backward sweep come up in three trips out of four (some quad of the sixteen is
+            // at one), the others a few times per read: the frequent ones are tested directly, the rest behind one test
+            do {
+                if (t == T_BWD_JEND) {
+                    num_prev = num_curr;
+                    if (num_curr == 0) t = T_ONEPOS_DONE;
+                    else { m_cur = j; --j; bwd_enter(); }
+                } else if (t == T_FWD_END) {
+                    if (s >= (IV)min_intv) {
+                        store_prev_arr(num_prev, k, l, s, n); ++num_prev;          // ... and (k, l, s, n) is entry 0 of the backward view
+                    } else if (num_prev > 0) {                                      // (a seed interval below min_intv: the last record pushed)
+                        take_prev(prev_load(num_prev - 1));
+                        k = pk; l = pl; s = ps; n = pn;
+                    }
+                    vbase = num_prev - 1; j = x - 1; m_cur = x;
+                    bwd_enter();
+                }
+                if (t == T_BWD_END) {
+                    if (num_prev != 0 && n - m_cur + 1 >= A.min_seed_len) emit(m_cur, n, k, l, s);      // view[0]
+                    t = T_ONEPOS_DONE;
+                }
+                if (t == T_ONEPOS_DONE) {
+                    if (phase == 0) {
+                        x = next_x;                                   // getSMEMsAllPosOneThread: on to the next start position
+                        if (x < len) onepos_init();
+                        else { n1 = n_out < RAW_CAP ? n_out : RAW_CAP; idx2 = 0; phase = 1; t = T_P2_NEXT; }
+                    } else t = T_P2_NEXT;
+                }
+                if (__ballot(t >= T_NEXT_READ) != 0) {
+                    switch (t) {
                 case T_NEXT_READ: {
                     unsigned long long r = 0;
                     if (b == 0) r = atomicAdd(&A.counters[0], 1ull);
@@ -252,34 +280,6 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                 case T_ONEPOS_INIT:
                     onepos_init();
                     break;
-                case T_FWD_END:
-                    if (s >= (IV)min_intv) {
-                        store_prev_arr(num_prev, k, l, s, n); ++num_prev;          // ... and (k, l, s, n) is entry 0 of the backward view
-                    } else if (num_prev > 0) {                                      // (a seed interval below min_intv: the last record pushed)
-                        take_prev(prev_load(num_prev - 1));
-                        k = pk; l = pl; s = ps; n = pn;
-                    }
-                    vbase = num_prev - 1; j = x - 1; m_cur = x;
-                    bwd_enter();
-                    break;
-                case T_BWD_JEND:
-                    num_prev = num_curr;
-                    if (num_curr == 0) { t = T_ONEPOS_DONE; break; }
-                    m_cur = j; --j;
-                    bwd_enter();
-                    break;
-                case T_BWD_END:
-                    if (num_prev != 0 && n - m_cur + 1 >= A.min_seed_len) emit(m_cur, n, k, l, s);      // view[0]
-                    t = T_ONEPOS_DONE;
-                    break;
-                case T_ONEPOS_DONE:
-                    if (phase == 0) {
-                        x = next_x;                                   // getSMEMsAllPosOneThread: on to the next start position
-                        if (x < len) { onepos_init(); break; }
-                        n1 = n_out < RAW_CAP ? n_out : RAW_CAP; idx2 = 0; phase = 1;
-                    }
-                    t = T_P2_NEXT;
-                    break;
                 case T_P2_NEXT: {                                     // fmi.cpp:230-254: re-seed from the middle of long, rare SMEMs
                     if (idx2 >= n1) { phase = 2; x = 0; seed_init(); break; }
                     const uint2 *e = raw_of() + (size_t)idx2 * 5;
@@ -303,8 +303,11 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                     }
                     t = T_NEXT_READ;
                     break;
+                default:
+                    break;
+                    }
                 }
-            }
+            } while (__ballot(t != T_EXT && t != T_IDLE) != 0);
             if (__ballot(t == T_EXT) == 0) break;
         }
 
