@@ -137,6 +137,18 @@ struct HostLane {
             for (size_t k = 0; k < v.size(); ++k)
                 if (v[k]->dev == dev) { l = v[k]; v.erase(v.begin() + (long)k); return GBX_OK; }
         }
+        // The runtime maps streams onto its four hardware queues in the order they are created, and streams that share a
+        // queue run in order.  The kernels of a call run on the lane's compute stream and the device's three side streams:
+        // the side streams are created first, then compute, so that in a process of its own those four get a queue each
+        // (the copy stream then shares one with a side stream, which the pipelined bsw path allows for by using three
+        // kernel streams).  A process that holds other streams of its own shifts the mapping: inside bench.py (torch's
+        // streams) phmm's four class kernels, 125-185 ms each, lose their overlap in the host entry (283 ms against 217
+        // standalone) - a property of the calling process, not of this pipeline.
+        {
+            SideStreams *ss = nullptr;
+            const int rc = side_streams(&ss);
+            if (rc) return rc;
+        }
         Lane *n = new Lane();
         n->dev = dev;
         hipError_t e = hipStreamCreateWithFlags(&n->compute, hipStreamNonBlocking);
