@@ -8,6 +8,11 @@ bsw_<name>.pairs.txt.gz   input, reference format (main_banded.cpp:131-141)
 bsw_<name>.golden.txt.gz  per pair: 6 outputs of scalarBandedSWA, then 6 of getScores16 (AVX2, -b 512)
 chain_<name>.in.gz        input, reference format (host_data_io.cpp:13-51)
 chain_<name>.golden.txt.gz  per anchor: score parent target peak (return_t vectors of host_chain_kernel)
+fmi_small.genome.txt.gz     one line of ACGT: the genome the index is built from (both strands, as bwa-mem2 does)
+fmi_small.reads.fastq.gz    the reads (FASTQ, as the reference driver takes them, fmi.cpp:62-70)
+fmi_small.smems.txt.gz      the SMEMs in the reference's PRINT_OUTPUT format (fmi.cpp:312-343), k l s appended to every record.
+                            NOT from the reference (tools/bwa-mem2 is an empty submodule): written by oracle/fmi_oracle.c and frozen
+                            here as a regression fixture; tests/test_fmi_cpu.py checks the same records against brute force
 """
 import gzip
 import os
@@ -52,6 +57,34 @@ def chain_fixture(name, off, ax, ay, hdr):
     print(name, len(off) - 1, "calls", len(s), "anchors")
 
 
+def fmi_fixture():
+    from genomicsbench_amd import fmi as FM
+    from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+    g = gen_fmi_genome(4000, 123)
+    g[1000:1300] = g[200:500]                                   # a repeat with two diverged copies: SMEMs with several hits
+    g[2500:2800] = 3 - g[200:500][::-1]
+    g[1100] = (g[1100] + 1) % 4
+    rs = gen_fmi_reads(g, 60, 124, read_len=101)
+    rs = FM.FmiReadSet(rs.enc, rs.read_off, np.maximum(20, rs.read_len - (np.arange(60) % 4).astype(np.int32) * 13))
+    with gzip.open(os.path.join(HERE, "fmi_small.genome.txt.gz"), "wt") as f:
+        f.write("".join("ACGT"[b] for b in g) + "\n")
+    FM.write_reads(os.path.join(HERE, "fmi_small.reads.fastq"), rs, fastq=True)
+    with open(os.path.join(HERE, "fmi_small.reads.fastq"), "rb") as fi, gzip.open(os.path.join(HERE, "fmi_small.reads.fastq.gz"), "wb") as fo:
+        fo.write(fi.read())
+    os.remove(os.path.join(HERE, "fmi_small.reads.fastq"))
+    out, off = O.fmi_oracle(FM.build_index(g), rs, FM.default_params(19))
+    with gzip.open(os.path.join(HERE, "fmi_small.smems.txt.gz"), "wt") as f:
+        prev = -1
+        for s_ in out:
+            rid = int(s_["rid"])
+            if rid != prev:
+                for j in range(prev + 1, rid + 1):
+                    f.write("%d:\n" % j)
+            prev = rid
+            f.write("[%d,%d] %d %d %d\n" % (s_["m"], s_["n"] + 1, s_["k"], s_["l"], s_["s"]))
+    print("fmi_small", rs.n_reads, "reads", len(out), "SMEMs")
+
+
 if __name__ == "__main__":
     assert O.ref_lib("bsw") is not None and O.ref_lib("chain") is not None, "run oracle/build_ref.sh first"
     only = sys.argv[1:]                       # e.g. `make_golden.py chain_cuts chain_realistic`: just these fixtures
@@ -62,3 +95,5 @@ if __name__ == "__main__":
     for name, case in chain_cases().items():
         if not only or "chain_" + name in only:
             chain_fixture(name, *case)
+    if not only or "fmi_small" in only:
+        fmi_fixture()

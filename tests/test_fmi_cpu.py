@@ -52,11 +52,22 @@ def test_suffix_array_and_index_tables(n, seed):
     assert idx.count[0] == 1 and idx.count[4] == 2 * n + 1
 
 
+_SUFFIXES = {}
+
+
 def sa_range(text, sa, pat):
-    """rows of the suffix array whose suffix starts with pat (brute force) -> (first row, count)"""
-    n = len(text)
-    rows = [i for i in range(n + 1) if sa[i] + len(pat) <= n and np.array_equal(text[sa[i]:sa[i] + len(pat)], pat)]
-    return (rows[0], len(rows)) if rows else (None, 0)
+    """rows of the suffix array whose suffix starts with pat (brute force: bisection over the sorted list of all suffixes
+    as byte strings, symbols + 1, the sentinel = 0) -> (first row, count)"""
+    import bisect
+    key = (len(text), text[:64].tobytes(), text[-64:].tobytes())
+    if key not in _SUFFIXES:
+        t = bytes(int(c) + 1 for c in text) + b"\x00"
+        _SUFFIXES.clear()
+        _SUFFIXES[key] = [t[i:] for i in sa]
+    suf = _SUFFIXES[key]
+    p = bytes(int(c) + 1 for c in pat)
+    lo, hi = bisect.bisect_left(suf, p), bisect.bisect_left(suf, p + b"\xff")
+    return (lo, hi - lo) if hi > lo else (None, 0)
 
 
 def test_every_interval_is_the_suffix_array_range_of_its_match():
@@ -89,11 +100,9 @@ def test_every_interval_is_the_suffix_array_range_of_its_match():
 
 
 def occurs(text_set_cache, text, pat):
-    key = pat.tobytes()
-    if key not in text_set_cache:
-        n, L = len(text), len(pat)
-        text_set_cache[key] = any(np.array_equal(text[i:i + L], pat) for i in range(n - L + 1))
-    return text_set_cache[key]
+    if "text" not in text_set_cache:
+        text_set_cache["text"] = text.tobytes()
+    return pat.tobytes() in text_set_cache["text"]
 
 
 def brute_smems(text, q, min_len):
@@ -166,3 +175,28 @@ def test_reads_without_any_valid_base_and_short_reads():
     rs = FmiReadSet(enc, np.array([0, 30, 32, 72]), np.array([30, 2, 40, 1]))
     out, off = O.fmi_oracle(idx, rs, default_params(19))
     assert list(np.diff(off)[:2]) == [0, 0] and off[3] - off[2] >= 1 and off[4] == off[3]
+
+
+def test_frozen_fixture_equals_the_oracle_and_brute_force():
+    """tests/golden/fmi_small.* (written by the oracle, frozen): the oracle still produces it, and every record in it is
+    right by brute force - (k, s) and (l, s) are the suffix-array ranges of the match and of its reverse complement, no
+    record can be extended to either side, and the round-1 SMEMs of every read are among them."""
+    from util import load_fmi_golden
+    g, rs, want = load_fmi_golden()
+    idx = build_index(g)
+    out, off = O.fmi_oracle(idx, rs, default_params(19))
+    got = np.stack([out[f].astype(np.int64) for f in ("rid", "m", "n", "k", "l", "s")], 1)
+    assert np.array_equal(got, want)
+    text = text_of(g)
+    sa = brute_sa(text)
+    cache = {}
+    for rid, m, n, k, l, s in want[::3]:
+        a = int(rs.read_off[rid])
+        q = rs.enc[a:a + int(rs.read_len[rid])]
+        pat = q[m:n + 1]
+        assert sa_range(text, sa, pat) == (k, s) and sa_range(text, sa, (3 - pat[::-1]).astype(np.uint8)) == (l, s)
+    for r in range(0, rs.n_reads, 5):
+        a = int(rs.read_off[r])
+        q = rs.enc[a:a + int(rs.read_len[r])]
+        mine = set((int(x[1]), int(x[2])) for x in want[want[:, 0] == r])
+        assert set(brute_smems(text, q, 19)) <= mine, "read %d" % r

@@ -28,6 +28,21 @@ def small():
     return g, build_index(g)
 
 
+def test_frozen_fixture():
+    """tests/golden/fmi_small.*: ragged reads against a genome with a three-copy repeat (one copy reversed)."""
+    from util import load_fmi_golden
+    g, rs, want = load_fmi_golden()
+    for wide in ("0", "1"):
+        import os
+        os.environ["GBX_FMI_WIDE"] = wide
+        try:
+            out, off = smem_host(build_index(g), rs, default_params(19))
+        finally:
+            del os.environ["GBX_FMI_WIDE"]
+        got = np.stack([out[f].astype(np.int64) for f in FIELDS], 1)
+        assert np.array_equal(got, want), "instance wide=%s" % wide
+
+
 def test_reads_of_the_bench_generator(small):
     g, idx = small
     rs = gen_fmi_reads(g, 3000, 6002)
