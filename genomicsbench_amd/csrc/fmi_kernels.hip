@@ -359,26 +359,26 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                 if (p < num_prev) take_prev(nxt);                                 // stays T_EXT / ST_BWD
                 else t = T_BWD_JEND;
             } else {
-                bool more;
-                if (state == ST_FWD) {
-                    const IV ns = rs;
-                    if (ns != s) { store_prev_arr(num_prev, k, l, s, n); ++num_prev; }
-                    more = ns >= (IV)min_intv;
-                    if (more) { k = rl; l = rk; s = ns; n = j; ++j; }
-                    else { next_x = j; t = T_FWD_END; }
-                } else {
-                    k = rl; l = rk; s = rs; n = j;
-                    more = !(s < (IV)A.max_intv && n - x + 1 >= A.min_seed_len + 1);
-                    if (more) ++j;
+                // a forward step of round 1 / 2 (ST_FWD) or of the LAST round (ST_SEED): one code path, the rounds differ in
+                // when they stop and in what they do then
+                const bool fwd = state == ST_FWD;
+                const IV ns = rs;
+                if (fwd && ns != s) { store_prev_arr(num_prev, k, l, s, n); ++num_prev; }
+                const bool stop = fwd ? ns < (IV)min_intv : (ns < (IV)A.max_intv && j - x + 1 >= A.min_seed_len + 1);
+                if (!(fwd && stop)) { k = rl; l = rk; s = ns; n = j; }             // round 1 keeps the match it could not extend
+                if (stop) {
+                    if (fwd) { next_x = j; t = T_FWD_END; }
                     else {
                         if (s > 0) emit(x, n, k, l, s);
                         x = next_x;
                         t = T_SEED_INIT;
                     }
-                }
-                if (more && !fwd_next()) {                                        // end of the read or an ambiguous base
-                    if (state == ST_FWD) t = T_FWD_END;
-                    else { x = next_x; t = T_SEED_INIT; }
+                } else {
+                    ++j;
+                    if (!fwd_next()) {                                           // end of the read or an ambiguous base
+                        if (fwd) t = T_FWD_END;
+                        else { x = next_x; t = T_SEED_INIT; }
+                    }
                 }
             }
         }
