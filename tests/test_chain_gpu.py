@@ -66,6 +66,32 @@ def test_realistic_calls_are_cut_into_jobs_and_equal_the_oracle():
     assert d.evaluated_pairs() == int(want[4])
 
 
+def test_extreme_cut_structures():
+    """Every anchor isolated (a cut at every anchor: only one per 64 is taken, the job list stays bounded), one long run
+    followed by thousands of isolated anchors, cuts exactly at the 64-anchor block boundaries, 3 000 one-anchor calls, and
+    an unsorted call between sorted ones (never cut)."""
+    rng = np.random.default_rng(17)
+    span = (np.uint64(15) << np.uint64(32))
+
+    def call(x, q):
+        return (np.asarray(x, dtype=np.uint64), span | np.asarray(q, dtype=np.uint64), (np.float32(15.0), 5000, 5000, 500, 1))
+    iso = call(1000 + np.arange(5000, dtype=np.uint64) * np.uint64(6000), 100 + np.arange(5000) * 7)
+    run = np.cumsum(rng.integers(1, 40, 3000)).astype(np.uint64) + np.uint64(1000)
+    tail = run[-1] + np.uint64(7000) + np.arange(4000, dtype=np.uint64) * np.uint64(5001)
+    mixed = call(np.concatenate([run, tail]), np.concatenate([100 + np.cumsum(rng.integers(1, 40, 3000)), 500 + np.arange(4000) * 3]))
+    blocks = []
+    for b in range(40):                                      # 40 runs of exactly 64 anchors, 9 000 apart
+        blocks.append(np.uint64(1000 + b * 9000) + np.sort(rng.integers(0, 2000, 64)).astype(np.uint64))
+    aligned = call(np.concatenate(blocks), 100 + np.arange(64 * 40) * 5)
+    ux = np.cumsum(rng.integers(1, 40, 500)).astype(np.uint64) + np.uint64(1000)
+    ux[[100, 300]] = ux[[300, 100]]                          # not sorted: one job, the kernel walks st itself
+    unsorted = call(ux, 100 + np.arange(500) * 11)
+    singles = [call([1000 + 13 * k], [200]) for k in range(3000)]
+    case = chain_pack([iso, mixed, unsorted, aligned] + singles + [iso])
+    want = O.chain_oracle(*case, nthreads=8)
+    assert_same(chain_host(*case), want)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_case_families_vs_oracle(seed):
     for case in chain_cases(seed=seed).values():
