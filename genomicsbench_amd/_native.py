@@ -129,6 +129,7 @@ def _declare(L):
         L.gbx_fmi_smem_host.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, C.POINTER(C.c_int64)]
         L.gbx_fmi_smem_device.argtypes = [vp, vp, vp, i64, C.c_int32, vp, vp, vp, vp, i64, vp, vp, vp, sz, vp]
         L.gbx_fmi_extensions.argtypes = [vp, C.POINTER(C.c_int64), vp]
+        L.gbx_fmi_overflow.argtypes = [vp, C.POINTER(C.c_int64), vp]
     if hasattr(L, "gbx_chain_host"):
         L.gbx_chain_job_stats.argtypes = [vp, i64, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
         L.gbx_chain_workspace_bytes.argtypes = [i64, i64]

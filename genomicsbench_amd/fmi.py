@@ -281,10 +281,18 @@ class DeviceFmi:
                                             self.out.data_ptr(), self.out_cap, self.smem_off.data_ptr(), self.n_out.data_ptr(),
                                             self.work.data_ptr(), self.work_bytes, stream))
 
+    def overflow(self, stream=None):
+        """0, or a lower bound of the SMEM count of a read that asked for more than its slot holds (gbx_fmi_overflow)."""
+        v = C.c_int64(0)
+        N.check(N.lib().gbx_fmi_overflow(self.work.data_ptr(), C.byref(v), stream))
+        return v.value
+
     def results(self):
         n = int(self.n_out.item())
         if n > self.out_cap:
             raise RuntimeError("fmi: %d SMEMs do not fit the output capacity %d" % (n, self.out_cap))
+        if self.overflow():
+            raise RuntimeError("fmi: a read produced more SMEMs than its slot holds (gbx_fmi_overflow): use the host entry, which resizes")
         raw = self.out[:n * SMEM_DTYPE.itemsize].cpu().numpy()
         return raw.view(SMEM_DTYPE).copy(), self.smem_off.cpu().numpy()
 

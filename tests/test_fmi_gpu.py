@@ -169,6 +169,20 @@ def test_unmappable_long_reads_with_short_seeds_need_more_than_one_resize(monkey
     assert_same(smem_host(idx, rs, P, out_cap=200 * 500), want)
 
 
+def test_device_entry_reports_reads_that_do_not_fit_their_slot():
+    """The device entry cannot resize its caller's workspace: it flags the job (gbx_fmi_overflow) instead."""
+    import torch
+    g = gen_fmi_genome(200_000, 4242 + 200_000)
+    idx = build_index(g)
+    rs = gen_fmi_reads(g, 500, 803022771, read_len=400)        # one read of this set yields 286 SMEMs at minSeedLen 8: slots hold 216
+    d = DeviceFmi(idx, rs, torch.device("cuda:0"), default_params(8), out_cap=200 * 500)
+    d.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d.overflow() > 216
+    with pytest.raises(RuntimeError, match="slot"):
+        d.results()
+
+
 def test_output_capacity_too_small_is_reported(small):
     g, idx = small
     rs = gen_fmi_reads(g, 200, 6004)
