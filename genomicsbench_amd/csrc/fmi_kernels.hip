@@ -58,7 +58,8 @@ struct FmiArgs {
     uint2 *raw;                        // [chunk reads][raw_cap][5] 8-byte words: {rid, m} {n, 0} k l s
     int32_t *raw_count;                // [chunk reads]
     uint2 *prev;                       // [resident quads][max_len + 1][4 lanes] words of 4 or 8 bytes: k, l, s, n of a backward-sweep record
-    unsigned long long *counters;      // [0] read cursor, [1] extensions, [2] overflow flag, [3] running output total
+    unsigned long long *counters;      // [0] read cursor, [1] extensions, [2] overflow flag, [3] running output total, [4] total before
+                                       // this chunk, [5] longest read that exceeded max_read_len
 };
 
 __device__ inline long long u2ll(uint2 v) { return (long long)(((unsigned long long)v.y << 32) | v.x); }
@@ -253,6 +254,10 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                     len = A.read_len[A.read_base + r];
                     q = A.enc + A.read_off[A.read_base + r];
                     n_out = 0;
+                    if (len > A.max_len) {                            // the caller's max_read_len is too small: no SMEMs, flagged
+                        if (b == 0) atomicMax(&A.counters[5], (unsigned long long)len);
+                        len = 0;
+                    }
                     if (len <= 0) { t = T_READ_DONE; break; }
                     if (LDSQ) {
                         // eight bases per dword, the quad's lanes take turns; nothing is read behind the read (the last
@@ -597,10 +602,11 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
 
 int fmi_read_overflow(const void *d_work, int64_t *worst, hipStream_t s)
 {
-    unsigned long long v = 0;
-    GBX_HIP(hipMemcpyAsync(&v, (const char *)d_work + 16, sizeof(v), hipMemcpyDeviceToHost, s));
+    unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+    GBX_HIP(hipMemcpyAsync(v, d_work, sizeof(v), hipMemcpyDeviceToHost, s));
     GBX_HIP(hipStreamSynchronize(s));
-    *worst = (int64_t)v;
+    *worst = (int64_t)v[2];
+    if (v[5]) { set_error("fmi: a read of %llu bases exceeds max_read_len (it got no SMEMs)", v[5]); return GBX_ERR_ARG; }
     return GBX_OK;
 }
 

@@ -399,7 +399,7 @@ int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx
  * a lower bound of the largest count a read of the last gbx_fmi_smem_device call on this workspace asked for when that was
  * more (its surplus records, and what the re-seeding round would have made of them, are missing from the output then:
  * very repetitive text, long reads with short seeds).  The host entry runs such a job again with larger slots until
- * every read fits. */
+ * every read fits.  GBX_ERR_ARG when a read was longer than the max_read_len the call was given (such a read gets no SMEMs). */
 int gbx_fmi_overflow(const void *d_work, int64_t *worst, void *stream);
 /* backwardExt calls (checkpoint look-ups: two 64-byte lines each) of the last gbx_fmi_smem_device call on this workspace. */
 int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream);

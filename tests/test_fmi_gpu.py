@@ -183,6 +183,19 @@ def test_device_entry_reports_reads_that_do_not_fit_their_slot():
         d.results()
 
 
+def test_device_entry_flags_a_read_longer_than_max_read_len(small):
+    import torch
+    from genomicsbench_amd._native import GbxError
+    g, idx = small
+    rs = gen_fmi_reads(g, 64, 6006)
+    d = DeviceFmi(idx, rs, torch.device("cuda:0"))
+    d.max_len = 100                                           # the caller lies about its longest read (151)
+    d.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    with pytest.raises(GbxError, match="exceeds max_read_len"):
+        d.overflow()
+
+
 def test_output_capacity_too_small_is_reported(small):
     g, idx = small
     rs = gen_fmi_reads(g, 200, 6004)
