@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Writes seeded synthetic datasets in the reference's file formats and directory layout
-(<OUT>/{bsw,chain,phmm,poa}/{small,large}/..., R/scripts/run-cpu.sh:29-74), because the real
+(<OUT>/{bsw,chain,phmm,poa,fmi}/{small,large}/..., R/scripts/run-cpu.sh:26-74), because the real
 input-datasets tarball (R/README.md:18) cannot be downloaded here.
 
-usage: gen_inputs.py <OUT_DIR> <small|large|tiny> [kernels...]
+usage: gen_inputs.py <OUT_DIR> <small|large|tiny> [kernels...]       (fmi only when named: its index is built with torch)
+
+fmi: <OUT>/fmi/broad = the index tables (the reference loads a bwa-mem2 index by that prefix, run-cpu.sh:27; ours are
+written by genomicsbench_amd.fmi.save_index for a synthetic genome of 64 Mbp (small / large) or 1 Mbp (tiny)), and
+<OUT>/fmi/<size>/SRR7733443_{1m,10m}_1.fastq = 151-bp reads sampled from it.
 """
 import os
 import sys
@@ -32,6 +36,18 @@ def main():
     nb, nc, nph, npo = SIZES[size]
     sub = "small" if size == "tiny" else size
     seed_off = 0 if size == "large" else -1
+    if "fmi" in kernels:
+        kernels = [k for k in kernels if k != "fmi"]
+        from genomicsbench_amd import fmi as FM
+        from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
+        import torch
+        g = gen_fmi_genome((1 << 20) if size == "tiny" else (64 << 20), 6001)
+        os.makedirs(os.path.join(out, "fmi", sub), exist_ok=True)
+        FM.save_index(FM.build_index(g, device="cuda:0" if torch.cuda.is_available() else None), os.path.join(out, "fmi", "broad"))
+        n = {"tiny": 2_000, "small": 1_000_000, "large": 10_000_000}[size]
+        path = os.path.join(out, "fmi", sub, "SRR7733443_%s_1.fastq" % ("10m" if size == "large" else "1m"))
+        FM.write_reads(path, gen_fmi_reads(g, n, 6002 + seed_off), fastq=True)
+        print("wrote", path, "and", os.path.join(out, "fmi", "broad"), flush=True)
     for k in kernels:
         d = os.path.join(out, k, sub)
         os.makedirs(d, exist_ok=True)
