@@ -440,13 +440,17 @@ __global__ void __launch_bounds__(1024) fmi_scan2_kernel(long long *block_sum, i
     }
 }
 
-// one thread per read: its offset, then its records in (m ascending, n descending) order (sortSMEMs' compare_smem
-// within one rid; records equal in (m, n) are equal in every field)
+// A block takes SCAN_BLOCK reads: their offsets (one thread per read), then their records in (m ascending, n descending)
+// order (sortSMEMs' compare_smem within one rid; records equal in (m, n) are equal in every field) - eight lanes per
+// read, a lane per record: a record's rank is the number of records with a smaller key (ties by slot), found by passing
+// the keys round the eight lanes; the lane then copies its 40 bytes to its place.
 __global__ void __launch_bounds__(SCAN_BLOCK) fmi_pack_kernel(const int32_t *cnt, long long n, long long read_base, const long long *block_off,
                                                               const unsigned long long *counters, const uint2 *raw, int RAW_CAP,
                                                               gbx_fmi_smem *out, long long out_cap, int64_t *smem_off)
 {
     __shared__ long long sh[SCAN_BLOCK / 64];
+    __shared__ long long soff[SCAN_BLOCK];
+    __shared__ int scnt[SCAN_BLOCK];
     const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const int c = i < n ? cnt[i] : 0;
     // exclusive prefix inside the block
@@ -458,20 +462,41 @@ __global__ void __launch_bounds__(SCAN_BLOCK) fmi_pack_kernel(const int32_t *cnt
     long long before = 0;
     for (int w = 0; w < wv; ++w) before += sh[w];
     const long long off = (long long)counters[4] + block_off[blockIdx.x] + before + v - c;
-    if (i >= n) return;
-    smem_off[read_base + i] = off;
-    if (i == n - 1) smem_off[read_base + n] = off + c;
-    if (off + c > out_cap) return;
-    const uint2 *e = raw + (size_t)i * RAW_CAP * 5;
-    for (int a = 0; a < c; ++a) {
-        const unsigned ma = e[a * 5].y, na = e[a * 5 + 1].x;
-        int rank = 0;
-        for (int o = 0; o < c; ++o) {
-            const unsigned mo = e[o * 5].y, no = e[o * 5 + 1].x;
-            rank += (mo < ma) || (mo == ma && (no > na || (no == na && o < a)));
+    soff[threadIdx.x] = off; scnt[threadIdx.x] = c;
+    if (i < n) {
+        smem_off[read_base + i] = off;
+        if (i == n - 1) smem_off[read_base + n] = off + c;
+    }
+    __syncthreads();
+    const int l8 = threadIdx.x & 7, grp = threadIdx.x >> 3;                    // 128 groups of eight lanes
+    for (int r = grp; r < SCAN_BLOCK; r += SCAN_BLOCK / 8) {
+        const long long rd = (long long)blockIdx.x * SCAN_BLOCK + r;
+        const int cr = scnt[r];
+        const long long o0 = soff[r];
+        if (rd >= n || cr == 0 || o0 + cr > out_cap) continue;                  // (group-uniform)
+        const uint2 *e = raw + (size_t)rd * (size_t)RAW_CAP * 5;
+        for (int a0 = 0; a0 < cr; a0 += 8) {
+            const int a = a0 + l8;
+            const bool mine = a < cr;
+            // key: m ascending, then n descending (reads have fewer than 65 536 bases)
+            const unsigned ka = mine ? (e[a * 5].y << 16) | (0xffffu - e[a * 5 + 1].x) : 0xffffffffu;
+            int rank = 0;
+            for (int b0 = 0; b0 < cr; b0 += 8) {
+                const int bb = b0 + l8;
+                const unsigned kb = b0 == a0 ? ka : (bb < cr ? (e[bb * 5].y << 16) | (0xffffu - e[bb * 5 + 1].x) : 0xffffffffu);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const unsigned ko = (unsigned)__shfl((int)kb, (threadIdx.x & ~7) | t, 64);
+                    const int oidx = b0 + t;
+                    rank += (oidx < cr) && (ko < ka || (ko == ka && oidx < a));
+                }
+            }
+            if (mine) {
+                uint2 *dst = (uint2 *)(out + o0 + rank);
+#pragma unroll
+                for (int w = 0; w < 5; ++w) dst[w] = e[a * 5 + w];
+            }
         }
-        uint2 *dst = (uint2 *)(out + off + rank);
-        for (int w = 0; w < 5; ++w) dst[w] = e[a * 5 + w];
     }
 }
 
