@@ -826,8 +826,11 @@ __device__ int poa_add_chain_wave(PoaGraph &g, const uint8_t *seq, int begin, in
     return n0;
 }
 
-// Graph::add_edge with the first four out-edges fetched in one load
-__device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
+// Graph::add_edge with the first four out-edges fetched in one load.  chg = the state bytes of the topological sort in
+// LDS (null when the sort runs in global memory): a node that gets a NEW in-edge is flagged there (POA_ST_CHANGED)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+constexpr int POA_ST_ROOT = 8, POA_ST_CHANGED = 16, POA_ST_MATE = 64;
+__device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w, lds_u8 *chg, bool use_chg)
 {
     const int oc = g.out_cnt[b];
     const PoaInt4 d4 = *(const PoaInt4 *)(g.out_dst + (int64_t)b * 4);
@@ -839,6 +842,7 @@ __device__ void poa_add_edge_wave(PoaGraph &g, int b, int e, int w)
     if (oc >= g.deg || ic >= g.deg) { g.err |= POA_ERR_DEGREE; return; }
     PG_OUT_DST(g, b, oc) = e; PG_OUT_SLOT(g, b, oc) = (uint8_t)ic; g.out_cnt[b] = (uint8_t)(oc + 1);
     PG_IN_SRC(g, e, ic) = b; PG_IN_WT(g, e, ic) = w; g.in_cnt[e] = (uint8_t)(ic + 1);
+    if (use_chg && (threadIdx.x & 63) == 0) chg[e] = (unsigned char)(chg[e] | POA_ST_CHANGED);
 }
 
 // Graph::topological_sort with all of its mutable state in LDS: per node one byte (mark in bits 0-1,
@@ -860,7 +864,6 @@ static_assert(POA_LDS_FIXED % 16 == 0, "per-node LDS arrays start 16-byte aligne
 // inferring the address space through the whole inlined window kernel; when it does not (it stopped after an unrelated
 // change of the DP: SQ_INSTS_LDS fell from 2.1e9 to 2.8e6 per launch) every access below becomes a FLAT instruction,
 // which works, and costs half as much again per visit.
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) short lds_s16;
 struct PoaTopoLds {
     lds_u8 *st8;             // [ncp] per node: mark in bits 0-1, "check aligned nodes" in bit 2
@@ -870,6 +873,7 @@ struct PoaTopoLds {
     lds_s16 *rec;            // [64][POA_REC_SHORTS] records of 64 nodes that were consecutive in the previous order
     lds_s16 *obuf;           // [POA_OBUF_SHORTS] the newest entries of the order, flushed to global memory 64 at a time
     int n_sorted;            // nodes ranked by the previous sort
+    int flags_ok;            // the root flags in st8 describe the previous order (not after a sort that ran in global memory)
     int use;                 // 0: the node capacity does not fit LDS, the global-memory sort runs instead (a null test
                              // will not do: LDS offset 0 is a valid address, and the LDS null pointer is not 0)
 };
@@ -882,6 +886,29 @@ struct PoaTopoLds {
 // order closely (one sequence changes the graph little), so the records of 64 nodes that were consecutive
 // in that order are cached in LDS and re-read when the walk has moved on (second miss in the same
 // 64-rank region); nodes added since the previous sort are read in place.
+// INCREMENTAL (round 3).  The order spoa's DFS produces is a concatenation of BLOCKS: what the walk that starts at one root
+// (a node not yet done when its id comes up) emits - the nodes it pulls in, then the root, then the root's aligned nodes
+// (a root is the first of its group to be examined, so it emits the group).  One more sequence changes few of them:
+//   * a node is examined through its own in-edge and aligned lists and the done / not-done state of the nodes in them;
+//   * new edges only run forward in the previous order (the alignment path visits the nodes by increasing rank, new nodes
+//     sit between them), so every node a walk pulls in - through old or new edges or aligned links - lies, in the previous
+//     order, in an EARLIER block (done already) or in the SAME block.  A walk never reaches into a later block, the roots
+//     stay roots, and their order (by id) is the blocks' order; new nodes have the largest ids, so those of them that no
+//     old node pulls in are the last roots.
+// Hence a block none of whose nodes got a new in-edge or aligned node (add_alignment flags those, POA_ST_CHANGED) comes out
+// exactly as before and is COPIED (lane-parallel, marked done); the walk is repeated only from the roots of the blocks that
+// hold a flagged node, with everything before the block done and everything behind it untouched: 66 of the 478 blocks of
+// a 30-sequence window per sequence.  Checked against the full sort on the host (tests/hostcheck/poa_topo_inc_check.cpp,
+// tests/test_poa_cpu.py: 0 differences in 23 000 sorts) and on the device: -DGBX_POA_TOPO_CHECK runs the full
+// global-memory sort behind every incremental one and counts the orders that differ (scripts/dbg_poa_phases.py).
+// State bytes (LDS, persistent for a window): mark (bits 0-1), check (2), POA_ST_ROOT (the node started a walk),
+// POA_ST_MATE (it was emitted as an aligned node of a root: the tail of that root's block), POA_ST_CHANGED.
+#ifdef GBX_POA_TOPO_CHECK
+__device__ unsigned long long g_topo_mismatch, g_topo_inc_sorts, g_topo_walked, g_topo_blocks_all;
+#endif
+// INC = false: every sort walks everything (the second launch's kernel, whose column-block DP leaves no registers for
+// the block bookkeeping: with it the 25 long windows of 'large' took 292 ms instead of 252 and ended after the main launch)
+template <bool INC>
 __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph &g, PoaTopoLds &T)
 {
     lds_u8 *st8 = T.st8; lds_s16 *stk = T.stk, *old = T.old, *rec = T.rec, *obuf = T.obuf;
@@ -896,7 +923,13 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
     const int n = g.n_nodes;
     const int lane = threadIdx.x & 63;
     const int n_old = T.n_sorted;
-    for (int i = lane; i < n; i += 64) { st8[i] = 4; if (i >= n_old) old[i] = -1; }   // mark 0, check 1
+    const bool inc = INC && T.flags_ok && n_old > 0;
+    // mark 0, check 1; old nodes keep their root flag and what add_alignment flagged
+    for (int i = lane; i < n; i += 64) {
+        const int keep = inc && i < n_old ? st8[i] & (POA_ST_ROOT | POA_ST_MATE | POA_ST_CHANGED) : 0;
+        st8[i] = (unsigned char)(4 | keep);
+        if (i >= n_old) old[i] = -1;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int rb = -64, miss_rb = -64;
@@ -925,9 +958,10 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
     // short: one overflow check per visit with a single exit, 32-bit ballots (lanes 0..11 hold the list),
     // v_mbcnt for a lane's push slot.
     bool overflow = false;
-    for (int i = 0; i < n && !overflow; ++i) {
-        const int st_i = st8[i];
-        if ((st_i & 3) != 0) continue;
+    // the walk from root i (its state byte st_i: not done), emitting into obuf / ord
+    auto walk = [&](int i, int st_i) {
+        if (lane == 0) st8[i] = (unsigned char)(st_i | POA_ST_ROOT);
+        st_i |= POA_ST_ROOT;
         stk[sp++] = (short)i;
         int top = i, top_st = st_i;
         bool top_known = true;
@@ -956,7 +990,7 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
             // this lane's list entry and the counts
             int cand, cc;
             const int l = o - rb;
-            if (o >= 0 && (unsigned)l < 64u) {
+            if (o >= 0 && (unsigned)l < 64u && !(stv & POA_ST_CHANGED)) {       // (a flagged node's cached record may be stale)
                 cand = rec[l * POA_REC_SHORTS + min(lane, 11)];
                 cc = (unsigned short)rec[l * POA_REC_SHORTS + 12];
             } else {
@@ -988,18 +1022,22 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
             }
             const uint32_t pal = (uint32_t)__ballot(is_al && need);
             if (pal) {
-                if (is_al && need) { stk[sp + (int)__builtin_amdgcn_mbcnt_lo(pal, 0u)] = (short)cand; st8[cand] = (unsigned char)(sa & 3); }
+                if (is_al && need) { stk[sp + (int)__builtin_amdgcn_mbcnt_lo(pal, 0u)] = (short)cand; st8[cand] = (unsigned char)(sa & ~4); }
                 sp += __builtin_popcount(pal); valid = false;
                 const int hi = 31 - __builtin_clz(pal);
-                top = __builtin_amdgcn_readlane(cand, hi); top_st = __builtin_amdgcn_readlane(sa, hi) & 3;
+                top = __builtin_amdgcn_readlane(cand, hi); top_st = __builtin_amdgcn_readlane(sa, hi) & ~4;
                 top_known = true;
             }
             if (valid) {
-                if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 2);
+                if (lane == 0) st8[id] = (unsigned char)((stv & (4 | POA_ST_ROOT)) | 2);
                 if (chk) {
                     const int ob = nr - nflush;                  // < 64
                     if (lane == 0) obuf[ob] = (short)id;
-                    if (lane >= 4 && lane < 4 + ac) obuf[ob + 1 + lane - 4] = (short)cand;
+                    if (lane >= 4 && lane < 4 + ac) {
+                        obuf[ob + 1 + lane - 4] = (short)cand;
+                        // the aligned nodes of a root are the tail of its block
+                        st8[cand] = (unsigned char)(((int)st8[cand] & ~POA_ST_MATE) | ((stv & POA_ST_ROOT) ? POA_ST_MATE : 0));
+                    }
                     nr += 1 + ac;
                     if (nr - nflush >= 64) {
                         ord[nflush + lane] = ((const volatile lds_s16 *)obuf)[lane];
@@ -1010,11 +1048,85 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
                     }
                 }
                 --sp;
-            } else if (lane == 0) st8[id] = (unsigned char)((stv & 4) | 1);
+            } else if (lane == 0) st8[id] = (unsigned char)((stv & (4 | POA_ST_ROOT | POA_ST_CHANGED)) | 1);
         }
 #ifdef GBX_POA_PHASE_STATS
         if (nvis_ - v0_ == 1) ++ntriv_;
 #endif
+    };
+#ifdef GBX_POA_TOPO_CHECK
+    unsigned long long walked_ = 0, blocks_ = 0;
+#endif
+    int first_new_root = 0;
+    if (inc) {
+        // The previous order in one pass, 64 ranks at a time: ballots of the root / tail / flagged bits, the blocks inside a
+        // chunk delimited by bit operations (a block ends at a root or tail rank that no tail rank follows), blocks that
+        // cross a chunk boundary carried along.  A block that ends untouched is left for a later copy; when a touched one
+        // ends, everything before it that is still pending is copied and the walk restarts at its root.
+        int q = 0;                                             // first rank not yet in the new order
+        int bs = 0, root_rank = -1;                            // the open block: its first rank, its root's rank once seen
+        bool chg = false, pend_end = false;                    // ... holds a flagged node; the previous chunk ended on a root / tail rank
+        auto copy_upto = [&](int upto) {
+            if (upto <= q) return;
+            if (lane < nr - nflush) ord[nflush + lane] = ((const volatile lds_s16 *)obuf)[lane];      // what the walks have staged
+            for (int t0 = q; t0 < upto; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < upto) {
+                    const int nd = g.r2n[t];
+                    ord[nr + t - q] = nd;
+                    st8[nd] = (unsigned char)((st8[nd] & (POA_ST_ROOT | POA_ST_MATE)) | 4 | 2);
+                }
+            }
+            nr += upto - q; nflush = nr; q = upto;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto close_block = [&](int e) {                        // the open block is [bs, e]
+            if (chg && root_rank >= 0) {
+                copy_upto(bs);
+                const int root = g.r2n[root_rank];
+                walk(root, (int)st8[root]);
+#ifdef GBX_POA_TOPO_CHECK
+                ++walked_;
+#endif
+                q = e + 1;
+            }
+            bs = e + 1; chg = false; root_rank = -1;
+        };
+        for (int t0 = 0; t0 < n_old && !overflow; t0 += 64) {
+            const int t = t0 + lane;
+            const int sv = t < n_old ? (int)st8[g.r2n[t]] : 0;
+            const unsigned long long rm = __ballot((sv & POA_ST_ROOT) != 0), mm = __ballot((sv & POA_ST_MATE) != 0);
+            const unsigned long long cm = __ballot((sv & POA_ST_CHANGED) != 0);
+            if (pend_end && !(mm & 1)) close_block(t0 - 1);
+            pend_end = false;
+            unsigned long long em = (rm | mm) & ~(mm >> 1);
+            if (em >> 63) { pend_end = true; em &= ~(1ull << 63); }    // whether rank t0 + 63 ends its block shows in the next chunk
+            while (em && !overflow) {
+                const int eb = __builtin_ctzll(em);
+                em &= em - 1;
+                const int lo = bs > t0 ? bs - t0 : 0;
+                const unsigned long long seg = (eb == 63 ? ~0ull : (2ull << eb) - 1) & ~((1ull << lo) - 1);
+                chg = chg || (cm & seg) != 0;
+                if (rm & seg) root_rank = t0 + 63 - __builtin_clzll(rm & seg);
+                close_block(t0 + eb);
+            }
+            const int lo = bs > t0 ? bs - t0 : 0;                       // what is left of the chunk belongs to the open block
+            if (lo < 64) {
+                const unsigned long long rest = ~((1ull << lo) - 1);
+                chg = chg || (cm & rest) != 0;
+                if (rm & rest) root_rank = t0 + 63 - __builtin_clzll(rm & rest);
+            }
+        }
+        if (pend_end && !overflow) close_block(n_old - 1);
+        if (!overflow) copy_upto(n_old);
+        first_new_root = n_old;
+    }
+    // full walk (first sort of a window, or after a sort in global memory) / the roots among the new nodes
+    for (int i = first_new_root; i < n && !overflow; ++i) {
+        const int st_i = st8[i];
+        if ((st_i & 3) != 0) continue;
+        walk(i, st_i);
     }
     if (overflow) {
         // deeper than the LDS stack (a long fresh chain walked back node by node): redo this sort with the
@@ -1023,7 +1135,7 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (g.err == 0) for (int r = lane; r < n; r += 64) old[g.r2n[r]] = (short)r;
-        T.n_sorted = n;
+        T.n_sorted = n; T.flags_ok = 0;                         // no root flags from that sort: the next one walks everything
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         return;
@@ -1035,9 +1147,34 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int r = lane; r < n; r += 64) { const int id = ord[r]; g.r2n[r] = id; g.n2r[id] = r; old[id] = (short)r; }
-    T.n_sorted = n;
+    T.n_sorted = n; T.flags_ok = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef GBX_POA_TOPO_CHECK
+    // the same sort once more, in full, in global memory: the two orders must agree
+    {
+        for (int r = lane; r < n; r += 64) g.score[r] = g.r2n[r];          // (cons_path is the DFS stack's memory; the row descriptors are free here)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        poa_topo_sort(g);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int bad = 0;
+        for (int r = lane; r < n; r += 64) bad += g.score[r] != g.r2n[r];
+        const unsigned long long any = __ballot(bad != 0);
+        for (int r = 0; r < n; r += 64) if (r + lane < n && (st8[r + lane] & POA_ST_ROOT)) ++blocks_;
+        if (lane == 0) {
+            if (any || nr != n) atomicAdd(&g_topo_mismatch, 1ull);
+            if (inc) { atomicAdd(&g_topo_inc_sorts, 1ull); atomicAdd(&g_topo_walked, walked_); }
+        }
+        unsigned long long bsum = blocks_;
+        for (int d = 32; d; d >>= 1) bsum += __shfl_xor(bsum, d);
+        if (lane == 0 && inc) atomicAdd(&g_topo_blocks_all, bsum);
+        for (int r = lane; r < n; r += 64) old[g.r2n[r]] = (short)r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#endif
 }
 
 #ifdef GBX_POA_PHASE_STATS
@@ -1046,7 +1183,8 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
 #define TOPO_TIMED(g) POA_TOPO(g);
 #endif
 // topological sort through LDS when the kernel was launched with the LDS layout, else the global-memory one
-#define POA_TOPO(g) { if (T.use) poa_topo_sort_lds(g, T); else poa_topo_sort(g); }
+#define POA_TOPO(g) { if (T.use) poa_topo_sort_lds<INC>(g, T); else poa_topo_sort(g); }
+template <bool INC>
 __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &g, const uint8_t *seq, int len, PoaTopoLds &T)
 {
     if (len == 0) return;
@@ -1137,18 +1275,20 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
                             const int a = g.aln[node_k * POA_ALN_STRIDE + z];
                             g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = a; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
                             g.aln[a * POA_ALN_STRIDE + g.aln_cnt[a]] = id; g.aln_cnt[a] = (uint8_t)(g.aln_cnt[a] + 1);
+                            if (T.use && lane == 0) T.st8[a] = (unsigned char)(T.st8[a] | POA_ST_CHANGED);
                         }
                         g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = node_k; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
                         g.aln[node_k * POA_ALN_STRIDE + ac] = id; g.aln_cnt[node_k] = (uint8_t)(ac + 1);
+                        if (T.use && lane == 0) T.st8[node_k] = (unsigned char)(T.st8[node_k] | POA_ST_CHANGED);
                     }
                 } else id = found;
             }
-            if (head != -1 && !((settled >> k) & 1)) poa_add_edge_wave(g, head, id, prev_w + 1);
+            if (head != -1 && !((settled >> k) & 1)) poa_add_edge_wave(g, head, id, prev_w + 1, T.st8, T.use != 0);
             head = id;
             prev_w = 1;
         }
     }
-    if (tail != -1) poa_add_edge_wave(g, head, tail, prev_w + 1);
+    if (tail != -1) poa_add_edge_wave(g, head, tail, prev_w + 1, T.st8, T.use != 0);
     if (g.err) return;
     TOPO_TIMED(g)
 }
@@ -1229,7 +1369,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     T.use = A.lds_marks;
     T.old = (lds_s16 *)(lds0 + POA_LDS_FIXED + ncp);
     T.stk_cap = A.lds_stack;
-    T.n_sorted = 0;
+    T.n_sorted = 0; T.flags_ok = 0;
     g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
 
@@ -1252,7 +1392,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
         if (q32 >= nwork) break;
         const int64_t w = (int64_t)A.wlist[q32];
         poa_graph_reset(g);
-        T.n_sorted = 0;
+        T.n_sorted = 0; T.flags_ok = 0;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
         for (int64_t s = s0; s < s1; ++s) {
             const uint8_t *seq = A.arena + A.seq_off[s];
@@ -1281,7 +1421,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
             }
             {
                 PH_T0
-                if (g.err == 0) poa_add_alignment_wave(g, seq, len, T);
+                if (g.err == 0) poa_add_alignment_wave<!LONG>(g, seq, len, T);
                 PH_ACC(t_add)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1301,6 +1441,9 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
         A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;
+#ifdef GBX_POA_TOPO_CHECK
+        A.cells[20] = g_topo_mismatch; A.cells[21] = g_topo_inc_sorts; A.cells[22] = g_topo_walked; A.cells[23] = g_topo_blocks_all;
+#endif
     }
 #endif
 }

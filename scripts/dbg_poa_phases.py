@@ -27,6 +27,9 @@ print("%d windows %.1f ms; wave clocks: DP %.1f%%  traceback %.1f%%  add_alignme
 roots, triv = int(c[10]), int(c[11])
 print("sort roots per node %.3f, single-visit roots per node %.3f" % (roots / max(topo_n, 1), triv / max(topo_n, 1)))
 print("sort: %.0f clocks per node, %.2f visits per node, %.3f block loads per node" % (topo / max(topo_n, 1), vis / max(topo_n, 1), blk / max(topo_n, 1)))
+if int(c[21]):         # a -DGBX_POA_TOPO_CHECK build: every incremental sort was followed by a full one in global memory
+    print("incremental sorts %d, orders that differ from the full sort: %d; blocks walked %.1f of %.1f per sort" % (
+        int(c[21]), int(c[20]), int(c[22]) / int(c[21]), int(c[23]) / int(c[21])))
 rows, steps = int(c[12]), int(c[13])
 if rows:
     print("DP: %d rows, %.0f wave clocks per row; traceback: %d steps, %.0f clocks per step; add_alignment without the sort: %.0f clocks per path element"

@@ -106,3 +106,30 @@ def test_capacity_overflow_is_reported(hostcheck):
     ws = gen_poa(1, 5)
     got, err = _host_window(hostcheck, p, ws.window(0), ncap=600)
     assert err & 1                                                      # POA_ERR_NODES
+
+
+def test_incremental_topological_sort_model_equals_the_full_sort():
+    """The device's topological sort (csrc/poa_kernels.hip: poa_topo_sort_lds) no longer walks the whole graph after every
+    sequence: the previous order is cut into the blocks the walks from the roots emitted, untouched blocks are copied and
+    the walk is repeated only from the roots of blocks that hold a node with a new in-edge or aligned node.  Here a host
+    model of exactly that scheme (tests/hostcheck/poa_topo_inc_check.cpp) runs beside the full sort (poa_graph.h:
+    poa_topo_sort, spoa's order) after every add_alignment of real windows: the two orders must be the same, sort after
+    sort.  (On the device the same comparison is a -DGBX_POA_TOPO_CHECK build: scripts/dbg_poa_phases.py.)"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "hostcheck", "poa_topo_inc_check.cpp")
+    out = os.path.join(ROOT, "tests", "hostcheck", "libpoa_topo_inc_check.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src, "-o", out], check=True)
+    L = C.CDLL(out)
+    p = make_params()
+    sorts = walked = blocks = 0
+    for seed, nw in ((4001, 40), (99, 20), (123456, 20)):
+        ws = gen_poa(nw, seed)
+        for w in range(ws.n_windows):
+            seqs = ws.window(w)
+            arr = (C.c_char_p * len(seqs))(*[s.encode() if isinstance(s, str) else bytes(s) for s in seqs])
+            lens = (C.c_int32 * len(seqs))(*[len(s) for s in seqs])
+            st = (C.c_int64 * 4)()
+            ncap = min(sum(len(s) for s in seqs), 6 * max(len(s) for s in seqs) + 256)
+            assert L.hostcheck_poa_topo_inc(C.byref(p), len(seqs), arr, lens, ncap, 40, st) == 0, (seed, w)
+            sorts += st[0]; walked += st[1]; blocks += st[2]
+    assert sorts > 2000 and walked < 0.25 * blocks           # and the point of it: a seventh of the blocks are walked
