@@ -1220,7 +1220,6 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
         const int node = t >= 0 ? g.path_node[t] : -1;
         const int scode = pos >= 0 ? (int)g.coder[seq[pos]] : -1;
         const int ncode = node >= 0 ? (int)g.code[node] : -1;
-        const int cnt = min(64, t0 + 1);
         // Lane-parallel part.  Most elements land on an existing node whose predecessor element did too, over an
         // edge that already exists: all that add_edge does then is add 2 to the edge's weight (distinct edges, so
         // the lanes do not collide, and weights commute with everything the serial loop below appends).  Lane k
@@ -1250,10 +1249,22 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
             }
             settled = __ballot(done);
         }
-        for (int k = 0; k < cnt; ++k) {
-            const int pos_k = rl(pos, k);
-            if (pos_k == -1) continue;
+        // The serial loop only visits what the lanes could not settle (a seventh of the elements): the element before an
+        // unsettled one is either the one this loop handled last (its node is `last_id`) or a settled one, whose node is the
+        // path's node.
+        const unsigned long long vmask = __ballot(pos >= 0);
+        unsigned long long todo = vmask & ~settled;
+        int last_k = -1, last_id = -1;
+        while (todo) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1;
             if (g.err) return;
+            const unsigned long long before_k = vmask & ((1ull << k) - 1);
+            if (before_k) {
+                const int pk = 63 - __builtin_clzll(before_k);
+                head = pk == last_k ? last_id : rl(node, pk);
+                prev_w = 1;
+            }
             const int node_k = rl(node, k), code = rl(scode, k), ncode_k = rl(ncode, k);
             int id;
             if (node_k == -1) {
@@ -1283,8 +1294,12 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
                     }
                 } else id = found;
             }
-            if (head != -1 && !((settled >> k) & 1)) poa_add_edge_wave(g, head, id, prev_w + 1, T.st8, T.use != 0);
-            head = id;
+            if (head != -1) poa_add_edge_wave(g, head, id, prev_w + 1, T.st8, T.use != 0);
+            last_k = k; last_id = id;
+        }
+        if (vmask) {                                            // the chunk's last element is the next chunk's predecessor
+            const int lv = 63 - __builtin_clzll(vmask);
+            head = lv == last_k ? last_id : rl(node, lv);
             prev_w = 1;
         }
     }
