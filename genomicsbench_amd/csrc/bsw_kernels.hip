@@ -612,29 +612,29 @@ __global__ void __launch_bounds__(1024) bsw_lane_scan_kernel(BswWork W)
     }
 }
 
-// Two columns of the compact lane kernel, scheduled by hand (30 VALU instructions; the compiler's version of the same
+// Two columns of the compact lane kernel, scheduled by hand (28 VALU instructions; the compiler's version of the same
 // C++ needs 43).  w = the lane's dword of the column pair, bytes {e(2p), h(2p), e(2p+1), h(2p+1)}; qq = the pair's query
-// codes (x 6) in bytes 0 and 1; the cell fields are byte operands (SDWA), never unpacked.  Returns the new dword;
-// updates f, left (the previous column's h), key.  vcc is written two instructions before it is read.
+// codes (0..4) in bytes 0 and 1, zero above: they are the selector of one v_perm_b32 over the matrix row of the target
+// base (rw = its four bytes against A C G T, rwn = the byte against N), which leaves the two scores in bytes 0 and 1;
+// scores and cell fields are byte operands (SDWA), never unpacked.  Returns the new dword; updates f, left (the previous
+// column's h), key.  vcc is written two instructions before it is read.
 template <bool SYM>
-__device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint32_t rw, int &f, int &left, uint32_t &key, int pa, int pa1,
+__device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint32_t rw, uint32_t rwn, int &f, int &left, uint32_t &key, int pa, int pa1,
                                                    int zero, int oe_del, int oe_ins, int e_del, int e_ins)
 {
     uint32_t wn;
     int hb;
     if (SYM) {
-        int sa, sb, ta, tb, ma, mb, x, ha, td, ed, ena, enb, fd, ka, kb, qb, u, v;
+        int sa, ta, tb, ma, mb, x, ha, td, ed, ena, enb, fd, ka, kb, u, v;
         asm volatile(
-            "v_bfe_i32 %[sa], %[rw], %[qq], 6\n"
-            "v_lshrrev_b32 %[qb], 8, %[qq]\n"
+            "v_perm_b32 %[sa], %[rwn], %[rw], %[qq]\n"
             "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n"
-            "v_add_u32_sdwa %[ta], %[sa], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
-            "v_bfe_i32 %[sb], %[rw], %[qb], 6\n"
             "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_add_u32_sdwa %[ta], sext(%[sa]), %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n"
             "v_cndmask_b32 %[ma], 0, %[ta], vcc\n"
             "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_3 src1_sel:DWORD\n"
             "v_max_i32_sdwa %[x], %[ma], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
-            "v_add_u32_sdwa %[tb], %[sb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n"
+            "v_add_u32_sdwa %[tb], sext(%[sa]), %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3\n"
             "v_max_i32 %[ha], %[x], %[f]\n"
             "v_subrev_u32 %[td], %[oed], %[ma]\n"
             "v_cndmask_b32 %[mb], 0, %[tb], vcc\n"
@@ -654,25 +654,23 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
             "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
             "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
             "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
-            : [sa] "=&v"(sa), [sb] "=&v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
+            : [sa] "=&v"(sa), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
               [hb] "=&v"(hb), [td] "=&v"(td), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
-              [kb] "=&v"(kb), [qb] "=&v"(qb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
-            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
               [edel] "s"(e_del), [eins] "s"(e_ins)
             : "vcc");
     } else {
-        int sa, sb, ta, tb, ma, mb, x, ha, td, ti, ed, ena, enb, fd, ka, kb, qb, u, v;
+        int sa, ta, tb, ma, mb, x, ha, td, ti, ed, ena, enb, fd, ka, kb, u, v;
         asm volatile(
-            "v_bfe_i32 %[sa], %[rw], %[qq], 6\n"
-            "v_lshrrev_b32 %[qb], 8, %[qq]\n"
+            "v_perm_b32 %[sa], %[rwn], %[rw], %[qq]\n"
             "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_1 src1_sel:DWORD\n"
-            "v_add_u32_sdwa %[ta], %[sa], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
-            "v_bfe_i32 %[sb], %[rw], %[qb], 6\n"
             "v_subrev_u32 %[fd], %[eins], %[f]\n"
+            "v_add_u32_sdwa %[ta], sext(%[sa]), %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1\n"
             "v_cndmask_b32 %[ma], 0, %[ta], vcc\n"
             "v_cmp_ne_u32_sdwa vcc, %[w], %[zero] src0_sel:BYTE_3 src1_sel:DWORD\n"
             "v_max_i32_sdwa %[x], %[ma], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
-            "v_add_u32_sdwa %[tb], %[sb], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n"
+            "v_add_u32_sdwa %[tb], sext(%[sa]), %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_3\n"
             "v_max_i32 %[ha], %[x], %[f]\n"
             "v_subrev_u32 %[td], %[oed], %[ma]\n"
             "v_subrev_u32 %[ti], %[oei], %[ma]\n"
@@ -694,10 +692,10 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
             "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
             "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
             "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
-            : [sa] "=&v"(sa), [sb] "=&v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
+            : [sa] "=&v"(sa), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
               [hb] "=&v"(hb), [td] "=&v"(td), [ti] "=&v"(ti), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
-              [kb] "=&v"(kb), [qb] "=&v"(qb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
-            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
               [oei] "s"(oe_ins), [edel] "s"(e_del), [eins] "s"(e_ins)
             : "vcc");
     }
@@ -712,10 +710,21 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
 // cycles, so again no two lanes of a group meet in a bank).  3 bytes per column and lane instead of 4: queries up to
 // ~100 long run at two wavefronts per SIMD and more; a column pair is one dword read, one halfword read and one dword
 // write, and its fields are byte operands of the arithmetic (SDWA), never unpacked.
+#ifdef GBX_BSW_LANE_STATS
+// development aid (scripts/dbg_bsw_lanes.py): how full the lock-step rows are.  Per launch slot: [0] cells the lanes
+// computed, [1] 64 x the widest window of every row (what the wavefront paid), [2] rows the lanes ran, [3] 64 x rows the
+// wavefront ran; units of 256.
+__device__ unsigned long long g_bsw_lane_stats[16][4];
+#endif
 template <bool SYM, bool COMPACT>
 __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, BswWork W, int rlo, int rhi, int cols, int slot)
 {
     extern __shared__ uint32_t lcell[];
+#ifdef GBX_BSW_LANE_STATS
+    __shared__ int st_rowmax[2048];
+    for (int k = threadIdx.x; k < 2048; k += 64) st_rowmax[k] = 0;
+    unsigned long long st_cells = 0, st_rows = 0, st_wcells = 0, st_wrows = 0;
+#endif
 #define LCELL(byte_addr) (*(uint32_t *)((char *)lcell + (byte_addr)))
 #define LCELL16(byte_addr) (*(uint16_t *)((char *)lcell + (byte_addr)))
 #define LQ8(byte_addr) (*((uint8_t *)lcell + (byte_addr)))
@@ -730,6 +739,10 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
     const int cb = lane * 4;
     const int qb = (cols >> 1) * 256 + (lane & 31) * 4 + (lane >> 5) * 2;       // cols is even
     auto cell_at = [&](int j) { return COMPACT ? (j >> 1) * 256 + cb + (j & 1) * 2 : j * 256 + cb; };
+    // the scoring matrix by target base, behind the planes: {bytes against A C G T, byte against N, 6-bit fields (wide format), -}
+    const int tab = COMPACT ? (cols >> 1) * 384 + 640 : (cols + 2) * 256;
+    if (lane < 5) *(uint4 *)((char *)lcell + tab + lane * 16) = make_uint4(prm.row0[lane], prm.row1[lane], prm.lrow[lane], 0u);
+#define LTAB(base_code) (*(const uint4 *)((const char *)lcell + tab + min((int)(base_code), 4) * 16))
     for (;;) {
         int c = 0;
         if (lane == 0) c = atomicAdd(&W.lchunk[slot], 1);
@@ -745,29 +758,41 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         // first row, :155-157, and the query codes (x 6: the bit offset of the score field in the matrix row word)
         for (int j = 0; j <= qlen; ++j) {
             const int hv = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
-            const int qc = j < qlen ? min((int)q[j], 4) * 6 : 0;
+            const int qc = j < qlen ? min((int)q[j], 4) : 0;
             if (COMPACT) { LCELL16(cell_at(j)) = (uint16_t)(hv << 8); LQ8(qb + (j >> 1) * 128 + (j & 1)) = (uint8_t)qc; }
-            else LCELL(cell_at(j)) = ((uint32_t)hv << 18) | (uint32_t)qc;
+            else LCELL(cell_at(j)) = ((uint32_t)hv << 18) | (uint32_t)(qc * 6);
         }
         const int w = band_width(prm, qlen);
         int best = h0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
         int beg = 0, end = qlen;
-        int tb = min((int)t[0], 4);
+        // the matrix row of the target base two rows ahead of its use: row i's in registers, row i+1's on its way from the
+        // table, the base of row i+2 on its way from memory (the arenas are readable 16 bytes past their last base)
+        uint4 mrow = LTAB(t[0]), mnext = LTAB(t[1]);
+        int tb2 = t[2];
+        const uint8_t *tp = t + 3;
+        int hrow = h0 - prm.o_del - e_del;                 // h0 - (o_del + e_del * (i + 1))
+        int imw = -w, ipw = w + 1;                         // i - w, i + w + 1
         for (int i = 0; i < tlen; ++i) {
-            const uint32_t rw = tb == 0 ? prm.lrow[0] : tb == 1 ? prm.lrow[1] : tb == 2 ? prm.lrow[2] : tb == 3 ? prm.lrow[3] : prm.lrow[4];
-            tb = min((int)t[min(i + 1, tlen - 1)], 4);      // next row's base: in flight during this row
-            if (beg < i - w) beg = i - w;                  // :179-181
-            if (end > i + w + 1) end = i + w + 1;
-            if (end > qlen) end = qlen;
-            int left = beg == 0 ? max(h0 - (prm.o_del + e_del * (i + 1)), 0) : 0;      // :183-186
+            const uint32_t rw = COMPACT ? mrow.x : mrow.z, rwn = mrow.y;
+            mrow = mnext;
+            mnext = LTAB(tb2);
+            tb2 = *tp++;
+            beg = max(beg, imw);                           // :179-181
+            end = min(min(end, ipw), qlen);
+            ++imw; ++ipw;
+#ifdef GBX_BSW_LANE_STATS
+            if (have) { st_cells += (unsigned)max(end - beg, 0); st_rows += 1; atomicMax(&st_rowmax[i & 2047], max(end - beg, 0) + 1); }
+#endif
+            int left = beg == 0 ? max(hrow, 0) : 0;        // :183-186
+            hrow -= e_del;
             int f = 0;
             uint32_t key = 0;                              // (row maximum << 18) | byte address of the cell of its last arg-max
             int vzero = 0;
             asm volatile("" : "+v"(vzero));                  // a zero in a vector register (SDWA compare operand)
             if (COMPACT) {
                 // one column, :187-212: h8 / e8 = the cell's fields (byte operands), qo = the query code's field offset; returns the new cell
-                auto step = [&](int diag, int e, uint32_t qo, int at) -> uint32_t {
-                    const int sc = __builtin_amdgcn_sbfe((int)rw, qo, 6u);
+                auto step = [&](int diag, int e, uint32_t qc, int at) -> uint32_t {
+                    const int sc = (int)(int8_t)__builtin_amdgcn_perm(rwn, rw, qc);
                     const int m = diag ? diag + sc : 0;    // :196
                     const int h = imax3(m, e, f);
                     key = max(key, ((uint32_t)h << 18) | (uint32_t)at);          // ties: the larger address wins = last arg-max, :200-201
@@ -793,22 +818,22 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                 uint32_t w0 = LCELL(pa), q0 = LCELL16(qa), w1 = LCELL(pa + 256), q1 = LCELL16(qa + 128);
                 for (; j + 7 < end; j += 8, pa += 1024, qa += 512) {
                     const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256), x1 = LCELL(pa + 768), y1 = LCELL16(qa + 384);
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = LCELL(pa + 1024); q0 = LCELL16(qa + 512); w1 = LCELL(pa + 1280); q1 = LCELL16(qa + 640);
-                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, f, left, key, pa + 512, pa + 514, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, f, left, key, pa + 768, pa + 770, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, rwn, f, left, key, pa + 512, pa + 514, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, rwn, f, left, key, pa + 768, pa + 770, vzero, oe_del, oe_ins, e_del, e_ins);
                 }
                 if (j + 3 < end) {
                     const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256);
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = x0; q0 = y0;
                     w1 = LCELL(pa + 768); q1 = LCELL16(qa + 384);
                     j += 4; pa += 512; qa += 256;
                 }
                 if (j + 1 < end) {
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = w1; q0 = q1;
                     j += 2; pa += 256; qa += 128;
                 }
@@ -876,10 +901,19 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         gbx_bsw_result r;
         r.score = best; r.tle = best_i + 1; r.gtle = g_i + 1; r.qle = best_j + 1; r.gscore = g_score; r.max_off = off;
         if (have) P.out[pair] = r;
+#ifdef GBX_BSW_LANE_STATS
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int k = threadIdx.x; k < 2048; k += 64) { const int m = st_rowmax[k]; if (m) { st_wcells += 64ull * (unsigned)(m - 1); st_wrows += 64; } st_rowmax[k] = 0; }
+#endif
     }
+#ifdef GBX_BSW_LANE_STATS
+    atomicAdd(&g_bsw_lane_stats[slot][0], st_cells); atomicAdd(&g_bsw_lane_stats[slot][1], st_wcells);
+    atomicAdd(&g_bsw_lane_stats[slot][2], st_rows); atomicAdd(&g_bsw_lane_stats[slot][3], st_wrows);
+#endif
 #undef LCELL
 #undef LCELL16
 #undef LQ8
+#undef LTAB
 }
 
 // ---- kernel shapes ----------------------------------------------------------
@@ -1128,7 +1162,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                 const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
                 // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
                 // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
-                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
+                const size_t lds = (fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640) + 128;      // + the matrix table
                 int per_cu = (int)((size_t)160 * 1024 / lds);
                 if (per_cu > 16) per_cu = 16;
                 // both formats of a range share a stream (one of the two is usually empty; an empty launch still has to get its
@@ -1204,3 +1238,12 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
 }
 
 }  // namespace gbx
+
+#ifdef GBX_BSW_LANE_STATS
+extern "C" int gbx_debug_bsw_lane_stats(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gbx::g_bsw_lane_stats), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gbx::g_bsw_lane_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
