@@ -617,12 +617,14 @@ __global__ void __launch_bounds__(1024) bsw_lane_scan_kernel(BswWork W)
 // codes (0..4) in bytes 0 and 1, zero above: they are the selector of one v_perm_b32 over the matrix row of the target
 // base (rw = its four bytes against A C G T, rwn = the byte against N), which leaves the two scores in bytes 0 and 1;
 // scores and cell fields are byte operands (SDWA), never unpacked.  Returns the new dword; updates f, left (the previous
-// column's h), key.  vcc is written two instructions before it is read.
+// column's h), key = max(kin, the two columns' (h << 18 | pa), (h << 18 | pa1)): pa, pa1 are absolute cell addresses, or
+// offsets within a trip of the main loop whose base is added once per trip.  vcc is written two instructions before it
+// is read.
 template <bool SYM>
-__device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint32_t rw, uint32_t rwn, int &f, int &left, uint32_t &key, int pa, int pa1,
+__device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint32_t rw, uint32_t rwn, int &f, int &left, uint32_t kin, uint32_t &key, int pa, int pa1,
                                                    int zero, int oe_del, int oe_ins, int e_del, int e_ins)
 {
-    uint32_t wn;
+    uint32_t wn, kout;
     int hb;
     if (SYM) {
         int sa, ta, tb, ma, mb, x, ha, td, ed, ena, enb, fd, ka, kb, u, v;
@@ -652,12 +654,12 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
             "v_lshl_or_b32 %[kb], %[hb], 18, %[pa1]\n"
             "v_lshl_or_b32 %[u], %[left], 8, %[ena]\n"
             "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
-            "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
+            "v_max3_u32 %[key], %[kin], %[ka], %[kb]\n"
             "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
             : [sa] "=&v"(sa), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
               [hb] "=&v"(hb), [td] "=&v"(td), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
-              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
-            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "=v"(kout)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [kin] "v"(kin), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
               [edel] "s"(e_del), [eins] "s"(e_ins)
             : "vcc");
     } else {
@@ -690,16 +692,17 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
             "v_lshl_or_b32 %[kb], %[hb], 18, %[pa1]\n"
             "v_lshl_or_b32 %[u], %[left], 8, %[ena]\n"
             "v_lshl_or_b32 %[v], %[ha], 8, %[enb]\n"
-            "v_max3_u32 %[key], %[key], %[ka], %[kb]\n"
+            "v_max3_u32 %[key], %[kin], %[ka], %[kb]\n"
             "v_lshl_or_b32 %[wn], %[v], 16, %[u]\n"
             : [sa] "=&v"(sa), [ta] "=&v"(ta), [tb] "=&v"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [x] "=&v"(x), [ha] "=&v"(ha),
               [hb] "=&v"(hb), [td] "=&v"(td), [ti] "=&v"(ti), [ed] "=&v"(ed), [ena] "=&v"(ena), [enb] "=&v"(enb), [fd] "=&v"(fd), [ka] "=&v"(ka),
-              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "+v"(key)
-            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
+              [kb] "=&v"(kb), [u] "=&v"(u), [v] "=&v"(v), [wn] "=&v"(wn), [f] "+v"(f), [key] "=v"(kout)
+            : [w] "v"(w), [qq] "v"(qq), [rw] "v"(rw), [rwn] "v"(rwn), [left] "v"(left), [kin] "v"(kin), [pa] "v"(pa), [pa1] "v"(pa1), [zero] "v"(zero), [oed] "s"(oe_del),
               [oei] "s"(oe_ins), [edel] "s"(e_del), [eins] "s"(e_ins)
             : "vcc");
     }
     left = hb;
+    key = kout;
     return wn;
 }
 
@@ -743,6 +746,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
     const int tab = COMPACT ? (cols >> 1) * 384 + 640 : (cols + 2) * 256;
     if (lane < 5) *(uint4 *)((char *)lcell + tab + lane * 16) = make_uint4(prm.row0[lane], prm.row1[lane], prm.lrow[lane], 0u);
 #define LTAB(base_code) (*(const uint4 *)((const char *)lcell + tab + min((int)(base_code), 4) * 16))
+    int rel0 = 0, rel1 = 2, rel2 = 256, rel3 = 258, rel4 = 512, rel5 = 514, rel6 = 768, rel7 = 770;      // cell offsets within a trip of the main loop
+    asm volatile("" : "+v"(rel0), "+v"(rel1), "+v"(rel2), "+v"(rel3), "+v"(rel4), "+v"(rel5), "+v"(rel6), "+v"(rel7));
     for (;;) {
         int c = 0;
         if (lane == 0) c = atomicAdd(&W.lchunk[slot], 1);
@@ -789,6 +794,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
             uint32_t key = 0;                              // (row maximum << 18) | byte address of the cell of its last arg-max
             int vzero = 0;
             asm volatile("" : "+v"(vzero));                  // a zero in a vector register (SDWA compare operand)
+            uint32_t sb0 = 0, sb1 = 0, se0 = 0, se1 = 0;    // compact: the cells the next window is decided on (below)
+            const int sp0 = beg >> 1, sq = max((end >> 1) - 1, 0);
             if (COMPACT) {
                 // one column, :187-212: h8 / e8 = the cell's fields (byte operands), qo = the query code's field offset; returns the new cell
                 auto step = [&](int diag, int e, uint32_t qc, int at) -> uint32_t {
@@ -818,22 +825,24 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                 uint32_t w0 = LCELL(pa), q0 = LCELL16(qa), w1 = LCELL(pa + 256), q1 = LCELL16(qa + 128);
                 for (; j + 7 < end; j += 8, pa += 1024, qa += 512) {
                     const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256), x1 = LCELL(pa + 768), y1 = LCELL16(qa + 384);
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    uint32_t kt;                            // the trip's maximum, positions relative to pa (eight constant registers)
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, (uint32_t)vzero, kt, rel0, rel1, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, kt, kt, rel2, rel3, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = LCELL(pa + 1024); q0 = LCELL16(qa + 512); w1 = LCELL(pa + 1280); q1 = LCELL16(qa + 640);
-                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, rwn, f, left, key, pa + 512, pa + 514, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, rwn, f, left, key, pa + 768, pa + 770, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, rwn, f, left, kt, kt, rel4, rel5, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, rwn, f, left, kt, kt, rel6, rel7, vzero, oe_del, oe_ins, e_del, e_ins);
+                    key = max(key, kt + (uint32_t)pa);
                 }
                 if (j + 3 < end) {
                     const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256);
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = x0; q0 = y0;
                     w1 = LCELL(pa + 768); q1 = LCELL16(qa + 384);
                     j += 4; pa += 512; qa += 256;
                 }
                 if (j + 1 < end) {
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = w1; q0 = q1;
                     j += 2; pa += 256; qa += 128;
                 }
@@ -841,6 +850,11 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                     LCELL16(pa) = (uint16_t)step((int)((w0 >> 8) & 0xffu), (int)(w0 & 0xffu), q0 & 0xffu, pa);
                 }
                 LCELL16(cell_at(end)) = (uint16_t)(left << 8);                   // eh[end] = {h1, 0}, :213
+                // The next window (:230-233) starts at the first non-zero cell from beg on and ends two past the last one up to
+                // end: the four cells from beg's pair on and the four up to end's pair are requested now, behind the row's last
+                // write, and arrive while the row's results are evaluated - no LDS round trip per probed cell.
+                sb0 = LCELL(sp0 * 256 + cb); sb1 = LCELL(sp0 * 256 + 256 + cb);
+                se0 = LCELL(sq * 256 + cb); se1 = LCELL(sq * 256 + 256 + cb);
             } else {
                 uint32_t left18 = (uint32_t)left << 18;
                 int ab = cell_at(beg);
@@ -886,10 +900,26 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
             // the next row's window, :230-233 (h == 0 and e == 0 <=> the cell is zero / the word is below 32)
             int j = beg;
             if (COMPACT) {
-                while (j < end && LCELL16(cell_at(j)) == 0) ++j;
-                beg = j;
-                j = end;
-                while (j >= beg && LCELL16(cell_at(j)) == 0) --j;
+                // cells 2 sp0 .. 2 sp0 + 3: the first non-zero one at or after beg (beg is 2 sp0 or 2 sp0 + 1)
+                int k = (sb1 >> 16) ? 3 : 4;
+                k = (sb1 & 0xffffu) ? 2 : k;
+                k = (sb0 >> 16) ? 1 : k;
+                k = (sb0 & 0xffffu) && !(beg & 1) ? 0 : k;
+                j = 2 * sp0 + k;
+                if (k == 4) while (j < end && LCELL16(cell_at(j)) == 0) ++j;      // four zero cells in a row: rare
+                j = min(j, end);                            // cells at and beyond end do not count (they hold older rows)
+                const int nbeg = beg < end ? j : beg;
+                // cells 2 sq .. 2 sq + 3 reach end (and past it): the last non-zero one up to end
+                const int khi = end - 2 * sq;              // 2 or 3; 0 or 1 while end < 2
+                k = (se0 & 0xffffu) ? 0 : -1;
+                k = (se0 >> 16) && khi >= 1 ? 1 : k;
+                k = (se1 & 0xffffu) && khi >= 2 ? 2 : k;
+                k = (se1 >> 16) && khi >= 3 ? 3 : k;
+                j = 2 * sq + k;
+                if (k < 0 && 2 * sq > nbeg) while (j >= nbeg && LCELL16(cell_at(j)) == 0) --j;      // rare
+                j = max(j, nbeg - 1);
+                j = nbeg > end ? end : j;
+                beg = nbeg;
             } else {
                 while (j < end && LCELL(cell_at(j)) < 32u) ++j;
                 beg = j;
