@@ -85,7 +85,8 @@ constexpr int LANE_BINS = LANE_ROWS * 256;
 constexpr int LANE_SCORE_LIMIT = 8192;               // wide cell word = h:14 | e:13 | query code x 6 : 5
 constexpr int LANE_COMPACT_LIMIT = 256;              // compact cell = h:8 | e:8, query code in a byte plane
 constexpr int LANE_NRANGE = 5;
-// query-length ranges of the launches = LDS classes: compact 16, 10, 8, 6, 5 wavefronts per CU, wide 15, 7, 5, 4, 3
+// query-length ranges of the launches = LDS classes: compact 16, 10, 8, 6, 5 wavefronts per CU, wide 15, 7, 5, 4, 3.  (Eight
+// compact ranges, one per step of the LDS occupancy between 16 and 5, measured no faster on 'large': 6.19 vs 6.03 ms.)
 constexpr int LANE_RANGE_HI[2][LANE_NRANGE] = {{47, 79, 99, 135, LANE_QMAX}, {39, 79, 103, 127, LANE_QMAX}};
 __host__ __device__ inline bool lane_ok(int lane_on, int qlen, int tlen, int h0, int max_mat)
 {
@@ -743,7 +744,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
     const int qb = (cols >> 1) * 256 + (lane & 31) * 4 + (lane >> 5) * 2;       // cols is even
     auto cell_at = [&](int j) { return COMPACT ? (j >> 1) * 256 + cb + (j & 1) * 2 : j * 256 + cb; };
     // the scoring matrix by target base, behind the planes: {bytes against A C G T, byte against N, 6-bit fields (wide format), -}
-    const int tab = COMPACT ? (cols >> 1) * 384 + 640 : (cols + 2) * 256;
+    // (in the last 128 bytes of the look-ahead rows: nothing is written there, and what a look-ahead load reads is not used)
+    const int tab = COMPACT ? (cols >> 1) * 384 + 512 : (cols + 2) * 256 - 128;
     if (lane < 5) *(uint4 *)((char *)lcell + tab + lane * 16) = make_uint4(prm.row0[lane], prm.row1[lane], prm.lrow[lane], 0u);
 #define LTAB(base_code) (*(const uint4 *)((const char *)lcell + tab + min((int)(base_code), 4) * 16))
     int rel0 = 0, rel1 = 2, rel2 = 256, rel3 = 258, rel4 = 512, rel5 = 514, rel6 = 768, rel7 = 770;      // cell offsets within a trip of the main loop
@@ -1181,37 +1183,8 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         side_lock = std::unique_lock<std::mutex>(ss->mu);
         if ((rc = ss->fork(s))) return rc;
     }
-    if (dev.lane_on) {
-        // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
-        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
-                                                    {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
-        int nl = 0;
-        for (int r = LANE_NRANGE - 1; r >= 0; --r)
-            for (int fmt = 0; fmt < 2; ++fmt, ++nl) {
-                const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
-                const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
-                // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
-                // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
-                const size_t lds = (fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640) + 128;      // + the matrix table
-                int per_cu = (int)((size_t)160 * 1024 / lds);
-                if (per_cu > 16) per_cu = 16;
-                // both formats of a range share a stream (one of the two is usually empty; an empty launch still has to get its
-                // LDS before it can see that, so it must not sit in front of a working kernel of another range)
-                const int sk = (LANE_NRANGE - 1 - r) & 3;
-                hipStream_t sc = serial || sk == 0 ? s : ss->side[sk - 1];
-                int64_t blocks = (int64_t)cus * per_cu, want = (n + 63) / 64;
-                if (blocks > want) blocks = want;
-                const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
-                Stage st(names[fmt][r], sc);
-                if (fmt == 0) {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                } else {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                }
-            }
-    }
+    // The row-kernel classes first: with the lane path on they hold next to nothing (what the lane kernels cannot take),
+    // and twenty near-empty launches at the end of the streams were 0.1 ms of tail.
     int launched = 0;
     for (int c = 0; c < NCLS - 1; ++c) {
         if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
@@ -1236,6 +1209,40 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         }
         Stage st(k->name, sc);
         hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
+    }
+    if (dev.lane_on) {
+        // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
+        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
+                                                    {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
+        // The wide launches go first, while the chip is empty: a launch has to be given its LDS before its wavefronts can
+        // see that their list is empty (the usual case for short reads), and behind a working compact launch that wait
+        // held up the stream for up to a millisecond (6.36 -> 6.03 ms on 'large').
+        for (int fmt = 1; fmt >= 0; --fmt) {
+            int nl = 0;
+            for (int r = LANE_NRANGE - 1; r >= 0; --r) {
+                const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
+                ++nl;                                          // the range's ordinal, longest first
+                const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
+                // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
+                // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
+                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
+                int per_cu = (int)((size_t)160 * 1024 / lds);
+                if (per_cu > 16) per_cu = 16;
+                const int sk = (nl - 1) & 3;
+                hipStream_t sc = serial || sk == 0 ? s : ss->side[sk - 1];
+                int64_t blocks = (int64_t)cus * per_cu, want = (n + 63) / 64;
+                if (blocks > want) blocks = want;
+                const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
+                Stage st(names[fmt][r], sc);
+                if (fmt == 0) {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                } else {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                }
+            }
+        }
     }
     // join_events == nullptr: the caller's stream waits for the side streams (everything of this call is then
     // ordered on `s`).  Otherwise nothing waits: one event per stream is recorded (join_events[0] on `s`,
