@@ -463,7 +463,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     settle_in(in0); settle_in(in1);
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
-        const int p2 = ap2, info = ainfo;
+        const int p2 = ap2, info = __builtin_amdgcn_readfirstlane(ainfo);      // the row's descriptor is the same in every lane: scalar, so that what follows branches
         const int letter = info & 0xff, ic = (info >> 8) & 0xff;
         const bool sink = (info >> 16) & 1;
         const int64_t ro = (int64_t)i * Wp + POA_COL0;
@@ -485,20 +485,16 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
             if (ic > 0) { po = max(po, x.o0); pf = max(pf, x.f0); }
             pred_terms(x, sc, Fa, Oa, Ha);
         }
-        {
-            // second predecessor: evaluated for every row (its registers hold the start row when there is none),
-            // merged only when it exists - no branch around the use of the prefetched registers
+        if (ic > 1) {
+            // second predecessor: its registers are requested for every row (a fixed number of loads per iteration; the
+            // start row stands in when there is none) and used only here, under a scalar branch (258 instead of 265 ms on
+            // 'large'; branching on "the predecessor is the previous row" as well, instead of selecting, gave part of that back)
             const PoaPredIn &x = reg1 ? last : in1;
-            const bool two = ic > 1;
-            if (two) { po = max(po, x.o0); pf = max(pf, x.f0); }
+            po = max(po, x.o0); pf = max(pf, x.f0);
             v2s F2[4], O2[4], H2[4];
             pred_terms(x, sc, F2, O2, H2);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                Fa[k] = two ? pk_max(Fa[k], F2[k]) : Fa[k];
-                Oa[k] = two ? pk_max(Oa[k], O2[k]) : Oa[k];
-                Ha[k] = two ? pk_max(Ha[k], H2[k]) : Ha[k];
-            }
+            for (int k = 0; k < 4; ++k) { Fa[k] = pk_max(Fa[k], F2[k]); Oa[k] = pk_max(Oa[k], O2[k]); Ha[k] = pk_max(Ha[k], H2[k]); }
         }
         // ---- request the inputs of row r+1 now: before this row's stores, behind those of the rows before.
         // Always both predecessors (the start row stands in for a missing one; a predecessor that is this very
