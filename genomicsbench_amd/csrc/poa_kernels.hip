@@ -850,6 +850,7 @@ constexpr int POA_LDS_STACK16 = 256;       // largest DFS stack kept in LDS (swe
 
 #ifdef GBX_POA_PHASE_STATS
 __device__ unsigned long long g_topo_cycles, g_topo_iters, g_topo_visits, g_topo_blocks, g_topo_dfs_cycles, g_topo_roots, g_topo_trivial;
+__device__ unsigned long long g_add_serial_cycles, g_add_unsettled, g_add_lanepar_cycles, g_add_head_cycles;
 #endif
 // LDS arrays of the topological sort, persistent per wavefront for the life of a window
 constexpr int POA_REC_SHORTS = 13;          // record of a node in the block cache: 4 in-edge sources, 8 aligned slots, counts
@@ -1198,6 +1199,12 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
             m = __ballot(unk);
         }
     }
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long ts_ = __builtin_readcyclecounter(), t_ser_ = 0, t_par_ = 0, n_uns_ = 0, t_head_ = 0;
+#define ADD_LAP(x) { const unsigned long long tn_ = __builtin_readcyclecounter(); x += tn_ - ts_; ts_ = tn_; }
+#else
+#define ADD_LAP(x)
+#endif
     const int np = g.n_path;
     if (np == 0) {
         poa_add_chain_wave(g, seq, 0, len);
@@ -1210,96 +1217,121 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
     int head = before == g.n_nodes ? -1 : g.n_nodes - 1;
     const int tail = poa_add_chain_wave(g, seq, last_pos + 1, len);
     int prev_w = head == -1 ? 0 : 1;
-    for (int t0 = np - 1; t0 >= 0; t0 -= 64) {                 // forward order = stored order reversed
+    bool head_new = head != -1;                                // head was made during this alignment and has no out-edge yet (here: the end of the fresh chain)
+    ADD_LAP(t_head_)
+    // The path, 64 elements at a time, ALL of it by the lanes in parallel (a lane = a path element).  What makes that
+    // possible: the nodes along a path are distinct, an element's edge appends to (or bumps a weight in) the out-list of
+    // the element before and the in-list of its own node only, and the aligned-node lists an element extends are those
+    // of its own column - no two elements touch the same list, so the order in which the serial Graph::add_alignment
+    // walks them does not show in the result, except in the ids of new nodes, which are handed out in path order by a
+    // prefix count.  A lane never reads back what another lane has just written: lists of nodes made here are known to
+    // be empty.  (The loop over the elements a lane-parallel pre-pass could not settle - 37 % of them, 6 000 clocks each,
+    // two dependent memory round trips - was 11.5 % of the kernel's wave clocks.)
+    for (int t0 = np - 1; t0 >= 0; t0 -= 64) {                 // forward order = stored order reversed: lane 0 first
         const int t = t0 - lane;
         const int pos = t >= 0 ? g.path_pos[t] : -1;
         const int node = t >= 0 ? g.path_node[t] : -1;
-        const int scode = pos >= 0 ? (int)g.coder[seq[pos]] : -1;
+        const bool valid = pos >= 0;
+        const int scode = valid ? (int)g.coder[seq[pos]] : -1;
         const int ncode = node >= 0 ? (int)g.code[node] : -1;
-        // Lane-parallel part.  Most elements land on an existing node whose predecessor element did too, over an
-        // edge that already exists: all that add_edge does then is add 2 to the edge's weight (distinct edges, so
-        // the lanes do not collide, and weights commute with everything the serial loop below appends).  Lane k
-        // looks its edge up among the first four out-edges of its predecessor's node; what it cannot settle
-        // (new nodes, new or cold edges, the first element of a chunk) stays with the serial loop.
-        unsigned long long settled;
-        {
-            const bool valid_l = pos >= 0;
-            const int simple = valid_l && node >= 0 && ncode == scode;
-            const unsigned long long vb = __ballot(valid_l) & ((1ull << lane) - 1);
-            const int prev_l = vb ? 63 - __builtin_clzll(vb) : lane;
-            const int b = __builtin_amdgcn_ds_bpermute(prev_l << 2, node);
-            const int simple_prev = __builtin_amdgcn_ds_bpermute(prev_l << 2, simple);
-            bool done = false;
-            if (simple && vb && simple_prev) {
-                const int oc = g.out_cnt[b];
-                const PoaInt4 d4 = *(const PoaInt4 *)(g.out_dst + (int64_t)b * 4);
-                int kk = -1;
+        // ---- the element's node: the path's, an aligned one with the element's letter, or a new one
+        int id = node;
+        bool fresh = valid && node < 0;
+        const bool mism = valid && node >= 0 && ncode != scode;
+        int ac = 0;
+        PoaInt4 m0, m1;
+        m0.v[0] = m0.v[1] = m0.v[2] = m0.v[3] = m1.v[0] = m1.v[1] = m1.v[2] = m1.v[3] = 0;
+        int mcnt[POA_ALN_STRIDE];                               // aln_cnt of the aligned nodes (their lists grow when a new node joins the column)
+        if (mism) {
+            ac = g.aln_cnt[node];
+            m0 = *(const PoaInt4 *)(g.aln + (int64_t)node * POA_ALN_STRIDE);
+            m1 = *(const PoaInt4 *)(g.aln + (int64_t)node * POA_ALN_STRIDE + 4);
+            int mcode[POA_ALN_STRIDE];
 #pragma unroll
-                for (int z = 3; z >= 0; --z) if (z < oc && d4.v[z] == node) kk = z;
-                if (kk >= 0) {
-                    const int sl = g.out_slot[(int64_t)b * 4 + kk];
-                    int32_t *wp = sl < 4 ? g.in_wt + (int64_t)node * 4 + sl : g.in_wt_x + (int64_t)node * (g.deg - 4) + (sl - 4);
-                    *wp += 2;
-                    done = true;
+            for (int z = 0; z < POA_ALN_STRIDE; ++z) {
+                const int a = z < 4 ? m0.v[z] : m1.v[z - 4];
+                mcode[z] = z < ac ? (int)g.code[a] : -1;
+                mcnt[z] = z < ac ? (int)g.aln_cnt[a] : 0;
+            }
+            int found = -1;
+#pragma unroll
+            for (int z = POA_ALN_STRIDE - 1; z >= 0; --z) if (z < ac && mcode[z] == scode) found = z < 4 ? m0.v[z] : m1.v[z - 4];      // the first in list order
+            if (found >= 0) id = found;
+            else fresh = true;
+        }
+        const bool joins = mism && fresh;                       // a new node that takes a place in the path node's column
+        // ---- ids of the new nodes, in path order
+        const unsigned long long fm = __ballot(fresh);
+        const int n_new = __builtin_popcountll(fm);
+        if (g.n_nodes + n_new > g.ncap) { g.err |= POA_ERR_NODES; return; }
+        if (__ballot(joins && ac + 1 > POA_ALN_CAP)) { g.err |= POA_ERR_LETTERS; return; }
+        if (fresh) {
+            id = g.n_nodes + __builtin_popcountll(fm & ((1ull << lane) - 1));
+            g.code[id] = (uint8_t)scode;
+            g.in_cnt[id] = 0; g.out_cnt[id] = 0; g.aln_cnt[id] = joins ? (uint8_t)(ac + 1) : (uint8_t)0;
+        }
+        g.n_nodes += n_new;
+        if (joins) {
+#pragma unroll
+            for (int z = 0; z < POA_ALN_STRIDE; ++z) {
+                if (z < ac) {
+                    const int a = z < 4 ? m0.v[z] : m1.v[z - 4];
+                    g.aln[(int64_t)id * POA_ALN_STRIDE + z] = a;
+                    g.aln[(int64_t)a * POA_ALN_STRIDE + mcnt[z]] = id; g.aln_cnt[a] = (uint8_t)(mcnt[z] + 1);
+                    if (T.use) T.st8[a] = (unsigned char)(T.st8[a] | POA_ST_CHANGED);
                 }
             }
-            settled = __ballot(done);
+            g.aln[(int64_t)id * POA_ALN_STRIDE + ac] = node;
+            g.aln[(int64_t)node * POA_ALN_STRIDE + ac] = id; g.aln_cnt[node] = (uint8_t)(ac + 1);
+            if (T.use) T.st8[node] = (unsigned char)(T.st8[node] | POA_ST_CHANGED);
         }
-        // The serial loop only visits what the lanes could not settle (a seventh of the elements): the element before an
-        // unsettled one is either the one this loop handled last (its node is `last_id`) or a settled one, whose node is the
-        // path's node.
-        const unsigned long long vmask = __ballot(pos >= 0);
-        unsigned long long todo = vmask & ~settled;
-        int last_k = -1, last_id = -1;
-        while (todo) {
-            const int k = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            if (g.err) return;
-            const unsigned long long before_k = vmask & ((1ull << k) - 1);
-            if (before_k) {
-                const int pk = 63 - __builtin_clzll(before_k);
-                head = pk == last_k ? last_id : rl(node, pk);
-                prev_w = 1;
+#ifdef GBX_POA_PHASE_STATS
+        n_uns_ += (unsigned long long)__builtin_popcountll(__ballot(valid));
+#endif
+        ADD_LAP(t_par_)
+        // ---- the edge from the element before (the last element of the chunk before, or the fresh chain, for the first one)
+        const unsigned long long vmask = __ballot(valid);
+        const unsigned long long vb = vmask & ((1ull << lane) - 1);
+        const int prev_l = vb ? 63 - __builtin_clzll(vb) : lane;
+        int pid = __builtin_amdgcn_ds_bpermute(prev_l << 2, id);
+        int pfresh = __builtin_amdgcn_ds_bpermute(prev_l << 2, (int)fresh);
+        if (!vb) { pid = head; pfresh = (int)head_new; }
+        bool deg_err = false;
+        if (valid && pid != -1) {
+            const int oc = pfresh ? 0 : (int)g.out_cnt[pid];
+            const int ic = fresh ? 0 : (int)g.in_cnt[id];
+            int kk = -1;
+            if (oc > 0 && !fresh) {
+                const PoaInt4 d4 = *(const PoaInt4 *)(g.out_dst + (int64_t)pid * 4);
+#pragma unroll
+                for (int z = 3; z >= 0; --z) if (z < oc && d4.v[z] == id) kk = z;
+                for (int z = 4; kk < 0 && z < oc; ++z) if (g.out_dst_x[(int64_t)pid * (g.deg - 4) + (z - 4)] == id) kk = z;
             }
-            const int node_k = rl(node, k), code = rl(scode, k), ncode_k = rl(ncode, k);
-            int id;
-            if (node_k == -1) {
-                id = poa_add_node(g, code);
-            } else if (ncode_k == code) {
-                id = node_k;
+            if (kk >= 0) {
+                const int sl = PG_OUT_SLOT(g, pid, kk);
+                int32_t *wp = sl < 4 ? g.in_wt + (int64_t)id * 4 + sl : g.in_wt_x + (int64_t)id * (g.deg - 4) + (sl - 4);
+                *wp += 2;
+            } else if (oc >= g.deg || ic >= g.deg) {
+                deg_err = true;
             } else {
-                int found = -1;
-                const int ac = g.aln_cnt[node_k];
-                for (int z = 0; z < ac; ++z) {
-                    const int a = g.aln[node_k * POA_ALN_STRIDE + z];
-                    if (g.code[a] == code) { found = a; break; }
-                }
-                if (found == -1) {
-                    id = poa_add_node(g, code);
-                    if (ac + 1 > POA_ALN_CAP) { g.err |= POA_ERR_LETTERS; }
-                    else {
-                        for (int z = 0; z < ac; ++z) {
-                            const int a = g.aln[node_k * POA_ALN_STRIDE + z];
-                            g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = a; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
-                            g.aln[a * POA_ALN_STRIDE + g.aln_cnt[a]] = id; g.aln_cnt[a] = (uint8_t)(g.aln_cnt[a] + 1);
-                            if (T.use && lane == 0) T.st8[a] = (unsigned char)(T.st8[a] | POA_ST_CHANGED);
-                        }
-                        g.aln[id * POA_ALN_STRIDE + g.aln_cnt[id]] = node_k; g.aln_cnt[id] = (uint8_t)(g.aln_cnt[id] + 1);
-                        g.aln[node_k * POA_ALN_STRIDE + ac] = id; g.aln_cnt[node_k] = (uint8_t)(ac + 1);
-                        if (T.use && lane == 0) T.st8[node_k] = (unsigned char)(T.st8[node_k] | POA_ST_CHANGED);
-                    }
-                } else id = found;
+                PG_OUT_DST(g, pid, oc) = id; PG_OUT_SLOT(g, pid, oc) = (uint8_t)ic; g.out_cnt[pid] = (uint8_t)(oc + 1);
+                PG_IN_SRC(g, id, ic) = pid; PG_IN_WT(g, id, ic) = 2; g.in_cnt[id] = (uint8_t)(ic + 1);
+                if (T.use) T.st8[id] = (unsigned char)(T.st8[id] | POA_ST_CHANGED);
             }
-            if (head != -1) poa_add_edge_wave(g, head, id, prev_w + 1, T.st8, T.use != 0);
-            last_k = k; last_id = id;
         }
+        if (__ballot(deg_err)) { g.err |= POA_ERR_DEGREE; return; }
         if (vmask) {                                            // the chunk's last element is the next chunk's predecessor
             const int lv = 63 - __builtin_clzll(vmask);
-            head = lv == last_k ? last_id : rl(node, lv);
+            head = rl(id, lv);
+            head_new = rl((int)fresh, lv) != 0;
             prev_w = 1;
         }
+        ADD_LAP(t_ser_)
     }
     if (tail != -1) poa_add_edge_wave(g, head, tail, prev_w + 1, T.st8, T.use != 0);
+#ifdef GBX_POA_PHASE_STATS
+    if (lane == 0) { atomicAdd(&g_add_serial_cycles, t_ser_); atomicAdd(&g_add_unsettled, n_uns_); atomicAdd(&g_add_lanepar_cycles, t_par_); atomicAdd(&g_add_head_cycles, t_head_); }
+#endif
     if (g.err) return;
     TOPO_TIMED(g)
 }
@@ -1452,6 +1484,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
         A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;
+        A.cells[14] = g_add_serial_cycles; A.cells[15] = g_add_unsettled; A.cells[16] = g_add_lanepar_cycles; A.cells[17] = g_add_head_cycles;
 #ifdef GBX_POA_TOPO_CHECK
         A.cells[20] = g_topo_mismatch; A.cells[21] = g_topo_inc_sorts; A.cells[22] = g_topo_walked; A.cells[23] = g_topo_blocks_all;
 #endif
