@@ -1484,7 +1484,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
         A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;
-        A.cells[14] = g_add_serial_cycles; A.cells[15] = g_add_unsettled; A.cells[16] = g_add_lanepar_cycles; A.cells[17] = g_add_head_cycles;
+        A.cells[24] = g_add_serial_cycles; A.cells[25] = g_add_unsettled; A.cells[26] = g_add_lanepar_cycles; A.cells[27] = g_add_head_cycles;      // (14-17 are the work lists' counts and cursors)
 #ifdef GBX_POA_TOPO_CHECK
         A.cells[20] = g_topo_mismatch; A.cells[21] = g_topo_inc_sorts; A.cells[22] = g_topo_walked; A.cells[23] = g_topo_blocks_all;
 #endif

@@ -37,7 +37,7 @@ rows, steps = int(c[12]), int(c[13])
 if rows:
     print("DP: %d rows, %.0f wave clocks per row; traceback: %d steps, %.0f clocks per step; add_alignment without the sort: %.0f clocks per path element"
           % (rows, dp / rows, steps, tb / max(steps, 1), (add - topo) / max(steps, 1)))
-ser, uns, par, hd = (int(c[k]) // RUNS for k in (14, 15, 16, 17))
+ser, uns, par, hd = (int(c[k]) // RUNS for k in (24, 25, 26, 27))
 if uns:
     print("add_alignment: letter codes + fresh chains %.1f%% of all wave clocks, nodes of the elements %.1f%%, their edges %.1f%% (%d elements with a base, %.0f clocks each for both)"
           % (100 * hd / tot, 100 * par / tot, 100 * ser / tot, uns, (par + ser) / uns))
