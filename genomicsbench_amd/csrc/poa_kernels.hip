@@ -583,6 +583,9 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     }
 }
 
+#ifdef GBX_POA_PHASE_STATS
+__device__ unsigned long long g_tb_fast, g_tb_slow, g_tb_fill;
+#endif
 // ---- traceback for the pipelined DP: E and Q are not stored ---------------------------------------
 // The pipelined DP writes H, F, O only (3 of the 5 planes: -40 % of the stores).  The traceback needs E and Q
 // of a row only where the path moves left (an insertion), a few per cent of its steps; there the row's E, Q
@@ -677,7 +680,13 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     // bj-8..bj-1, one cell per lane, with the row's descriptor and the column's letter): a run of diagonal moves
     // to first predecessors is served from registers, one gather per 4-5 steps instead of one round trip each.
     int bi = -(1 << 20), bj = -(1 << 20), bH = 0, bP0 = 0, bInfo = 0, bNode = 0, bS = 0;
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long tb_fast_ = 0, tb_slow_ = 0, tb_fill_ = 0;
+#endif
     auto fill_block = [&](int oi, int oj) {
+#ifdef GBX_POA_PHASE_STATS
+        ++tb_fill_;
+#endif
         bi = oi; bj = oj;
         const int row = max(oi - 1 - (lane >> 3), 0), col = max(oj - 1 - (lane & 7), 0);
         bH = PG_AT(M.H, row, col);
@@ -695,6 +704,9 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
                 const int hd = __builtin_amdgcn_readlane(bH, L);
                 const int mc = (d_info & 0xff) == __builtin_amdgcn_readlane(bS, L) ? S.m : S.n;
                 if (Hcur == hd + mc) {
+#ifdef GBX_POA_PHASE_STATS
+                    ++tb_fast_;
+#endif
                     PG_PUSH(d_node, j - 1);
                     i = p0f; j = j - 1; Hcur = hd;
                     d_p0 = __builtin_amdgcn_readlane(bP0, L); d_info = __builtin_amdgcn_readlane(bInfo, L);
@@ -704,6 +716,9 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
                 }
             }
         }
+#ifdef GBX_POA_PHASE_STATS
+        ++tb_slow_;
+#endif
         const int Hij = h_known ? Hcur : PG_AT(M.H, i, j);
         bool found = false, ext_left = false, ext_up = false;
         int node = -1, ic = 0, p0 = 0;
@@ -787,6 +802,9 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     }
 #undef PG_AT
 #undef PG_PUSH
+#ifdef GBX_POA_PHASE_STATS
+    if (lane == 0) { atomicAdd(&g_tb_fast, tb_fast_); atomicAdd(&g_tb_slow, tb_slow_); atomicAdd(&g_tb_fill, tb_fill_); }
+#endif
     if (np & 63) path_flush(np & ~63, np & 63);
     g.n_path = np <= g.aln_path_cap ? np : 0;
     g.path_lo = plo; g.path_hi = phi;
@@ -1484,6 +1502,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     __syncthreads();
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
         A.cells[5] = g_topo_cycles; A.cells[6] = g_topo_iters; A.cells[7] = g_topo_visits; A.cells[8] = g_topo_blocks; A.cells[9] = g_topo_dfs_cycles; A.cells[10] = g_topo_roots; A.cells[11] = g_topo_trivial;
+        A.cells[28] = g_tb_fast; A.cells[29] = g_tb_slow; A.cells[30] = g_tb_fill;
         A.cells[24] = g_add_serial_cycles; A.cells[25] = g_add_unsettled; A.cells[26] = g_add_lanepar_cycles; A.cells[27] = g_add_head_cycles;      // (14-17 are the work lists' counts and cursors)
 #ifdef GBX_POA_TOPO_CHECK
         A.cells[20] = g_topo_mismatch; A.cells[21] = g_topo_inc_sorts; A.cells[22] = g_topo_walked; A.cells[23] = g_topo_blocks_all;

@@ -41,3 +41,6 @@ ser, uns, par, hd = (int(c[k]) // RUNS for k in (24, 25, 26, 27))
 if uns:
     print("add_alignment: letter codes + fresh chains %.1f%% of all wave clocks, nodes of the elements %.1f%%, their edges %.1f%% (%d elements with a base, %.0f clocks each for both)"
           % (100 * hd / tot, 100 * par / tot, 100 * ser / tot, uns, (par + ser) / uns))
+fast, slow, fill = (int(c[k]) // RUNS for k in (28, 29, 30))
+if fast + slow:
+    print("traceback: %.1f%% of the steps served from the 8x8 block, %.1f%% through the general path; %.2f block fills per step" % (100 * fast / (fast + slow), 100 * slow / (fast + slow), fill / (fast + slow)))
