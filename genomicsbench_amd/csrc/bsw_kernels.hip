@@ -1183,8 +1183,45 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         side_lock = std::unique_lock<std::mutex>(ss->mu);
         if ((rc = ss->fork(s))) return rc;
     }
-    // The row-kernel classes first: with the lane path on they hold next to nothing (what the lane kernels cannot take),
-    // and twenty near-empty launches at the end of the streams were 0.1 ms of tail.
+    if (dev.lane_on) {
+        // one launch per format and LDS class, spread over the streams; grids = resident wavefronts
+        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
+                                                    {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
+        // Order (kernel timeline of 'large', rocprofv3 --kernel-trace): a launch has to be given its LDS before its wavefronts
+        // can see that their list is empty, and behind working launches that takes until they drain - a near-empty launch must
+        // never sit in a stream in front of a working one.  For short reads the wide launches and the longest compact range
+        // are the near-empty ones: the four shorter compact ranges start first, one per stream, then the longest, then the
+        // wide ones (an empty wide launch between two compact ones held its stream up for a millisecond; the empty longest
+        // range in front of the shortest made that one run alone at the end, 0.8 ms).
+        for (int ord = 0; ord < 2 * LANE_NRANGE; ++ord) {
+            {
+                const int fmt = ord < LANE_NRANGE ? 0 : 1;
+                const int oi = ord % LANE_NRANGE;
+                const int r = fmt == 0 ? (oi == LANE_NRANGE - 1 ? LANE_NRANGE - 1 : LANE_NRANGE - 2 - oi) : LANE_NRANGE - 1 - oi;
+                const int nl = fmt == 0 && oi == LANE_NRANGE - 1 ? LANE_NRANGE - 1 : oi + 1;      // stream ordinal
+                const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
+                const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
+                // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
+                // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
+                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
+                int per_cu = (int)((size_t)160 * 1024 / lds);
+                if (per_cu > 16) per_cu = 16;
+                const int sk = (nl - 1) & 3;
+                hipStream_t sc = serial || sk == 0 ? s : ss->side[sk - 1];
+                int64_t blocks = (int64_t)cus * per_cu, want = (n + 63) / 64;
+                if (blocks > want) blocks = want;
+                const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
+                Stage st(names[fmt][r], sc);
+                if (fmt == 0) {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                } else {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                }
+            }
+        }
+    }
     int launched = 0;
     for (int c = 0; c < NCLS - 1; ++c) {
         if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
@@ -1209,40 +1246,6 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         }
         Stage st(k->name, sc);
         hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
-    }
-    if (dev.lane_on) {
-        // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
-        static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
-                                                    {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
-        // The wide launches go first, while the chip is empty: a launch has to be given its LDS before its wavefronts can
-        // see that their list is empty (the usual case for short reads), and behind a working compact launch that wait
-        // held up the stream for up to a millisecond (6.36 -> 6.03 ms on 'large').
-        for (int fmt = 1; fmt >= 0; --fmt) {
-            int nl = 0;
-            for (int r = LANE_NRANGE - 1; r >= 0; --r) {
-                const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
-                ++nl;                                          // the range's ordinal, longest first
-                const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
-                // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
-                // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
-                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
-                int per_cu = (int)((size_t)160 * 1024 / lds);
-                if (per_cu > 16) per_cu = 16;
-                const int sk = (nl - 1) & 3;
-                hipStream_t sc = serial || sk == 0 ? s : ss->side[sk - 1];
-                int64_t blocks = (int64_t)cus * per_cu, want = (n + 63) / 64;
-                if (blocks > want) blocks = want;
-                const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
-                Stage st(names[fmt][r], sc);
-                if (fmt == 0) {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                } else {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                }
-            }
-        }
     }
     // join_events == nullptr: the caller's stream waits for the side streams (everything of this call is then
     // ordered on `s`).  Otherwise nothing waits: one event per stream is recorded (join_events[0] on `s`,
