@@ -1144,13 +1144,31 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         const bool want = lane_env ? atoi(lane_env) != 0 : n >= lane_min;
         dev.lane_on = dev.lane_on && want ? 1 : 0;
     }
+    // the classes are independent and every kernel ends in a tail of a few long pairs: they go to four
+    // streams so that a tail overlaps the next class (GBX_BSW_SERIAL=1 keeps them on the caller's stream)
+    static const bool serial = getenv("GBX_BSW_SERIAL") != nullptr;
+    SideStreams *ss = nullptr;
+    std::unique_lock<std::mutex> side_lock;
+    if (!serial) {
+        if ((rc = side_streams(&ss))) return rc;
+        side_lock = std::unique_lock<std::mutex>(ss->mu);
+    }
+    // The lane sort (0.3 ms on 'large': two passes of scattered atomics) runs on a side stream of its own, beside
+    // classify and the row-kernel classes on the caller's stream, which do not need it; the lane launches wait for it.
+    const bool sort_aside = dev.lane_on && !serial;
     if (dev.lane_on) {
         GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
-        Stage st("bsw_lane_sort", s);
+        hipStream_t so = s;
+        if (sort_aside) {
+            if ((rc = ss->fork(s))) return rc;
+            so = ss->side[SideStreams::N - 1];
+        }
+        Stage st("bsw_lane_sort", so);
         const int sblocks = (int)((n + 255) / 256);
-        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, s, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_lane_scan_kernel, dim3(1), dim3(1024), 0, s, W);
-        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, s, dev, P, n, W, 1);
+        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 0);
+        hipLaunchKernelGGL(bsw_lane_scan_kernel, dim3(1), dim3(1024), 0, so, W);
+        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 1);
+        if (sort_aside) GBX_HIP(hipEventRecord(ss->ev_aux, so));
     }
     const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
@@ -1173,33 +1191,50 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     // round-robin over the longest-first list starts every group on the longest pairs together
     const bool sym = dev.oe_ins == dev.oe_del;
     const RowShape *shapes = class_shapes();
-    // the classes are independent and every kernel ends in a tail of a few long pairs: they go to four
-    // streams so that a tail overlaps the next class (GBX_BSW_SERIAL=1 keeps them on the caller's stream)
-    static const bool serial = getenv("GBX_BSW_SERIAL") != nullptr;
-    SideStreams *ss = nullptr;
-    std::unique_lock<std::mutex> side_lock;
-    if (!serial) {
-        if ((rc = side_streams(&ss))) return rc;
-        side_lock = std::unique_lock<std::mutex>(ss->mu);
-        if ((rc = ss->fork(s))) return rc;
+    if (!serial && !sort_aside && (rc = ss->fork(s))) return rc;
+    // The row-kernel classes first.  With the lane path on they hold next to nothing (what the lane kernels cannot take):
+    // twenty near-empty launches, all on the caller's stream, in the shadow of the lane sort.
+    int launched = 0;
+    for (int c = 0; c < NCLS - 1; ++c) {
+        if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
+        // Four kernel streams when the inputs are resident.  The host pipeline (join_events) uses three: the
+        // runtime maps streams onto four hardware queues, and with all four busy with class kernels its copy
+        // stream shares one and the uploads stall behind kernels (measured; GBX_BSW_KSTREAMS overrides).
+        static const int nk_env = getenv("GBX_BSW_KSTREAMS") ? atoi(getenv("GBX_BSW_KSTREAMS")) : 0;
+        const int nk = nk_env > 0 ? nk_env : join_events ? 3 : 4;
+        const int lane_k = mode ? launched++ % (nk > 4 ? 4 : nk) : nk >= 4 ? (c & 3) : c % nk;
+        hipStream_t sc = serial || sort_aside || lane_k == 0 ? s : ss->side[lane_k - 1];
+        RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
+        if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
+        int bpc = k->bpc[sym].load(std::memory_order_relaxed);
+        if (!bpc) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k->fn[sym], 256, 0) != hipSuccess || q < 1) {
+                (void)hipGetLastError();
+                q = 2;
+            }
+            bpc = q > 8 ? 8 : q;
+            k->bpc[sym].store(bpc, std::memory_order_relaxed);
+        }
+        Stage st(k->name, sc);
+        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
+    }
+    if (sort_aside) {                                          // the lane launches need the sorted lists (the sort's own stream has them in order)
+        GBX_HIP(hipStreamWaitEvent(s, ss->ev_aux, 0));
+        for (int k = 0; k + 1 < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_aux, 0));
     }
     if (dev.lane_on) {
-        // one launch per format and LDS class, spread over the streams; grids = resident wavefronts
+        // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
         static const char *names[2][LANE_NRANGE] = {{"bsw_lane_c47", "bsw_lane_c79", "bsw_lane_c99", "bsw_lane_c135", "bsw_lane_c159"},
                                                     {"bsw_lane_w39", "bsw_lane_w79", "bsw_lane_w103", "bsw_lane_w127", "bsw_lane_w159"}};
-        // Order (kernel timeline of 'large', rocprofv3 --kernel-trace): a launch has to be given its LDS before its wavefronts
-        // can see that their list is empty, and behind working launches that takes until they drain - a near-empty launch must
-        // never sit in a stream in front of a working one.  For short reads the wide launches and the longest compact range
-        // are the near-empty ones: the four shorter compact ranges start first, one per stream, then the longest, then the
-        // wide ones (an empty wide launch between two compact ones held its stream up for a millisecond; the empty longest
-        // range in front of the shortest made that one run alone at the end, 0.8 ms).
-        for (int ord = 0; ord < 2 * LANE_NRANGE; ++ord) {
-            {
-                const int fmt = ord < LANE_NRANGE ? 0 : 1;
-                const int oi = ord % LANE_NRANGE;
-                const int r = fmt == 0 ? (oi == LANE_NRANGE - 1 ? LANE_NRANGE - 1 : LANE_NRANGE - 2 - oi) : LANE_NRANGE - 1 - oi;
-                const int nl = fmt == 0 && oi == LANE_NRANGE - 1 ? LANE_NRANGE - 1 : oi + 1;      // stream ordinal
+        // The wide launches go first, while the chip is empty: a launch has to be given its LDS before its wavefronts can
+        // see that their list is empty (the usual case for short reads), and behind a working compact launch that wait
+        // held up the stream for up to a millisecond (6.36 -> 6.03 ms on 'large').
+        for (int fmt = 1; fmt >= 0; --fmt) {
+            int nl = 0;
+            for (int r = LANE_NRANGE - 1; r >= 0; --r) {
                 const int qlo = r ? LANE_RANGE_HI[fmt][r - 1] + 1 : 1, qhi = LANE_RANGE_HI[fmt][r];
+                ++nl;                                          // the range's ordinal, longest first
                 const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
                 // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
                 // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
@@ -1221,31 +1256,6 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                 }
             }
         }
-    }
-    int launched = 0;
-    for (int c = 0; c < NCLS - 1; ++c) {
-        if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
-        // Four kernel streams when the inputs are resident.  The host pipeline (join_events) uses three: the
-        // runtime maps streams onto four hardware queues, and with all four busy with class kernels its copy
-        // stream shares one and the uploads stall behind kernels (measured; GBX_BSW_KSTREAMS overrides).
-        static const int nk_env = getenv("GBX_BSW_KSTREAMS") ? atoi(getenv("GBX_BSW_KSTREAMS")) : 0;
-        const int nk = nk_env > 0 ? nk_env : join_events ? 3 : 4;
-        const int lane_k = mode ? launched++ % (nk > 4 ? 4 : nk) : nk >= 4 ? (c & 3) : c % nk;
-        hipStream_t sc = serial || lane_k == 0 ? s : ss->side[lane_k - 1];
-        RowKernel *k = find_row_kernel(shapes[c].lpp, shapes[c].cpl);
-        if (!k) { set_error("bsw: no row kernel for class %d", c); return GBX_ERR_UNSUPPORTED; }
-        int bpc = k->bpc[sym].load(std::memory_order_relaxed);
-        if (!bpc) {
-            int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k->fn[sym], 256, 0) != hipSuccess || q < 1) {
-                (void)hipGetLastError();
-                q = 2;
-            }
-            bpc = q > 8 ? 8 : q;
-            k->bpc[sym].store(bpc, std::memory_order_relaxed);
-        }
-        Stage st(k->name, sc);
-        hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
     }
     // join_events == nullptr: the caller's stream waits for the side streams (everything of this call is then
     // ordered on `s`).  Otherwise nothing waits: one event per stream is recorded (join_events[0] on `s`,

@@ -110,6 +110,7 @@ int side_streams(SideStreams **out)
     for (auto &m : made) if (m.first == dev) { *out = m.second; return GBX_OK; }
     SideStreams *ss = new SideStreams();
     GBX_HIP(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming));
+    GBX_HIP(hipEventCreateWithFlags(&ss->ev_aux, hipEventDisableTiming));
     for (int k = 0; k < SideStreams::N; ++k) {
         GBX_HIP(hipStreamCreateWithFlags(&ss->side[k], hipStreamNonBlocking));
         GBX_HIP(hipEventCreateWithFlags(&ss->ev_join[k], hipEventDisableTiming));

@@ -48,7 +48,7 @@ struct Stage {
 struct SideStreams {
     static constexpr int N = 3;
     hipStream_t side[N];
-    hipEvent_t ev_fork, ev_join[N];
+    hipEvent_t ev_fork, ev_join[N], ev_aux;      // ev_aux: a point on one side stream the others wait for (bsw: the lane sort)
     std::mutex mu;
     int fork(hipStream_t main);
     int join(hipStream_t main);
