@@ -37,8 +37,14 @@ while time.time() < t_end:
                                                   e_ins=int(rng.integers(1, 4)), zdrop=int(rng.choice([0, 20, 100])), w=int(rng.choice([3, 30, 100, 400])),
                                                   mat=fill_scmat(int(rng.integers(1, 4)), int(rng.integers(1, 6)), -int(rng.integers(0, 3))))
         p = bsw_params(**kw)
-        ok = np.array_equal(extend_host(p, b), O.bsw_oracle(p, b, 8))
-        what = "n=%d adversarial=%s kw=%s" % (n, adv, kw)
+        lane = rng.random() < 0.5                                # the lane kernels (large jobs take them by default) on this job too
+        if lane:
+            os.environ["GBX_BSW_LANE"] = "1"
+        try:
+            ok = np.array_equal(extend_host(p, b), O.bsw_oracle(p, b, 8))
+        finally:
+            os.environ.pop("GBX_BSW_LANE", None)
+        what = "n=%d adversarial=%s lane=%s kw=%s" % (n, adv, lane, kw)
     elif k == "chain":
         nc = int(rng.choice([1, 3, 40, 300]))
         real = bool(rng.random() < 0.5)                          # minimap2's strand / reference structure: calls cut into jobs
