@@ -72,6 +72,9 @@ def _declare(L):
     L.gbx_device_count.restype = C.c_int
     L.gbx_set_device.argtypes = [C.c_int]
     L.gbx_device_name.argtypes = [C.c_char_p, sz]
+    L.gbx_host_set_devices.argtypes = [C.c_int]
+    L.gbx_host_devices.argtypes = []
+    L.gbx_split_by_cost.argtypes = [i64, vp, C.c_int, vp]
     L.gbx_host_prepare.argtypes = []
     L.gbx_host_release.argtypes = []
     L.gbx_host_reserve.argtypes = [sz]

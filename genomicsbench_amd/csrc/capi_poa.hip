@@ -1,0 +1,303 @@
+// capi_poa.hip — poa entries of the C-ABI (include/gbx.h).
+#include "capi_common.h"
+
+using namespace gbx;
+
+extern "C" {
+
+/* --------------------------------------------------------------------- poa */
+void gbx_poa_default_params(gbx_poa_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->m = 2; p->n = -4; p->g = -6; p->e = -2; p->q = -25; p->c = -1;   /* msa_spoa_omp.cpp:156-162,184 */
+}
+
+int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int32_t *seq_len, gbx_poa_plan *plan)
+{
+    if (n_windows < 0 || !plan || (n_windows > 0 && (!win_first_seq || !seq_len))) {
+        set_error("gbx_poa_plan_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    int lmax = 1, smax = 1;
+    int64_t bmax = 1, n_long = 0;
+    for (int64_t w = 0; w < n_windows; ++w) {
+        const int64_t a = win_first_seq[w], b = win_first_seq[w + 1];
+        if (b < a) { set_error("gbx_poa_plan_host: win_first_seq not monotone at window %lld", (long long)w); return GBX_ERR_ARG; }
+        if (b - a > GBX_POA_MAX_SEQS_PER_WINDOW) {
+            set_error("gbx_poa_plan_host: window %lld has more than %d sequences", (long long)w, GBX_POA_MAX_SEQS_PER_WINDOW);
+            return GBX_ERR_UNSUPPORTED;
+        }
+        int64_t bases = 0;
+        bool is_long = false;
+        for (int64_t s = a; s < b; ++s) {
+            if (seq_len[s] < 0) { set_error("gbx_poa_plan_host: negative sequence length"); return GBX_ERR_ARG; }
+            if (seq_len[s] > lmax) lmax = seq_len[s];
+            if (seq_len[s] > POA_PIPE_MAXLEN) is_long = true;
+            bases += seq_len[s];
+        }
+        if (is_long) ++n_long;
+        if (b - a > smax) smax = (int)(b - a);
+        if (bases > bmax) bmax = bases;
+    }
+    if (n_long > 0x7fffffff) { set_error("gbx_poa_plan_host: too many windows"); return GBX_ERR_UNSUPPORTED; }
+    plan->max_seq_len = lmax;
+    plan->max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);     /* multiple of 4: 16-byte aligned edge rows */
+    int nf = 6;                                            /* typical windows stay below ~3.6x the read length */
+    if (const char *e = getenv("GBX_POA_NODE_FACTOR")) { const int v = atoi(e); if (v >= 2 && v <= 16) nf = v; }   /* tuning aid */
+    int64_t cap = (int64_t)nf * lmax + 256;
+    if (bmax + 8 < cap) cap = bmax + 8;
+    plan->node_cap = (int32_t)cap;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    else (void)hipGetLastError();
+    const int64_t resident = (int64_t)cus * poa_waves_per_cu(plan->node_cap);   /* one window per resident wavefront */
+    const int64_t n_main = n_windows - n_long;
+    plan->n_slots = (int32_t)(n_main < resident ? n_main : resident);
+    plan->n_long_windows = (int32_t)n_long;
+    plan->long_slots = (int32_t)(n_long < resident ? n_long : resident);
+    plan->n_windows = n_windows;
+    return GBX_OK;
+}
+
+size_t gbx_poa_workspace_bytes(const gbx_poa_plan *plan)
+{
+    if (!plan) return 0;
+    return poa_workspace_bytes(plan);
+}
+
+int gbx_poa_cells(const gbx_poa_plan *plan, const void *d_work, int64_t *cells, void *stream)
+{
+    if (!plan || !d_work || !cells) { set_error("gbx_poa_cells: null pointer"); return GBX_ERR_ARG; }
+    return poa_read_cells(d_work, poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len, false) * (size_t)(plan->n_slots > 0 ? plan->n_slots : 0),
+                          cells, (hipStream_t)stream);
+}
+
+/* development aid (scripts/dbg_poa_phases.py): byte offset of the 32-counter block inside a poa workspace */
+size_t gbx_debug_poa_counter_offset(const gbx_poa_plan *plan)
+{
+    return poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len, false) * (size_t)(plan->n_slots > 0 ? plan->n_slots : 0);
+}
+
+int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows,
+                             const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
+                             const char *d_arena, char *d_cons, int32_t *d_cons_len, int32_t *d_status,
+                             int64_t cons_stride, void *d_work, size_t work_bytes, void *stream)
+{
+    if (!p || !plan || n_windows < 0 || cons_stride <= 0) { set_error("gbx_poa_consensus_device: bad argument"); return GBX_ERR_ARG; }
+    if (n_windows == 0) return GBX_OK;
+    if (!d_win_first_seq || !d_seq_off || !d_seq_len || !d_arena || !d_cons || !d_cons_len || !d_status || !d_work) {
+        set_error("gbx_poa_consensus_device: null pointer");
+        return GBX_ERR_ARG;
+    }
+    int rc = require_device();
+    if (rc) return rc;
+    return poa_launch(p, plan, n_windows, d_win_first_seq, d_seq_off, d_seq_len, (const uint8_t *)d_arena, (uint8_t *)d_cons, d_cons_len,
+                      d_status, cons_stride, d_work, work_bytes, (hipStream_t)stream);
+}
+
+// One device (the calling thread's current one).  win_base / seq_base = indices of window 0 / sequence 0 in the caller's job
+// (error texts only).
+static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                        int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                        const char *arena, int64_t arena_bytes,
+                        char *cons, int32_t *cons_len, int64_t cons_stride, int64_t win_base = 0, int64_t seq_base = 0)
+{
+    RoctxRange range_("gbx_poa_consensus_host");
+    if (!p || n_windows < 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0) {
+        set_error("gbx_poa_consensus_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    if (n_windows == 0) return GBX_OK;
+    if (!win_first_seq || !seq_off || !seq_len || !arena || !cons || !cons_len) {
+        set_error("gbx_poa_consensus_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    if (win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs) {
+        set_error("gbx_poa_consensus_host: win_first_seq must span [0, n_seqs]");
+        return GBX_ERR_ARG;
+    }
+    for (int64_t s = 0; s < n_seqs; ++s)
+        if (seq_len[s] < 0 || seq_off[s] < 0 || seq_off[s] + seq_len[s] > arena_bytes) {
+            set_error("gbx_poa_consensus_host: sequence %lld lies outside the arena", (long long)(seq_base + s));
+            return GBX_ERR_ARG;
+        }
+    int rc = require_device();
+    if (rc) return rc;
+    gbx_poa_plan plan;
+    if ((rc = gbx_poa_plan_host(n_windows, win_first_seq, seq_len, &plan))) return rc;
+    const size_t wb = gbx_poa_workspace_bytes(&plan);
+    const bool trace = getenv("GBX_HOST_TRACE") != nullptr;
+    const double t_begin = wall_s();
+    auto mark = [&](const char *what) { if (trace) fprintf(stderr, "[gbx poa host] %9.3f ms %s\n", (wall_s() - t_begin) * 1e3, what); };
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    DevBuf dwf(L), doff(L), dlen(L), dar(L), dcons(L), dcl(L), dst(L), dw(L);
+    if ((rc = dwf.alloc((n_windows + 1) * 8)) || (rc = doff.alloc(n_seqs * 8)) || (rc = dlen.alloc(n_seqs * 4)) ||
+        (rc = dar.alloc(arena_bytes)) || (rc = dcons.alloc(n_windows * cons_stride)) || (rc = dcl.alloc(n_windows * 4)) ||
+        (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
+        return rc;
+    mark("allocated");
+    std::vector<int32_t> status(n_windows);
+    {
+        HostPipe pipe(lane.l, (size_t)arena_bytes + (size_t)n_seqs * 12 + (size_t)n_windows * 8, false);
+        if ((rc = pipe.prepare(1))) return rc;
+        pipe.stage(0, dwf.p, win_first_seq, (n_windows + 1) * 8);
+        pipe.stage(0, doff.p, seq_off, n_seqs * 8);
+        pipe.stage(0, dlen.p, seq_len, n_seqs * 4);
+        pipe.stage(0, dar.p, arena, arena_bytes);
+        pipe.start();
+        if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        rc = poa_launch(p, &plan, n_windows, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(),
+                        dcons.as<uint8_t>(), dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, dw.p, wb, lane.l->compute);
+            if (rc) return pipe.finish(rc);
+        pipe.fetch(0, cons, dcons.p, n_windows * cons_stride);
+        pipe.fetch(0, cons_len, dcl.p, n_windows * 4);
+        pipe.fetch(0, status.data(), dst.p, n_windows * 4);
+        if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+        mark("kernels queued");
+        if ((rc = pipe.finish())) return rc;
+        mark("results fetched");
+    }
+    // Windows whose graph outgrew the first pass's node capacity (deep or noisy windows; the plan sizes it for the
+    // typical case so that the 'large' job's slots stay small) run again with room for the worst case of exactly
+    // those windows: every base its own node, bounded by what int16 scores admit.  spoa has no such limit
+    // (msa_spoa_omp.cpp:237-252), so only a window that cannot be represented at all fails the call.
+    std::vector<int64_t> redo;
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (status[w] & GBX_POA_ST_NODES) redo.push_back(w);      // (other bits set next to it are re-decided by the second pass)
+    if (!redo.empty()) {
+        std::vector<int64_t> wf(redo.size() + 1, 0), off;
+        std::vector<int32_t> len;
+        int64_t bmax = 1, n_long = 0;
+        int lmax = 1, smax = 1;
+        for (size_t k = 0; k < redo.size(); ++k) {
+            const int64_t a = win_first_seq[redo[k]], b = win_first_seq[redo[k] + 1];
+            int64_t bases = 0;
+            bool is_long = false;
+            for (int64_t sidx = a; sidx < b; ++sidx) {
+                off.push_back(seq_off[sidx]); len.push_back(seq_len[sidx]);
+                bases += seq_len[sidx];
+                if (seq_len[sidx] > lmax) lmax = seq_len[sidx];
+                if (seq_len[sidx] > POA_PIPE_MAXLEN) is_long = true;
+            }
+            if (is_long) ++n_long;
+            if (b - a > smax) smax = (int)(b - a);
+            if (bases > bmax) bmax = bases;
+            wf[k + 1] = (int64_t)off.size();
+        }
+        int64_t cap = bmax + 8;
+        while (cap > plan.node_cap && !poa_scores_fit_int16(p, cap, lmax)) cap -= (cap - plan.node_cap + 1) / 2;
+        if (cap > plan.node_cap) {
+            const int64_t nr = (int64_t)redo.size(), ns = (int64_t)off.size();
+            gbx_poa_plan big = plan;
+            big.max_seq_len = lmax;
+            big.max_seqs_per_window = smax < 4 ? 4 : ((smax + 3) & ~3);
+            big.node_cap = (int32_t)cap;
+            big.n_windows = nr;
+            big.n_long_windows = (int32_t)n_long;
+            // slots: what the device has room for beside the first pass's buffers (still held), at most 16 GB, at most one per window
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+            size_t budget = free_b / 2 < ((size_t)16 << 30) ? free_b / 2 : ((size_t)16 << 30);
+            DevBuf dwf2(L), doff2(L), dlen2(L), dcons2(L), dcl2(L), dst2(L), dw2(L);
+            if ((rc = dwf2.alloc((nr + 1) * 8)) || (rc = doff2.alloc(ns * 8)) || (rc = dlen2.alloc(ns * 4)) ||
+                (rc = dcons2.alloc(nr * cons_stride)) || (rc = dcl2.alloc(nr * 4)) || (rc = dst2.alloc(nr * 4)))
+                return rc;
+            size_t wb2 = 0;
+            for (;;) {                                      // fewer slots when the allocation fails
+                const size_t ms = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len, false);
+                const size_t ls = poa_slot_bytes(big.node_cap, big.max_seqs_per_window, big.max_seq_len, true);
+                int64_t slots = (int64_t)(budget / (ls ? ls : 1));
+                if (slots < 1) slots = 1;
+                if (slots > plan.n_slots + plan.long_slots && plan.n_slots + plan.long_slots > 0) slots = plan.n_slots + plan.long_slots;
+                const int64_t n_main = nr - n_long;
+                big.n_slots = (int32_t)(n_main < slots ? n_main : slots);
+                big.long_slots = (int32_t)(n_long < slots ? n_long : slots);
+                (void)ms;
+                wb2 = gbx_poa_workspace_bytes(&big);
+                if (dw2.alloc(wb2) == GBX_OK) break;
+                if (budget <= ls) { set_error("gbx_poa_consensus_host: no device memory for the second pass of %lld oversized window(s)", (long long)nr); return GBX_ERR_NOMEM; }
+                budget /= 2;
+            }
+            hipStream_t st = lane.l->compute;
+            GBX_HIP(hipMemcpyAsync(dwf2.p, wf.data(), (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, st));
+            GBX_HIP(hipMemcpyAsync(doff2.p, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st));
+            GBX_HIP(hipMemcpyAsync(dlen2.p, len.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+            if ((rc = poa_launch(p, &big, nr, dwf2.as<int64_t>(), doff2.as<int64_t>(), dlen2.as<int32_t>(), dar.as<uint8_t>(),
+                                 dcons2.as<uint8_t>(), dcl2.as<int32_t>(), dst2.as<int32_t>(), cons_stride, dw2.p, wb2, st)))
+                return rc;
+            std::vector<char> c2((size_t)nr * (size_t)cons_stride);
+            std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);
+            GBX_HIP(hipMemcpyAsync(c2.data(), dcons2.p, c2.size(), hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipMemcpyAsync(l2.data(), dcl2.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipMemcpyAsync(s2.data(), dst2.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+            GBX_HIP(hipStreamSynchronize(st));
+            for (int64_t k = 0; k < nr; ++k) {
+                status[(size_t)redo[(size_t)k]] = s2[(size_t)k];
+                if (s2[(size_t)k]) continue;
+                cons_len[redo[(size_t)k]] = l2[(size_t)k];
+                memcpy(cons + redo[(size_t)k] * cons_stride, c2.data() + (size_t)k * (size_t)cons_stride, (size_t)cons_stride);
+            }
+            mark("oversized windows redone");
+        }
+    }
+    int64_t n_bad = 0, first_bad = -1;
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (status[w]) { if (first_bad < 0) first_bad = w; ++n_bad; }
+    if (n_bad) {
+        set_error("gbx_poa_consensus_host: %lld window(s) exceeded a device capacity, first is window %lld (status bits 0x%x, "
+                  "see GBX_POA_ST_*); the others' results are valid", (long long)n_bad, (long long)(win_base + first_bad), status[(size_t)first_bad]);
+        return GBX_ERR_UNSUPPORTED;
+    }
+    return GBX_OK;
+}
+
+
+// The host entry: one device, or the windows cut into contiguous ranges of equal estimated cells over the devices of
+// gbx_host_set_devices / GBX_GPUS - the driver's OpenMP loop over windows, one engine per thread
+// (msa_spoa_omp.cpp:184-196,230-260), as a loop over devices.  A window's cells ~ (bases) x (mean length) x (1 + depth / 20)
+// (shard.py:poa_cost: the graph starts as the first sequence and grows by about a tenth of every later one).
+int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                           const char *arena, int64_t arena_bytes,
+                           char *cons, int32_t *cons_len, int64_t cons_stride)
+{
+    auto one = [&]() { return poa_host_one(p, n_windows, win_first_seq, n_seqs, seq_off, seq_len, arena, arena_bytes, cons, cons_len, cons_stride); };
+    if (!host_multi_wanted() || !p || n_windows <= 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0 || !win_first_seq || !seq_off ||
+        !seq_len || !arena || !cons || !cons_len || win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs)
+        return one();
+    for (int64_t s = 0; s < n_seqs; ++s)
+        if (seq_len[s] < 0 || seq_off[s] < 0 || seq_off[s] + seq_len[s] > arena_bytes) return one();
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (win_first_seq[w + 1] < win_first_seq[w] || win_first_seq[w + 1] - win_first_seq[w] > GBX_POA_MAX_SEQS_PER_WINDOW) return one();
+    int map[MAX_HOST_DEVICES];
+    const int n_dev = host_device_set(map);
+    if (n_dev < 0) return n_dev;
+    const int parts = shard_parts(n_dev, n_windows, 256);
+    if (parts == 1) {
+        DeviceGuard g;
+        int rc = g.set(map[host_next_small_call_device(n_dev)]);
+        return rc ? rc : one();
+    }
+    const std::vector<int64_t> cuts = split_by_cost(n_windows, parts, [&](int64_t w) {
+        double tot = 0.0;
+        for (int64_t s = win_first_seq[w]; s < win_first_seq[w + 1]; ++s) tot += seq_len[s];
+        const double n = win_first_seq[w + 1] > win_first_seq[w] ? (double)(win_first_seq[w + 1] - win_first_seq[w]) : 1.0;
+        return tot * (tot / n) * (1.0 + n / 20.0);
+    });
+    return run_on_devices(parts, map, "gbx_poa_consensus_host", [&](int k) -> int {
+        const int64_t lo = cuts[(size_t)k], hi = cuts[(size_t)k + 1], m = hi - lo;
+        if (m == 0) return GBX_OK;
+        const int64_t a = win_first_seq[lo], b = win_first_seq[hi];
+        std::vector<int64_t> wf((size_t)m + 1), so((size_t)(b - a));
+        for (int64_t w = 0; w <= m; ++w) wf[(size_t)w] = win_first_seq[lo + w] - a;
+        int64_t a0 = arena_bytes, a1 = 0;
+        for (int64_t s = a; s < b; ++s) { a0 = seq_off[s] < a0 ? seq_off[s] : a0; a1 = seq_off[s] + seq_len[s] > a1 ? seq_off[s] + seq_len[s] : a1; }
+        if (a1 < a0) a0 = a1 = 0;
+        for (int64_t s = a; s < b; ++s) so[(size_t)(s - a)] = seq_off[s] - a0;
+        return poa_host_one(p, m, wf.data(), b - a, so.data(), seq_len + a, arena + a0, a1 - a0, cons + lo * cons_stride, cons_len + lo, cons_stride, lo, a);
+    });
+}
+
+}  // extern "C"

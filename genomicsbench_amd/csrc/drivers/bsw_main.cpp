@@ -11,6 +11,7 @@
 
 int main(int argc, char **argv)
 {
+    const int gpus = take_gpus_flag(argc, argv);
     if (argc < 3) {
         fprintf(stderr, "usage: bsw -pairs <InSeqFile> -t <threads> -b <batch_size>\n");
         return EXIT_FAILURE;
@@ -74,7 +75,7 @@ int main(int argc, char **argv)
     gbx_bsw_default_params(&P);
     P.o_del = P.o_ins = o; P.e_del = P.e_ins = e;
     gbx_bsw_fill_scmat(a, b, ambig, P.mat);
-    print_device_banner();
+    print_device_banner(gpus);
     std::vector<gbx_bsw_result> out((size_t)n);
     // runtime initialisation is not billed to the timed region (the reference constructs its aligner objects
     // before it, main_banded.cpp:262-270): staging buffers (print_device_banner), then a warm-up call on a tiny prefix

@@ -10,6 +10,7 @@ static void help() { fprintf(stderr, "usage: chain -i <input> -o <output> [-t th
 
 int main(int argc, char **argv)
 {
+    const int gpus = take_gpus_flag(argc, argv);
     std::string in, outp;
     bool print = false, parse_only = false;
     int threads = 1;
@@ -100,7 +101,7 @@ int main(int argc, char **argv)
         return 0;
     }
     fprintf(stderr, "Ingest: %.2f s with %d thread(s)\n", t_read, threads);
-    print_device_banner();
+    print_device_banner(gpus);
     std::vector<int32_t> score((size_t)na + 1), parent((size_t)na + 1);
     if (nc > 0) {                                               // warm-up on the first call only
         int64_t o2[2] = {0, off[1]};

@@ -90,9 +90,27 @@ static inline uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 146959
 
 // device banner + the library's one-time host-side setup (streams, pinned staging buffers), which the drivers
 // keep out of their timed regions like the reference keeps its object construction out of them
-static inline void print_device_banner()
+// `--gpus N` (every driver; not a reference flag): the host entries spread each call over N devices of this node
+// (gbx_host_set_devices: contiguous cost-balanced ranges of the units, one host lane per device).  Takes the flag out of
+// argv so that the reference-style option loops never see it; 0 = not given (GBX_GPUS, else one device).
+static inline int take_gpus_flag(int &argc, char **argv)
+{
+    int gpus = 0;
+    for (int i = 1; i < argc;) {
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) {
+            gpus = atoi(argv[i + 1]);
+            if (gpus < 1) { fprintf(stderr, "--gpus needs a positive device count\n"); exit(EXIT_FAILURE); }
+            for (int j = i; j + 2 < argc; ++j) argv[j] = argv[j + 2];
+            argc -= 2;
+        } else ++i;
+    }
+    return gpus;
+}
+
+static inline void print_device_banner(int gpus = 0)
 {
     char name[256];
-    if (gbx_device_name(name, sizeof(name)) == GBX_OK) fprintf(stderr, "gbx device: %s\n", name);
+    if (gpus > 0) die_on(gbx_host_set_devices(gpus), "gbx_host_set_devices");
+    if (gbx_device_name(name, sizeof(name)) == GBX_OK) fprintf(stderr, "gbx device: %s x %d\n", name, gbx_host_devices());
     die_on(gbx_host_prepare(), "gbx_host_prepare");
 }

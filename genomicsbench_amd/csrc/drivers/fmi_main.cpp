@@ -16,6 +16,7 @@ static void help() { fprintf(stderr, "Need five arguments : ref_file query_set b
 
 int main(int argc, char **argv)
 {
+    const int gpus = take_gpus_flag(argc, argv);
     std::vector<const char *> pos;
     bool print = false, parse_only = false;
     for (int i = 1; i < argc; ++i) {
@@ -92,7 +93,7 @@ int main(int argc, char **argv)
     printf("reference seq len = %lld\n", (long long)idx.ref_seq_len);
     for (int c = 0; c < 5; ++c) printf("count[%d] = %lld\n", c, (long long)idx.count[c]);
 
-    print_device_banner();
+    print_device_banner(gpus);
     gbx_fmi_params prm;
     gbx_fmi_default_params(&prm, min_seed_len);
     std::vector<gbx_fmi_smem> smem((size_t)n_reads * 20);        // the reference's quota per thread (fmi.cpp:183)

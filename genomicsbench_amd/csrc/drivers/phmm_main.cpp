@@ -8,6 +8,7 @@
 
 int main(int argc, char **argv)
 {
+    const int gpus = take_gpus_flag(argc, argv);
     const char *file = nullptr;
     int loops = 1, threads = 1;
     bool print = false, parse_only = false;
@@ -114,7 +115,7 @@ int main(int argc, char **argv)
     printf("Num Batches %zu, Num threads %d\n", n_batches, threads);
     const int64_t np = (int64_t)pair_read.size();
     std::vector<double> out((size_t)np + 1);
-    print_device_banner();
+    print_device_banner(gpus);
     die_on(gbx_phmm_init(), "gbx_phmm_init");                    // initPairHMM(), :193
     double dt = 0;
     for (int l = 0; l < (loops < 1 ? 1 : loops); ++l) {

@@ -10,6 +10,7 @@
 
 int main(int argc, char **argv)
 {
+    const int gpus = take_gpus_flag(argc, argv);
     std::string seq_file = "seq.fa";
     int m = 2, x = -4, o1 = -4, e1 = -2, o2 = -24, e2 = -1, threads = 1;
     bool print = false, parse_only = false, warmup = false;
@@ -86,13 +87,15 @@ int main(int argc, char **argv)
     std::vector<char> cons((size_t)(nw > 0 ? nw : 1) * stride);
     std::vector<int32_t> clen((size_t)nw + 1);
     arena.resize(arena.size() + 8);
-    print_device_banner();
+    print_device_banner(gpus);
     {
         // the workspace (one slot per window in flight, ~10 GB for the 'large' input) is allocated before the timed
         // region, as the reference creates its alignment engines and graphs before it (msa_spoa_omp.cpp:184-190)
         gbx_poa_plan plan;
         die_on(gbx_poa_plan_host(nw, win_first.data(), seq_len.data(), &plan), "gbx_poa_plan_host");
-        die_on(gbx_host_reserve(gbx_poa_workspace_bytes(&plan)), "gbx_host_reserve");
+        // (several devices: every shard has a plan of its own, which the untimed run below makes and caches per device)
+        if (gbx_host_devices() <= 1) die_on(gbx_host_reserve(gbx_poa_workspace_bytes(&plan)), "gbx_host_reserve");
+        else warmup = true;
     }
     if (warmup)      // an untimed run of the whole job first: every allocation of the timed call is then a cache hit
         die_on(gbx_poa_consensus_host(&P, nw, win_first.data(), ns, seq_off.data(), seq_len.data(), arena.data(),

@@ -9,7 +9,7 @@
 
 namespace gbx {
 
-// thread-local last-error text (gbx_capi.hip)
+// thread-local last-error text (gbx_core.hip)
 void set_error(const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what);
 

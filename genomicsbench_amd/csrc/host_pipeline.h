@@ -1,5 +1,5 @@
 // host_pipeline.h — what the *_host entry points of libgbx.so use to move caller-owned (pageable) buffers to the
-// device and the results back while kernels run.  Included by gbx_capi.hip only.
+// device and the results back while kernels run.  Included through capi_common.h by the capi_<kernel>.hip files.
 //
 // A call takes a Lane (streams + pinned staging slabs, pooled per device, one per concurrent caller) and
 // describes its uploads as an ordered list of stages; stage c is everything chunk c of the input needs.  Large

@@ -39,6 +39,24 @@ const char *gbx_last_error(void);       /* thread-local, never NULL */
 int  gbx_device_count(void);            /* number of HIP devices, 0 if none; never errors  */
 int  gbx_set_device(int dev);           /* selects the device later calls of this thread use */
 int  gbx_device_name(char *buf, size_t cap);
+/* Multi-GPU: how many devices of this node the *_host entries spread one call over.  The units of every
+ * kernel here are independent, so a call is cut into n contiguous ranges of equal cost (nominal cells / anchors / bases,
+ * the same rule as genomicsbench_amd/shard.py), range k runs on device k through a host lane of its own (its own streams,
+ * pinned slabs and upload / download threads: the shard goes from the caller's memory straight to that device and its
+ * results come back in place) and the call returns when all are done; results are identical to the one-device call.
+ * This is the reference's one-engine-per-OpenMP-thread shape (bsw/main_banded.cpp:253-291, chain/src/host_kernel.cpp:98-107,
+ * phmm/PairHMMUnitTest.cpp:224-247, poa/msa_spoa_omp.cpp:184-260) with devices in the place of threads.  A call too small
+ * to cut (bsw: under 2 x 128 Ki pairs, ...) runs whole on one device and such calls take the devices in turn, so a driver
+ * that hands over small slices from many threads still uses every GPU.
+ *   n_gpus = 0: the default, i.e. the environment variable GBX_GPUS if set, else 1 (then the calling thread's current
+ *   device is used, see gbx_set_device).  Process-wide; not meant to be changed while calls are in flight.
+ *   GBX_DEVICE_MAP="0,0,1" (test aid) maps logical devices 0..n-1 onto physical ones: the multi-device path on one GPU.
+ * The *_device entries are single-device by construction (the caller owns the buffers and the stream). */
+int  gbx_host_set_devices(int n_gpus);
+/* The cut itself, for callers that want to see or reuse it: cuts[0..n_parts] with cuts[k] = the first unit index at which the
+ * cost of the units before it reaches k / n_parts of the total (negative costs count as 0). */
+int  gbx_split_by_cost(int64_t n_units, const double *cost, int n_parts, int64_t *cuts);
+int  gbx_host_devices(void);             /* devices the *_host entries currently use (>= 1; 0 without any HIP device) */
 /* Optional: creates the calling thread's streams and the pinned staging buffers the *_host entries use for
  * large inputs (about 144 MB of pinned host memory), so that the first large call does not pay for them.  The
  * counterpart of constructing the reference's aligner object before its timed region

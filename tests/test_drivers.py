@@ -258,3 +258,62 @@ def test_fmi_driver_prints_the_oracles_smems(fmi_data):
     k = next(i for i, ln in enumerate(lines) if ln.startswith("totalSmems"))
     assert lines[k] == "totalSmems = %d" % len(want)
     assert lines[k + 1:] == FM.smems_text(want)
+
+
+# ---- --gpus N: the drivers hand the device count to the host entries (gbx_host_set_devices); on a one-GPU box the logical
+# devices are mapped onto GPU 0 (GBX_DEVICE_MAP) and small jobs are cut all the same (GBX_SHARD_MIN_UNITS)
+def test_gpus_flag_is_taken_out_of_the_reference_options(data):
+    """--gpus sits anywhere on the command line without disturbing the reference-style option loops (CPU: --parse-only)."""
+    d, b = data[0], data[1]
+    for args in (["--gpus", "4", "-pairs", str(d / "pairs.txt"), "-t", "2", "--parse-only", "1"],
+                 ["-pairs", str(d / "pairs.txt"), "--gpus", "2", "-t", "2", "--parse-only", "1"],
+                 ["-pairs", str(d / "pairs.txt"), "-t", "2", "--parse-only", "1", "--gpus", "8"]):
+        r = run([os.path.join(BIN, "bsw")] + args)
+        assert r.returncode == 0, r.stderr
+        assert json.loads(r.stdout.strip().splitlines()[-1])["pairs"] == b.n
+    assert run([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "--gpus", "0"]).returncode != 0
+    r = run([os.path.join(BIN, "chain"), "--gpus", "3", "-i", str(d / "chain.in"), "-o", str(d / "unused"), "-t", "2", "--parse-only"])
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["calls"] == len(data[2][0]) - 1
+
+
+@pytest.mark.gpu
+def test_drivers_with_gpus_flag_end_to_end(data, fmi_data):
+    d, b, c, ph, po = data
+    env = dict(os.environ, GBX_DEVICE_MAP="0,0,0", GBX_SHARD_MIN_UNITS="1")
+
+    def run_env(args):
+        return subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)
+
+    r = run_env([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", "2", "--gpus", "3", "--dump", str(d / "bsw3.out")])
+    assert r.returncode == 0 and " x 3" in r.stderr, r.stderr
+    assert np.array_equal(np.loadtxt(str(d / "bsw3.out"), dtype=np.int32), O.bsw_oracle(make_params(), b, 4))
+    r = run_env([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", str(d / "chain2.out"), "--print", "--gpus", "2"])
+    assert r.returncode == 0, r.stderr
+    case = gio.read_chain_calls(str(d / "chain.in"))
+    s, p, _, _ = O.chain_oracle(*case)
+    import io
+    buf = io.StringIO()
+    gio.write_chain_returns(buf, case[0], s, p)
+    assert open(str(d / "chain2.out")).read() == buf.getvalue()
+    r = run_env([os.path.join(BIN, "poa"), "-s", str(d / "poa.fasta"), "-t", "1", "--print", "--gpus", "2"])
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.split("\n") if ln]
+    assert lines[1::2] == O.poa_oracle(poa_params(), po, 4)
+    r = run_env([os.path.join(BIN, "phmm"), "-f", str(d / "phmm.in"), "-t", "1", "--print", "--gpus", "2"])
+    assert r.returncode == 0, r.stderr
+    vals = []
+    for ln in r.stdout.split("\n"):
+        try:
+            vals.append(float(ln))
+        except ValueError:
+            pass
+    want = O.phmm_oracle(gio.read_phmm_batches(str(d / "phmm.in")), 4)
+    assert len(vals) >= len(want) and np.all(np.abs(np.array(vals[:len(want)]) - want) <= 1e-5 * np.maximum(1, np.abs(want)) + 5e-7)
+    from genomicsbench_amd import fmi as FM
+    fd, idx, rs = fmi_data
+    r = run_env([os.path.join(BIN, "fmi"), str(fd / "genome.gbxfmi"), str(fd / "reads.fastq"), "512", "19", "2", "--print", "--gpus", "3"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    wantf, _ = O.fmi_oracle(idx, rs, FM.default_params(19))
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("totalSmems"))
+    assert lines[k] == "totalSmems = %d" % len(wantf) and lines[k + 1:] == FM.smems_text(wantf)

@@ -1,0 +1,159 @@
+"""The *_host entries over several devices (csrc/host_multi.h; gbx_host_set_devices / GBX_GPUS): n = 2, 3 logical
+devices mapped onto GPU 0 (GBX_DEVICE_MAP, the test aid for a one-GPU box) must give exactly what n = 1 gives, which
+is the oracle's - for all six kernels, for calls small enough to run whole on one device in turn, for staged (large)
+transfers, and with several multi-device calls in flight at once."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from genomicsbench_amd import _native as N
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+class devices:
+    """with devices(n): the host entries use n logical devices, all of them GPU 0, and cut even small jobs."""
+    def __init__(self, n, min_units="1"):
+        self.n, self.min_units = n, min_units
+
+    def __enter__(self):
+        import os
+        self.saved = {k: os.environ.get(k) for k in ("GBX_DEVICE_MAP", "GBX_SHARD_MIN_UNITS")}
+        os.environ["GBX_DEVICE_MAP"] = ",".join(["0"] * self.n)
+        if self.min_units is not None:
+            os.environ["GBX_SHARD_MIN_UNITS"] = self.min_units
+        N.check(N.lib().gbx_host_set_devices(self.n))
+        assert N.lib().gbx_host_devices() == self.n
+
+    def __exit__(self, *a):
+        import os
+        N.check(N.lib().gbx_host_set_devices(0))
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _jobs():
+    """name -> (callable giving the host entry's result, the oracle's result, equality)."""
+    from cases import adversarial_bsw
+    from genomicsbench_amd import abea as AB, bsw as BS, chain as CH, fmi as FM, phmm as PH, poa as PO
+    from genomicsbench_amd.datagen import gen_abea, gen_bsw, gen_chain, gen_fmi_genome, gen_fmi_reads, gen_phmm, gen_poa
+    from oracle import oracle_py as O
+    pb, pp = BS.make_params(), PO.make_params()
+    b1, b2 = gen_bsw(30000, 901), adversarial_bsw(3000, 902)
+    ch = gen_chain(60, 903)
+    ph = gen_phmm(40, 904)
+    po = gen_poa(24, 905)
+    ab = gen_abea(40, 906)
+    g = gen_fmi_genome(80_000, 907)
+    idx, fr = FM.build_index(g), gen_fmi_reads(g, 3000, 908)
+
+    def eq(a, b):
+        if isinstance(a, (list, tuple)):
+            return len(a) == len(b) and all(eq(x, y) for x, y in zip(a, b))
+        if isinstance(a, np.ndarray):
+            if a.dtype.names:
+                return all(np.array_equal(a[f], b[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+            return np.array_equal(a, b)
+        return a == b
+
+    def phmm_close(got, want):
+        fin = np.isfinite(want)
+        return np.array_equal(np.isfinite(got), fin) and bool(
+            np.all(np.abs(got[fin] - want[fin]) <= 1e-5 * np.maximum(1.0, np.abs(want[fin]))))
+
+    return {
+        "bsw": (lambda: BS.extend_host(pb, b1), O.bsw_oracle(pb, b1, 8), eq),
+        "bsw-adversarial": (lambda: BS.extend_host(pb, b2), O.bsw_oracle(pb, b2, 8), eq),
+        "chain": (lambda: list(CH.chain_host(*ch)), list(O.chain_oracle(*ch, nthreads=8)), eq),
+        "phmm": (lambda: PH.forward_host(ph), O.phmm_oracle(ph, 8), phmm_close),
+        "poa": (lambda: PO.consensus_host(pp, po), O.poa_oracle(pp, po, 8), eq),
+        "abea": (lambda: (lambda o, n: (ab.split_pairs(o, n), n))(*AB.align_host(ab)),
+                 (lambda o, n: (ab.split_pairs(o, n), n))(*O.abea_oracle(ab, 8)), eq),
+        "fmi": (lambda: list(FM.smem_host(idx, fr)), list(O.fmi_oracle(idx, fr, nthreads=8)), eq),
+    }
+
+
+@pytest.fixture(scope="module")
+def jobs():
+    return _jobs()
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_n_devices_equal_one_device_equal_oracle(jobs, n):
+    for name, (run, want, same) in jobs.items():
+        one = run()
+        assert same(one, want), "%s: one device differs from the oracle" % name
+        with devices(n):
+            many = run()
+        assert same(many, want), "%s: %d devices differ from the oracle" % (name, n)
+        if name != "phmm":
+            assert same(many, one)
+        else:
+            assert np.array_equal(many, one), "phmm: the same pairs through the same kernels must give the same bits"
+
+
+def test_small_calls_take_the_devices_in_turn(jobs):
+    """Jobs below the cutting threshold run whole on one logical device; successive calls rotate over them."""
+    with devices(3, min_units=None):
+        for _ in range(4):
+            for name, (run, want, same) in jobs.items():
+                assert same(run(), want), name
+
+
+def test_multi_device_calls_in_flight_together(jobs):
+    """Four host threads, each inside a 2-device call of a different kernel: the shards of all of them share GPU 0's side
+    streams, every shard has a lane of its own."""
+    names = ["bsw", "chain", "phmm", "poa", "abea", "fmi"]
+    with devices(2):
+        for _ in range(3):
+            got = {}
+
+            def work(k):
+                got[k] = jobs[k][0]()
+
+            th = [threading.Thread(target=work, args=(k,)) for k in names]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for k in names:
+                assert jobs[k][2](got[k], jobs[k][1]), "%s differs inside concurrent multi-device calls" % k
+
+
+def test_staged_transfers_per_device(monkeypatch):
+    """A job large enough for the staged pipeline (pinned slabs, upload workers, overlapped chunks) on every shard."""
+    from genomicsbench_amd.bsw import extend_host, make_params
+    from genomicsbench_amd.datagen import gen_bsw
+    from oracle import oracle_py as O
+    b, p = gen_bsw(900_000, 911), make_params()
+    want = O.bsw_oracle(p, b, 16)
+    assert np.array_equal(extend_host(p, b), want)
+    with devices(3, min_units=None):
+        assert np.array_equal(extend_host(p, b), want)
+    monkeypatch.setenv("GBX_BSW_HOST_CHUNK", "100000")          # three pipeline chunks inside each shard
+    with devices(2, min_units=None):
+        assert np.array_equal(extend_host(p, b), want)
+
+
+def test_errors_name_the_job_s_units():
+    """A shard's error speaks about the caller's indices; argument errors read as on one device."""
+    from genomicsbench_amd.poa import consensus_host, make_params
+    from genomicsbench_amd.datagen import gen_poa
+    from genomicsbench_amd.bsw import extend_host, make_params as bp
+    from genomicsbench_amd.datagen import gen_bsw
+    bad = gen_bsw(5000, 5)
+    bad.idq[4321] = -1
+    with devices(2):
+        with pytest.raises(N.GbxError) as e:
+            extend_host(bp(), bad)
+        assert e.value.code == -1 and "pair 4321" in str(e.value)
+    ws = gen_poa(12, 77)
+    with devices(3):
+        with pytest.raises(N.GbxError) as e:
+            consensus_host(make_params(), ws, stride=64)            # every consensus is longer than 64 bytes
+        assert e.value.code == -5 and "first is window 0" in str(e.value) and "shard 0 of 3" in str(e.value)
