@@ -71,8 +71,8 @@ class BswWork:
         from genomicsbench_amd.bsw import make_params
         self.n = args.size or self.large
         self.params = make_params()
-        self.workload = ("bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), inputs resident "
-                         "in HBM, nominal cells = sum len1*len2" % self.n)
+        self.workload = "bsw large: %d synthetic 151-bp seed-extension pairs per GPU (seed 1002), inputs resident in HBM" % self.n
+        self.detail = {"cell": "nominal cells = sum len1*len2 (main_banded.cpp:183,323)"}
 
     # host side (rank 0 in scatter mode, every rank in local mode)
     def generate(self, first, n_units):
@@ -202,8 +202,8 @@ class ChainWork:
 
     def __init__(self, args):
         self.n = args.size or self.large
-        self.workload = ("chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), inputs resident in HBM, "
-                         "cell = evaluated predecessor pair" % self.n)
+        self.workload = "chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), inputs resident in HBM" % self.n
+        self.detail = {"cell": "evaluated predecessor pair (i, j) of chain_dp's inner loop"}
 
     def generate(self, first, n_units):
         from genomicsbench_amd.datagen import gen_chain
@@ -342,8 +342,8 @@ class PhmmWork:
 
     def __init__(self, args):
         self.n = args.size or self.large
-        self.workload = ("phmm large: %d synthetic GATK batches per GPU (seed 3001), inputs resident in HBM, "
-                         "cell = rslen*haplen; fp32 with fp64 redo below 1e-28" % self.n)
+        self.workload = "phmm large: %d synthetic GATK batches per GPU (seed 3001), inputs resident in HBM" % self.n
+        self.detail = {"cell": "rslen*haplen per (read, haplotype) pair; fp32 with fp64 redo below 1e-28"}
 
     def generate(self, first, n_units):
         from genomicsbench_amd.datagen import gen_phmm
@@ -434,8 +434,8 @@ class PoaWork:
         from genomicsbench_amd.poa import make_params
         self.n = args.size or self.large
         self.params = make_params()
-        self.workload = ("poa large: %d synthetic 500-bp consensus windows per GPU (seed 4001), inputs resident in HBM, "
-                         "cell = graph node x sequence position per alignment" % self.n)
+        self.workload = "poa large: %d synthetic 500-bp consensus windows per GPU (seed 4001), inputs resident in HBM" % self.n
+        self.detail = {"cell": "graph node x sequence position per alignment"}
 
     def generate(self, first, n_units):
         from genomicsbench_amd.datagen import gen_poa
@@ -529,8 +529,9 @@ class AbeaWork:
 
     def __init__(self, args):
         self.n = args.size or self.large
-        self.workload = ("abea large: %d synthetic nanopore reads per GPU (seed 5001: synthetic 6-mer pore model, read lengths "
-                         "LogNormal(median 6000), 1.76 events per k-mer), inputs resident in HBM, cell = filled band cell" % self.n)
+        self.workload = "abea large: %d synthetic nanopore reads per GPU (seed 5001), inputs resident in HBM" % self.n
+        self.detail = {"cell": "filled band cell (align.c `fills`)",
+                       "generator": "synthetic 6-mer pore model, read lengths LogNormal(median 6000), 1.76 events per k-mer"}
 
     def generate(self, first, n_units):
         from genomicsbench_amd.datagen import gen_abea
@@ -646,9 +647,9 @@ class FmiWork:
     def __init__(self, args):
         self.n = args.size or self.large
         self.glen = int(os.environ.get("GBX_FMI_GENOME", self.genome))
-        self.workload = ("fmi large: %d synthetic 151-bp reads per GPU (seed 6001) against the FM-index of a synthetic %d-Mbp genome "
-                         "and its reverse complement (%d MB of checkpoints; 4 %% repeat families), minSeedLen 19, index and reads "
-                         "resident in HBM, unit = backwardExt call (two checkpoint look-ups)" % (self.n, self.glen >> 20, (2 * self.glen + 1) >> 20))
+        self.workload = "fmi large: %d synthetic 151-bp reads per GPU (seed 6001), %d-Mbp genome, index + reads resident in HBM" % (self.n, self.glen >> 20)
+        self.detail = {"cell": "unit = backwardExt call (two checkpoint look-ups)",
+                       "index": "FM-index of genome + reverse complement, %d MB of checkpoints, 4 %% repeat families, minSeedLen 19" % ((2 * self.glen + 1) >> 20)}
         self._g = None
 
     def genome_codes(self):
@@ -688,6 +689,11 @@ class FmiWork:
         self.units = float(self.d.extensions(stream))
         self.extra["extensions_this_gpu"] = int(self.units)
         self.extra["smems_this_gpu"] = int(self.d.n_out.item())
+        # a truncated run must not be reported as a verified one: a read that outgrew its slot, or records beyond out_cap
+        over, n_out = self.d.overflow(stream), int(self.d.n_out.item())
+        self.truncated = bool(over) or n_out > self.d.out_cap
+        if self.truncated:
+            self.extra["TRUNCATED"] = "slot overflow %d, %d SMEMs for out_cap %d" % (over, n_out, self.d.out_cap)
 
     def output_tensor(self):
         """Variable-length result: [total | per-read offsets | records] as bytes."""
@@ -713,6 +719,8 @@ class FmiWork:
                 ok = np.array_equal(off[:m + 1], woff) and all(np.array_equal(rec[f][:len(wo)], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
                 bad += int(not ok)
                 checked += m
+        if getattr(self, "truncated", False):
+            bad += 1
         return "%d reads (front of every shard) vs oracle, every field of every SMEM: %s" % (checked, "identical" if not bad else "DIFFER")
 
     def roofline_bytes(self, kernel):
@@ -930,11 +938,24 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
             valu["job_lane_ops_per_s"] = tot / (dt_max / steps)
             if roof:
                 valu["job_frac"] = min(1.0, valu["job_lane_ops_per_s"] / roof)
+    # (every string under 120 characters: the driver's record of the line cuts longer ones)
     cfg = {"workload": label or work.workload, "mode": args.mode if world > 1 else "single",
-           "parallelism": ("units sharded over %d rank(s) in contiguous cost-balanced ranges, no data-path collective; "
-                           % world) + ("rank 0 scatters packed shards / gathers outputs over RCCL p2p"
-                                       if args.mode != "local" else "every rank generates its own shard")}
+           "parallelism": "units sharded over %d rank(s), contiguous cost-balanced ranges, no data-path collective" % world,
+           "inputs": ("rank 0 scatters packed shards / gathers outputs over %s p2p" % ctx["comm"]) if args.mode != "local"
+                     else "every rank generates its own shard"}
+    cfg.update(getattr(work, "detail", {}))
     cfg.update(work.extra)
+    # job-level figures, flat (the driver's record keeps only flat keys of `roofline`): every stage of a step with work in it
+    # (the class kernels of bsw overlap on four streams, so per-launch fractions of overlapping launches say little; these
+    # are the stable ones) - algorithmic bytes of all stages over the step time, all VALU lane operations over the step time
+    if kind == "bsw":
+        job_bytes = sum(sb for sb, su in (work.roofline_bytes(sname) for sname in stages) if su)
+    else:
+        job_bytes = work.roofline_bytes(name)[0]            # the other kinds' figure is the whole job's already
+    step_s = dt_max / steps
+    flat = {"job_bytes_per_s": job_bytes / step_s, "job_hbm_frac": job_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+            "valu_frac": (valu or {}).get("frac"), "job_valu_frac": (valu or {}).get("job_frac"),
+            "job_lane_ops_per_s": (valu or {}).get("job_lane_ops_per_s"), "valu_roof_lane_ops_per_s": roof}
     line = {
         "metric": work.metric, "value": total_units * steps / dt_max / 1e9, "unit": work.unit,
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -944,7 +965,7 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                      "valu_busy": valu_b, "valu_busy_source": vsrc, "valu": valu, "kernel_ms": k_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3)},
+                     "cells_per_s_dominant_kernel": (k_units or 0.0) / (k_ms * 1e-3), **flat},
         "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
         "scatter_ms": scatter_ms, "gather_ms": gather_ms, "rccl_ranks": world, "comm": ctx["comm"],
     }

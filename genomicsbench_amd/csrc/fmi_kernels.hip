@@ -593,11 +593,15 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
     // the read of a quad is staged in LDS, four bits per base (an odd dword count per quad: the copies start in different
     // banks): 16 x 19 dwords per wavefront for 151-bp reads; reads of more than ~8000 bases are read in place
     const int qwords = ((max_len + 7) / 8) | 1;
-    const bool ldsq = (size_t)qwords * 64 <= 65536 - 128;
+    static const size_t pad = getenv("GBX_FMI_LDS_PAD") ? (size_t)atol(getenv("GBX_FMI_LDS_PAD")) : 0;
+    // the whole request must stay inside the 64 KB a workgroup gets without raising the function's limit: the staged reads,
+    // the prev[] slab, the tuning pad and the kernel's static LDS (cnt_lds: 64 B)
+    const size_t lds_fixed = (size_t)GBX_FMI_LDS_PREV * 16 * 16 + pad + 64;
+    const char *ipenv = getenv("GBX_FMI_INPLACE");                    // test aid: 1 = read the bases in place whatever their length
+    const bool ldsq = (size_t)qwords * 64 + lds_fixed <= 65536 && !(ipenv && atoi(ipenv));
     const bool wide = idx->ref_seq_len >= (1ll << 32);                // SA rows and interval sizes need 64 bits
     // GBX_FMI_LDS_PAD (tuning aid): extra dynamic LDS per wavefront, i.e. fewer wavefronts per CU; GBX_FMI_WIDE=1 (test aid):
     // the 64-bit instance whatever the reference length
-    static const size_t pad = getenv("GBX_FMI_LDS_PAD") ? (size_t)atol(getenv("GBX_FMI_LDS_PAD")) : 0;
     const char *wenv = getenv("GBX_FMI_WIDE");
     const bool w64 = wide || (wenv && atoi(wenv));
     for (long long base = 0; base < n_reads; base += L.chunk) {

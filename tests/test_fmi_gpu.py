@@ -111,7 +111,46 @@ def test_ragged_reads_ambiguous_bases_and_empty_reads(small):
     assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P))
 
 
-def test_long_reads_take_the_lds_and_the_in_place_paths(small):
+def _long_reads(g, L, n, rng):
+    reads = []
+    for _ in range(n):
+        p = int(rng.integers(0, len(g) - L))
+        r = g[p:p + L].copy()
+        hit = rng.random(L) < 0.02
+        r[hit] = (r[hit] + 1) % 4
+        if rng.random() < 0.3:
+            r[rng.integers(0, L, 3)] = 4                       # ambiguous bases: the in-place and the staged path must agree on them
+        reads.append(r)
+    return FmiReadSet.fixed(np.array(reads))
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+@pytest.mark.parametrize("L", [7650, 7700, 8100, 8200, 9000, 9999])
+def test_reads_beyond_the_lds_staging_are_read_in_place(small, monkeypatch, L, wide):
+    """Reads of up to ~8000 bases are staged in LDS four bits per base; longer ones (the reference accepts 9999,
+    fmi.cpp:93) are read in place (fmi_smem_kernel<false, *>).  The lengths straddle the switch (the whole LDS request -
+    staged reads + prev[] slab + static - must fit 64 KB); both SA-row widths."""
+    g, idx = small
+    monkeypatch.setenv("GBX_FMI_WIDE", wide)
+    rs = _long_reads(g, L, 12, np.random.default_rng(L))
+    P = default_params(19)
+    assert_same(smem_host(idx, rs, P, out_cap=12 * 1500), O.fmi_oracle(idx, rs, P, nthreads=8))
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_in_place_path_on_ordinary_reads(small, monkeypatch, wide):
+    """GBX_FMI_INPLACE=1 forces the in-place instance for any length: the ragged / N-rich set and 151-bp reads."""
+    g, idx = small
+    monkeypatch.setenv("GBX_FMI_WIDE", wide)
+    monkeypatch.setenv("GBX_FMI_INPLACE", "1")
+    P = default_params(19)
+    rs = gen_fmi_reads(g, 3000, 6011)
+    assert_same(smem_host(idx, rs, P), O.fmi_oracle(idx, rs, P, nthreads=8))
+    rs = _long_reads(g, 700, 30, np.random.default_rng(3))
+    assert_same(smem_host(idx, rs, P, out_cap=30 * 400), O.fmi_oracle(idx, rs, P, nthreads=8))
+
+
+def test_long_reads_on_the_lds_path(small):
     g, idx = small
     rng = np.random.default_rng(10)
     for L in (700, 2500):

@@ -1,7 +1,8 @@
 """Full-size parity: every kernel's BASELINE.json 'large' configuration, the whole job on the device entry, compared
 with the CPU side unit for unit (bsw: oracle, all six fields of all 2 M pairs; chain: the compiled reference's
-chain_dp on all 10 000 calls, oracle if the reference build did not travel; phmm: oracle on the first >= 1 M pairs
-of the 20 000 batches; poa: oracle on all 6 000 windows).  The CPU side runs on the GPU box's host cores (OpenMP):
+chain_dp on all 10 000 calls, oracle if the reference build did not travel; phmm: oracle on all ~10.9 M pairs of
+the 20 000 batches; poa: oracle on all 6 000 windows; fmi: all 10 M reads on the 1-GB index, ten strata of 100 k reads
+against the oracle).  The CPU side runs on the GPU box's host cores (OpenMP):
 about a minute and a half in total there."""
 import os
 
@@ -53,7 +54,9 @@ def test_chain_large_all_calls(realistic):
         assert not len(bad), "chain %s: %d of %d anchors differ, first at %d" % (name, len(bad), len(w), bad[0])
 
 
-def test_phmm_large_first_million_pairs():
+def test_phmm_large_all_pairs():
+    """All ~10.9 M pairs of the 20 000 batches against the oracle (every unit class of the device path - the stream units
+    of 1..8 rows per lane, the tiles, the fp64 redo - wherever in the job it occurs): about 100 s of oracle on the box."""
     import torch
     from genomicsbench_amd.datagen import gen_phmm
     from genomicsbench_amd.phmm import DevicePhmmBatchSet
@@ -62,17 +65,20 @@ def test_phmm_large_first_million_pairs():
     d = DevicePhmmBatchSet(bs, torch.device("cuda:0"))
     d.run(_stream())
     torch.cuda.synchronize()
-    nb = int(np.searchsorted(bs.batch_pair_off, 1_000_000)) + 1          # whole batches covering >= 1 M pairs
-    sub = bs.take_batches(0, nb)
-    assert sub.n_pairs >= 1_000_000
-    got, want = d.results()[:sub.n_pairs], O.phmm_oracle(sub, CORES)
-    fin = np.isfinite(want)
-    assert np.array_equal(np.isfinite(got), fin)
-    err = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)      # 1e-5 relative, |want| floored at 1
-    assert err.max() <= 1e-5, "max rel err %.3g at pair %d" % (err.max(), int(np.argmax(err)))
-    # the rest of the job: finite, negative log-likelihoods everywhere
-    rest = d.results()[sub.n_pairs:]
-    assert np.isfinite(rest).all() and (rest < 0).all()
+    got = d.results()
+    assert len(got) == bs.n_pairs
+    worst = 0.0
+    step = 2500                                                              # batches per oracle call: bounded host memory
+    for b0 in range(0, 20_000, step):
+        sub = bs.take_batches(b0, min(20_000, b0 + step))
+        lo = int(bs.batch_pair_off[b0])
+        g, want = got[lo:lo + sub.n_pairs], O.phmm_oracle(sub, CORES)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(g), fin), "batches %d..: finiteness differs" % b0
+        err = np.abs(g[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)    # 1e-5 relative, |want| floored at 1
+        assert err.max() <= 1e-5, "max rel err %.3g at pair %d" % (err.max(), lo + int(np.argmax(err)))
+        worst = max(worst, float(err.max()))
+    print("phmm large: %d pairs, max relative error %.3g" % (bs.n_pairs, worst))
 
 
 def test_poa_large_all_windows():
@@ -106,24 +112,35 @@ def test_abea_large_all_reads():
         assert np.array_equal(go[a:a + int(wn[r])], wo[a:a + int(wn[r])]), "read %d" % r
 
 
-def test_fmi_two_million_reads_of_large():
-    """The first 2 M of fmi 'large' (10 M reads of 151 bases) against the oracle, every field of every SMEM, on a
-    64-Mbp genome (128 MB of checkpoints: beyond the L2, the index build and the oracle stay within seconds)."""
+def test_fmi_large_real_index_stratified():
+    """fmi 'large' as bench.py runs it: all 10 M reads of 151 bases in one device call against the index of the 512-Mbp
+    genome (1 GB of checkpoints: beyond L2 and Infinity Cache, where the kernel actually lives).  Checked against the
+    oracle, every field of every SMEM: ten strata of 100 000 reads spread over the job (reads k M .. k M + 100 k), and the
+    extension count of those strata run on their own."""
     import torch
     from genomicsbench_amd.datagen import gen_fmi_genome, gen_fmi_reads
     from genomicsbench_amd.fmi import DeviceFmi, build_index
     from oracle import oracle_py as O
     dev = torch.device("cuda:0")
-    g = gen_fmi_genome(64 << 20, 6001)
+    g = gen_fmi_genome(512 << 20, 6001)
     idx = build_index(g, device=dev)
-    rs = gen_fmi_reads(g, 2_000_000, 6002)
+    rs = gen_fmi_reads(g, 10_000_000, 6002)
     d = DeviceFmi(idx, rs, dev)
     d.run(_stream())
     torch.cuda.synchronize()
     got, goff = d.results()
-    wo, woff, ext, _ = O.fmi_oracle(idx.host(), rs, nthreads=CORES, return_stats=True)
-    assert np.array_equal(goff, woff)
-    for f in ("rid", "m", "n", "k", "l", "s"):
-        bad = np.nonzero(got[f] != wo[f])[0]
-        assert not len(bad), "fmi %s: %d of %d records differ, first at %d" % (f, len(bad), len(wo), bad[0])
-    assert d.extensions() == ext
+    hidx = idx.host()
+    assert goff[0] == 0 and goff[-1] == len(got) and np.all(np.diff(goff) >= 0)
+    checked = 0
+    for k in range(10):
+        lo, hi = k * 1_000_000, k * 1_000_000 + 100_000
+        wo, woff = O.fmi_oracle(hidx, rs.take(lo, hi), nthreads=CORES)
+        a, b = int(goff[lo]), int(goff[hi])
+        assert np.array_equal(goff[lo:hi + 1] - a, woff), "stratum %d: per-read SMEM counts differ" % k
+        sub = got[a:b]
+        assert np.array_equal(sub["rid"], wo["rid"] + lo), "stratum %d: rid" % k
+        for f in ("m", "n", "k", "l", "s"):
+            bad = np.nonzero(sub[f] != wo[f])[0]
+            assert not len(bad), "fmi %s, stratum %d: %d of %d records differ, first at %d" % (f, k, len(bad), len(wo), bad[0])
+        checked += len(wo)
+    print("fmi large: %d SMEMs of 1 M reads in ten strata identical to the oracle (job: %d SMEMs, %d extensions)" % (checked, len(got), d.extensions()))
