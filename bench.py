@@ -113,6 +113,8 @@ class BswWork:
 
     def roofline_bytes(self, kernel):
         b = self.batch
+        if kernel in ("bsw_lane_sort", "bsw_classify", "bsw_unpack4") or not kernel.startswith("bsw_"):
+            return 0, 0.0                                       # pre-passes: no pairs of their own
         if kernel.startswith("bsw_lane_"):
             # lane-per-pair kernels (csrc/bsw_kernels.hip: LANE_RANGE_HI): format c = every score below 256, w = below 8192
             fmt, hi = kernel[9], int(kernel[10:])
@@ -949,7 +951,8 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     # (the class kernels of bsw overlap on four streams, so per-launch fractions of overlapping launches say little; these
     # are the stable ones) - algorithmic bytes of all stages over the step time, all VALU lane operations over the step time
     if kind == "bsw":
-        job_bytes = sum(sb for sb, su in (work.roofline_bytes(sname) for sname in stages) if su)
+        b = work.batch                                       # every pair once, whichever launch took it: len1 + len2 + 36 bytes
+        job_bytes = int(b.len1.astype(np.int64).sum() + b.len2.astype(np.int64).sum() + 36 * b.n)
     else:
         job_bytes = work.roofline_bytes(name)[0]            # the other kinds' figure is the whole job's already
     step_s = dt_max / steps

@@ -53,6 +53,14 @@ int gbx_poa_plan_host(int64_t n_windows, const int64_t *win_first_seq, const int
     const int64_t resident = (int64_t)cus * poa_waves_per_cu(plan->node_cap);   /* one window per resident wavefront */
     const int64_t n_main = n_windows - n_long;
     plan->n_slots = (int32_t)(n_main < resident ? n_main : resident);
+    // more windows than resident wavefronts: the lock-step form (poa_kernels.hip), a slot per window, while that fits the
+    // budget (GBX_POA_LOCKSTEP_MAX_GB, default 96 of the 288 GB: 'large' takes 55)
+    if (poa_lockstep_wanted(n_main, resident)) {
+        const char *e = getenv("GBX_POA_LOCKSTEP_MAX_GB");
+        const double budget = (e && atof(e) > 0 ? atof(e) : 96.0) * 1e9;
+        if ((double)poa_slot_bytes(plan->node_cap, plan->max_seqs_per_window, plan->max_seq_len, false) * (double)n_main <= budget)
+            plan->n_slots = (int32_t)n_main;
+    }
     plan->n_long_windows = (int32_t)n_long;
     plan->long_slots = (int32_t)(n_long < resident ? n_long : resident);
     plan->n_windows = n_windows;

@@ -2,15 +2,59 @@
 // (fmi.cpp:54-58).  query_set: FASTA or FASTQ as bseq_read_one_fasta_file takes it, uncompressed (sequence lines may
 // wrap in FASTA; FASTQ records are four lines).  Bases are encoded as fmi.cpp:113-124 does (A C G T -> 0 1 2 3, anything
 // else 4) and every read is padded to the longest one with 4s, like the reference's enc_qdb rows.
-// ref_file: the reference loads a bwa-mem2 index by prefix (FMI_search::load_index); `bwa-mem2 index` is not part of
-// this repo, so this driver reads the tables that call fills - reference_seq_len, count[5], sentinel_index, cp_occ[] -
-// from <ref_file>, written by genomicsbench_amd/fmi.py:save_index:  "GBXFMI01", int64 ref_seq_len, int64 count[5],
-// int64 sentinel_index, then ((ref_seq_len >> 6) + 1) CP_OCC records of 64 bytes (bwa-mem2's layout).
+// ref_file: as in the reference, the prefix of a bwa-mem2 index (<ref_file>.bwt.2bit.64, what `bwa-mem2 index` writes and
+// FMI_search::load_index reads), or a file of genomicsbench_amd/fmi.py:save_index (read_index below).
 // batch_size is accepted and ignored: the three seeding rounds only combine SMEMs of one read and batches are contiguous
 // rid ranges, so the sorted output does not depend on it - all reads go to the GPU in one call.  n_threads = ingest
 // threads.  --print (the reference needs a PRINT_OUTPUT rebuild): the SMEMs in the format of fmi.cpp:312-343.
 // --parse-only stops after the ingest and prints counts and a checksum (no GPU needed).
 #include "driver_common.h"
+
+// The index tables FMI_search::load_index fills (reference_seq_len, count[5], sentinel_index, cp_occ[]), from either
+//   * bwa-mem2's own file <ref_file>.bwt.2bit.64 - the reference opens the index by prefix exactly like this (fmi.cpp:79-80;
+//     layout as published in bwa-mem2's src/FMI_search.cpp, tools/bwa-mem2 being an empty submodule here: UNPINNED):
+//     int64 reference_seq_len, int64 count[5] (load_index adds 1 to each), the CP_OCC records, the suffix-array samples
+//     (int8 ms bytes then uint32 ls words; one per 8 rows from v2.1 on, one per row before: the size is taken from the file
+//     length, the search never reads them), int64 sentinel_index; <ref_file> may also name such a file directly; or
+//   * <ref_file> written by genomicsbench_amd/fmi.py:save_index: "GBXFMI01", int64 ref_seq_len, int64 count[5] (final
+//     values), int64 sentinel_index, the CP_OCC records.
+static bool read_index(const char *ref_file, gbx_fmi_index &idx, std::vector<gbx_fmi_cp_occ> &cp)
+{
+    const std::string pref = std::string(ref_file) + ".bwt.2bit.64";
+    FILE *f = fopen(pref.c_str(), "rb");
+    std::string path = pref;
+    bool bwa = f != nullptr;
+    if (!f) {
+        f = fopen(ref_file, "rb");
+        path = ref_file;
+        if (!f) { fprintf(stderr, "cannot open %s or %s\n", pref.c_str(), ref_file); return false; }
+        char magic[8];
+        if (fread(magic, 1, 8, f) != 8) { fprintf(stderr, "%s: truncated\n", ref_file); fclose(f); return false; }
+        bwa = memcmp(magic, "GBXFMI01", 8) != 0;
+        if (bwa) rewind(f);
+    }
+    bool ok = fread(&idx.ref_seq_len, 8, 1, f) == 1 && fread(idx.count, 8, 5, f) == 5;
+    if (ok && !bwa) ok = fread(&idx.sentinel_index, 8, 1, f) == 1;
+    if (!ok || idx.ref_seq_len < 2 || idx.ref_seq_len > ((int64_t)1 << 40)) { fprintf(stderr, "%s: not an fmi index\n", path.c_str()); fclose(f); return false; }
+    cp.resize((size_t)(idx.ref_seq_len >> 6) + 1);
+    if (fread(cp.data(), sizeof(gbx_fmi_cp_occ), cp.size(), f) != cp.size()) { fprintf(stderr, "%s: truncated\n", path.c_str()); fclose(f); return false; }
+    if (bwa) {
+        const long at = ftell(f);
+        fseek(f, 0, SEEK_END);
+        const int64_t rest = (int64_t)ftell(f) - at - 8, n = idx.ref_seq_len;
+        if (rest < 0 || rest % 5 || (rest / 5 != n && rest / 5 != (n >> 3) + 1)) {
+            fprintf(stderr, "%s: %lld bytes of suffix-array samples fit neither published layout of a .bwt.2bit.64 file\n", path.c_str(), (long long)rest);
+            fclose(f);
+            return false;
+        }
+        fseek(f, -8, SEEK_END);
+        if (fread(&idx.sentinel_index, 8, 1, f) != 1) { fclose(f); return false; }
+        for (int c = 0; c < 5; ++c) idx.count[c] += 1;               // FMI_search::load_index
+        fprintf(stderr, "index: bwa-mem2 file %s (%s suffix-array samples skipped)\n", path.c_str(), rest / 5 == n ? "uncompressed" : "1-in-8");
+    }
+    fclose(f);
+    return true;
+}
 
 static void help() { fprintf(stderr, "Need five arguments : ref_file query_set batch_size minSeedLen n_threads [--print] [--parse-only]\n"); }
 
@@ -20,6 +64,15 @@ int main(int argc, char **argv)
     std::vector<const char *> pos;
     bool print = false, parse_only = false;
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--index-info") && i + 1 < argc) {      // fmi --index-info <ref_file>: the tables' scalars and a checksum, no GPU
+            gbx_fmi_index ix;
+            std::vector<gbx_fmi_cp_occ> c;
+            if (!read_index(argv[i + 1], ix, c)) return EXIT_FAILURE;
+            printf("{\"ref_seq_len\": %lld, \"count\": [%lld, %lld, %lld, %lld, %lld], \"sentinel_index\": %lld, \"checkpoints\": %zu, \"fnv1a\": \"%016llx\"}\n",
+                   (long long)ix.ref_seq_len, (long long)ix.count[0], (long long)ix.count[1], (long long)ix.count[2], (long long)ix.count[3],
+                   (long long)ix.count[4], (long long)ix.sentinel_index, c.size(), (unsigned long long)fnv1a(c.data(), c.size() * sizeof(gbx_fmi_cp_occ)));
+            return 0;
+        }
         if (!strcmp(argv[i], "--print")) print = true;
         else if (!strcmp(argv[i], "--parse-only")) parse_only = true;
         else pos.push_back(argv[i]);
@@ -77,18 +130,10 @@ int main(int argc, char **argv)
         return 0;
     }
 
-    // ---- index tables
-    FILE *fi = fopen(pos[0], "rb");
-    char magic[8];
+    // ---- index tables (read_index below)
     gbx_fmi_index idx;
-    if (!fi || fread(magic, 1, 8, fi) != 8 || memcmp(magic, "GBXFMI01", 8) || fread(&idx.ref_seq_len, 8, 1, fi) != 1 ||
-        fread(idx.count, 8, 5, fi) != 5 || fread(&idx.sentinel_index, 8, 1, fi) != 1 || idx.ref_seq_len < 2) {
-        fprintf(stderr, "cannot read the index tables from %s (write them with genomicsbench_amd.fmi.save_index)\n", pos[0]);
-        return EXIT_FAILURE;
-    }
-    std::vector<gbx_fmi_cp_occ> cp((size_t)(idx.ref_seq_len >> 6) + 1);
-    if (fread(cp.data(), sizeof(gbx_fmi_cp_occ), cp.size(), fi) != cp.size()) { fprintf(stderr, "%s: truncated\n", pos[0]); return EXIT_FAILURE; }
-    fclose(fi);
+    std::vector<gbx_fmi_cp_occ> cp;
+    if (!read_index(pos[0], idx, cp)) return EXIT_FAILURE;
     idx.cp_occ = cp.data();
     printf("reference seq len = %lld\n", (long long)idx.ref_seq_len);
     for (int c = 0; c < 5; ++c) printf("count[%d] = %lld\n", c, (long long)idx.count[c]);

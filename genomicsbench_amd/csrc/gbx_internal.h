@@ -118,6 +118,7 @@ constexpr int POA_PIPE_MAXLEN = 512;     // longest sequence of the pipelined DP
 size_t poa_slot_bytes(int ncap, int deg, int lmax, bool long_slot);
 size_t poa_workspace_bytes(const gbx_poa_plan *plan);
 int poa_waves_per_cu(int ncap);
+bool poa_lockstep_wanted(int64_t n_main, int64_t resident);      // the lock-step form (a slot per window) pays for this job
 bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax);
 int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena,

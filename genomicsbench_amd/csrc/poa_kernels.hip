@@ -84,6 +84,7 @@ __host__ __device__ inline int poa_cap_stride(int lmax) { const int s = poa_row_
 struct SlotLayout {
     int64_t code, in_cnt, out_cnt, aln_cnt, out_slot, out_slot_x, mark, check, decoder, coder;
     int64_t in_src, in_wt, out_dst, in_src_x, in_wt_x, out_dst_x, aln, r2n, n2r, stack, score, pred, path_node, path_pos, mat, total;
+    int64_t hdr, st8save;      // lock-step form: the window's scalars and the sort's state bytes between launches
     int stk_cap, path_cap;
 };
 
@@ -99,12 +100,19 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, b
     L.code = take(ncap); L.in_cnt = take(ncap); L.out_cnt = take(ncap); L.aln_cnt = take(ncap);
     L.out_slot = take((int64_t)ncap * 4); L.out_slot_x = take((int64_t)ncap * (deg - 4) + 16); L.mark = take(ncap); L.check = take(ncap);
     L.decoder = take(256); L.coder = take(512);
+    L.hdr = take(64); L.st8save = take(ncap);
     L.in_src = take((int64_t)ncap * 16); L.in_wt = take((int64_t)ncap * 16); L.out_dst = take((int64_t)ncap * 16);
     L.in_src_x = take((int64_t)ncap * (deg - 4) * 4 + 16); L.in_wt_x = take((int64_t)ncap * (deg - 4) * 4 + 16);
     L.out_dst_x = take((int64_t)ncap * (deg - 4) * 4 + 16); L.aln = take((int64_t)ncap * POA_ALN_STRIDE * 4 + 64);
     L.r2n = take((int64_t)ncap * 4); L.n2r = take((int64_t)ncap * 4);
     L.stack = take((int64_t)L.stk_cap * 4); L.score = take((int64_t)ncap * 4); L.pred = take((int64_t)ncap * 4);
     L.path_node = take((int64_t)L.path_cap * 4); L.path_pos = take((int64_t)L.path_cap * 4);
+#ifndef GBX_POA_DP_WAVES
+#define GBX_POA_DP_WAVES 5          // wavefronts per SIMD of the lock-step DP kernel's default instance
+#endif
+#ifndef GBX_POA_SERIAL_WAVES
+#define GBX_POA_SERIAL_WAVES 3      // ... and the serial-phase kernel (its LDS admits twelve windows per CU)
+#endif
 #ifndef GBX_POA_PLANES
 #define GBX_POA_PLANES 2
 #endif
@@ -1394,16 +1402,8 @@ __global__ void __launch_bounds__(1024) poa_classify_kernel(PoaArgs A, int32_t *
     }
 }
 
-// The phase functions above are always_inline: the window kernel is one function on purpose.  Left to its cost model the
-// inliner stops at 1100 basic blocks (amdgpu-inline-max-bb) and the first phase it leaves out (add_alignment, after the
-// DP grew by a dozen instructions) takes `PoaGraph &` by reference: the graph's pointers then live in scratch memory,
-// lose their address space, and every access of the kernel becomes a FLAT instruction (993 of them, 397 instead of
-// 330 ms, found through SQ_INSTS_LDS dropping to nothing).
-template <bool LONG>
-__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
+__device__ __attribute__((always_inline)) inline void poa_bind_graph(PoaGraph &g, char *slot, const SlotLayout &L, const PoaArgs &A)
 {
-    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
-    PoaGraph g;
     g.ncap = A.ncap; g.deg = A.deg; g.stk_cap = L.stk_cap; g.aln_path_cap = L.path_cap;
     g.code = (uint8_t *)(slot + L.code); g.in_cnt = (uint8_t *)(slot + L.in_cnt);
     g.out_cnt = (uint8_t *)(slot + L.out_cnt); g.aln_cnt = (uint8_t *)(slot + L.aln_cnt);
@@ -1416,10 +1416,12 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     g.r2n = (int32_t *)(slot + L.r2n); g.n2r = (int32_t *)(slot + L.n2r);
     g.stack = (int32_t *)(slot + L.stack); g.score = (int32_t *)(slot + L.score); g.pred = (int32_t *)(slot + L.pred);
     g.cons_path = g.stack;                                    // the global DFS-stack area doubles as the consensus path
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
+}
+// serial DFS state on chip (LDS): state byte per node, order under construction, stack
+__device__ __attribute__((always_inline)) inline void poa_bind_lds(PoaTopoLds &T, char *lds_raw, const PoaArgs &A)
+{
     const int ncp = (A.ncap + 15) & ~15;
-    // serial DFS state on chip (LDS): state byte per node, order under construction, stack
-    PoaTopoLds T;
     lds_u8 *const lds0 = (lds_u8 *)lds_raw;
     // fixed-size arrays first, at compile-time offsets (the per-node arrays behind them need the node capacity): the
     // bases then fold into the ds instructions' offset fields instead of living in (spilled) scalar registers
@@ -1431,7 +1433,22 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
     T.old = (lds_s16 *)(lds0 + POA_LDS_FIXED + ncp);
     T.stk_cap = A.lds_stack;
     T.n_sorted = 0; T.flags_ok = 0;
-    g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
+}
+
+// The phase functions above are always_inline: the window kernel is one function on purpose.  Left to its cost model the
+// inliner stops at 1100 basic blocks (amdgpu-inline-max-bb) and the first phase it leaves out (add_alignment, after the
+// DP grew by a dozen instructions) takes `PoaGraph &` by reference: the graph's pointers then live in scratch memory,
+// lose their address space, and every access of the kernel becomes a FLAT instruction (993 of them, 397 instead of
+// 330 ms, found through SQ_INSTS_LDS dropping to nothing).
+template <bool LONG>
+__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
+{
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    PoaGraph g;
+    poa_bind_graph(g, slot, L, A);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    PoaTopoLds T;
+    poa_bind_lds(T, lds_raw, A);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
 
     unsigned long long cells = 0;
@@ -1511,6 +1528,104 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 #endif
 }
 
+
+// ---- the lock-step form (round 4): every window resident, one launch per phase and sequence index ----------------
+// poa_kernel keeps a window in one wavefront from its first sequence to its consensus: the DP (throughput work: packed
+// arithmetic and row traffic), the traceback (one dependent row fetch per step) and add_alignment / the sort (chains of
+// dependent LDS reads) share one register budget (168 VGPRs, 234 spilled SGPRs) and one occupancy (12 windows per CU),
+// and a CU's issue slots and memory queues are shared by whatever mix of phases its twelve windows happen to be in.
+// With a slot per window (288 GB of HBM: 'large' takes 55 GB) the phases become launches of their own over ALL windows:
+// for sequence index s = 1, 2, ...: poa_phase_kernel<DP> aligns sequence s of every window that has one against its graph,
+// poa_phase_kernel<serial> adds the alignments and re-sorts.  Each kernel holds only what its phase needs (the DP no sort
+// state and no LDS, the serial phases a third of the DP's registers), every wavefront of a launch is in the same phase,
+// and what a window carries from launch to launch - the graph's counters, the alignment's end point and path, the state
+// bytes of the incremental sort - sits in its slot (PoaSlotHdr, st8save; the previous ranks are n2r).  The windows with a
+// sequence over 512 bases keep the window kernel (second launch, side stream), small jobs too.
+struct PoaSlotHdr { int n_nodes, n_codes, n_path, err, path_lo, path_hi, mi, mj, n_sorted, flags_ok, dp_ran, pad_[5]; };
+static_assert(sizeof(PoaSlotHdr) == 64, "one 64-byte line per window");
+
+// WAVES = wavefronts per SIMD the instance is compiled for (DP alone: 87 VGPRs as the compiler likes it = 5, 80 VGPRs with two
+// spilled = 6, i.e. 24 windows per CU: all 6 000 of 'large' in flight at once)
+template <bool DO_DP, bool DO_TB, bool DO_ADD, int WAVES>
+__global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLayout L, int s_idx)
+{
+    const int q = blockIdx.x;                                  // position in the work list = the window's slot
+    const int64_t w = (int64_t)A.wlist[q];
+    const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+    const int nseq = (int)(s1 - s0);
+    if (s_idx >= nseq && !(DO_ADD && s_idx == 0)) return;      // (a window without sequences still gets its empty consensus)
+    char *slot = A.work + (int64_t)q * A.slot_bytes;
+    PoaSlotHdr *hdr = (PoaSlotHdr *)(slot + L.hdr);
+    PoaGraph g;
+    poa_bind_graph(g, slot, L, A);
+    const int lane = threadIdx.x & 63;
+    if (DO_ADD && s_idx == 0) {
+        poa_graph_reset(g);
+        g.path_lo = g.path_hi = -1;
+        if (nseq == 0) {
+            const int clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+            if (lane == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+            return;
+        }
+    } else {
+        g.n_nodes = hdr->n_nodes; g.n_codes = hdr->n_codes; g.n_path = hdr->n_path; g.err = hdr->err;
+        g.path_lo = hdr->path_lo; g.path_hi = hdr->path_hi;
+    }
+    const uint8_t *seq = A.arena + A.seq_off[s0 + s_idx];
+    const int len = A.seq_len[s0 + s_idx];
+    poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
+    const int wp = POA_PIPE_STRIDE;
+    const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
+    const PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
+    int mi = -1, mj = -1, dp_ran = 0;
+    if (DO_DP) {
+        g.n_path = 0;
+        if (g.n_nodes != 0 && len != 0 && g.err == 0) {
+            poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+            dp_ran = 1;
+            if (lane == 0) atomicAdd(A.cells, (unsigned long long)g.n_nodes * (unsigned long long)len);
+        }
+        if (!DO_TB && lane == 0) { hdr->mi = mi; hdr->mj = mj; hdr->dp_ran = dp_ran; hdr->n_path = 0; }
+    } else if (DO_TB) {
+        mi = hdr->mi; mj = hdr->mj; dp_ran = hdr->dp_ran;
+        if (s_idx == 0) dp_ran = 0;
+    }
+    if (DO_TB) {
+        if (dp_ran) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+        else g.n_path = 0;
+        if (!DO_ADD && lane == 0) { hdr->n_path = g.n_path; hdr->path_lo = g.path_lo; hdr->path_hi = g.path_hi; hdr->err = g.err; }
+    }
+    if (DO_ADD) {
+        extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+        PoaTopoLds T;
+        poa_bind_lds(T, lds_raw, A);
+        uint8_t *const save = (uint8_t *)(slot + L.st8save);
+        if (s_idx != 0) {
+            T.n_sorted = hdr->n_sorted; T.flags_ok = hdr->flags_ok;
+            if (T.use) {
+                // the sort's state as the previous launch left it: state bytes from the slot, previous ranks = n2r
+                for (int i = lane; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        if (g.err == 0) poa_add_alignment_wave<true>(g, seq, len, T);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s_idx == nseq - 1) {
+            int clen = 0;
+            if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+            if (lane == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+        } else {
+            if (T.use) for (int i = lane; i < g.n_nodes; i += 64) save[i] = T.st8[i];
+            if (lane == 0) {
+                hdr->n_nodes = g.n_nodes; hdr->n_codes = g.n_codes; hdr->n_path = 0; hdr->err = g.err; hdr->path_lo = -1; hdr->path_hi = -1;
+                hdr->n_sorted = T.n_sorted; hdr->flags_ok = T.flags_ok; hdr->dp_ran = 0;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // wavefronts (= windows in flight) one CU keeps resident for this node capacity: registers and the LDS of
@@ -1560,6 +1675,26 @@ int poa_waves_per_cu(int ncap)
     }
     return q;
 }
+
+// The lock-step form needs a slot per window of the main list and pays for ~2 launches per sequence index: it is taken
+// when the job has more windows than the chip holds wavefronts of the window kernel (a job that fits runs every window
+// at once there anyway) and the plan gave every window a slot.  GBX_POA_LOCKSTEP=0 / 1 (test / tuning aid): never / whenever
+// the slots allow.
+bool poa_lockstep_wanted(int64_t n_main, int64_t resident)
+{
+    if (const char *e = getenv("GBX_POA_LOCKSTEP")) return atoi(e) != 0 && n_main > 0;
+    return n_main > resident;
+}
+namespace {
+bool poa_use_lockstep(const gbx_poa_plan *plan, int64_t n_main)
+{
+    if (n_main <= 0 || plan->n_slots < n_main) return false;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    else (void)hipGetLastError();
+    return poa_lockstep_wanted(n_main, (int64_t)cus * poa_waves_per_cu(plan->node_cap));
+}
+}  // namespace
 
 // workspace = main slots | counter block | main work list | long-window list | long slots
 size_t poa_slot_bytes(int ncap, int deg, int lmax, bool long_slot) { return (size_t)make_layout(ncap, deg, lmax, long_slot).total; }
@@ -1661,7 +1796,31 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         Stage st("poa_window_long", sl);
         hipLaunchKernelGGL(poa_kernel<true>, dim3(plan->long_slots), dim3(64), A.lds_marks ? lds_need : 0, sl, B, LL);
     }
-    if (has_main) {
+    const int64_t n_main = n_windows - plan->n_long_windows;
+    if (has_main && poa_use_lockstep(plan, n_main)) {
+        // lock-step form: a slot per window, per sequence index one DP (+ traceback) launch and one launch of the serial phases
+        // over all windows of the list (heaviest class first; a window without a sequence s leaves at once)
+        const SlotLayout L = make_layout(ncap, deg, lmax, false);
+        A.slot_bytes = L.total;
+        const dim3 grid((unsigned)n_main), tb(64);
+        const size_t lds = A.lds_marks ? lds_need : 0;
+        // tuning aids, read per call: GBX_POA_TB_SERIAL=1 moves the traceback from the DP launch to the serial one,
+        // GBX_POA_DP_OCC=5|6 picks the DP instance
+        const bool tb_with_dp = !(getenv("GBX_POA_TB_SERIAL") && atoi(getenv("GBX_POA_TB_SERIAL")) != 0);
+        const int occ = getenv("GBX_POA_DP_OCC") ? atoi(getenv("GBX_POA_DP_OCC")) : GBX_POA_DP_WAVES;
+        for (int sidx = 0; sidx < plan->max_seqs_per_window; ++sidx) {
+            if (sidx > 0) {
+                Stage st("poa_dp", s);
+                if (tb_with_dp && occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 6>), grid, tb, 0, s, A, L, sidx);
+                else if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 5>), grid, tb, 0, s, A, L, sidx);
+                else if (occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 6>), grid, tb, 0, s, A, L, sidx);
+                else hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 5>), grid, tb, 0, s, A, L, sidx);
+            }
+            Stage st("poa_serial", s);
+            if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<false, false, true, GBX_POA_SERIAL_WAVES>), grid, tb, lds, s, A, L, sidx);
+            else hipLaunchKernelGGL((poa_phase_kernel<false, true, true, GBX_POA_SERIAL_WAVES>), grid, tb, lds, s, A, L, sidx);
+        }
+    } else if (has_main) {
         const SlotLayout L = make_layout(ncap, deg, lmax, false);
         A.slot_bytes = L.total;
         // (the long launch was queued first and its wavefronts need their place on the chip: a full main grid would keep them

@@ -150,6 +150,57 @@ def load_index(path):
     return FmiIndex(int(head[0]), head[1:6], int(head[6]), cp)
 
 
+# ---- bwa-mem2's own index file, <prefix>.bwt.2bit.64, as FMI_search::load_index reads it (the call the reference driver
+# makes, fmi.cpp:79-80).  Layout as published in bwa-mem2's src/FMI_search.cpp (tools/bwa-mem2 is an empty submodule here:
+# UNPINNED, nothing of it can be compiled or run in this image):
+#     int64   reference_seq_len                      2 x genome length + 1
+#     int64   count[5]                               symbols smaller than base c; load_index adds 1 to each (the sentinel row)
+#     CP_OCC  cp_occ[(reference_seq_len >> 6) + 1]   64 bytes each: int64 cp_count[4], uint64 one_hot_bwt_str[4]
+#     int8    sa_ms_byte[n_sa]; uint32 sa_ls_word[n_sa]   suffix-array samples: n_sa = (reference_seq_len >> 3) + 1 with
+#                                                    SA_COMPRESSION (SA_COMPX 3, v2.1 on), = reference_seq_len before
+#     int64   sentinel_index
+# The SMEM search reads neither array of SA samples; a reader takes their size from the file length.
+def save_bwa_mem2_index(index, prefix, sa=None, sa_compx=3):
+    """Writes <prefix>.bwt.2bit.64.  sa: the full suffix array (int64[ref_seq_len]) to sample from, or None - the samples are
+    then written as zeros: such a file serves the seeding benchmark (and this repo's drivers), not `bwa-mem2 mem`."""
+    idx = index.host()
+    n = int(idx.ref_seq_len)
+    n_sa = (n >> sa_compx) + 1 if sa_compx else n
+    path = "%s.bwt.2bit.64" % prefix
+    with open(path, "wb") as f:
+        f.write(np.array([n] + [int(c) - 1 for c in idx.count], dtype="<i8").tobytes())
+        f.write(idx.cp_occ.view(np.uint8).tobytes())
+        if sa is None:
+            f.write(np.zeros(n_sa, dtype=np.int8).tobytes())
+            f.write(np.zeros(n_sa, dtype="<u4").tobytes())
+        else:
+            smp = np.asarray(sa, dtype=np.int64)[::(1 << sa_compx) if sa_compx else 1][:n_sa]
+            smp = np.concatenate([smp, np.zeros(n_sa - len(smp), dtype=np.int64)])
+            f.write((smp >> 32).astype(np.int8).tobytes())
+            f.write((smp & 0xffffffff).astype("<u4").tobytes())
+        f.write(np.array([idx.sentinel_index], dtype="<i8").tobytes())
+    return path
+
+
+def load_bwa_mem2_index(prefix):
+    """FMI_search::load_index as far as the SMEM search needs it: reads <prefix>.bwt.2bit.64 (or the file itself when
+    `prefix` already names one).  The SA samples are skipped, whichever of the two published sizes they have."""
+    import os
+    path = prefix if os.path.exists(prefix) and not os.path.exists("%s.bwt.2bit.64" % prefix) else "%s.bwt.2bit.64" % prefix
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        head = np.frombuffer(f.read(48), dtype="<i8")
+        n = int(head[0])
+        ncp = (n >> 6) + 1
+        cp = np.frombuffer(f.read(ncp * 64), dtype=CP_OCC_DTYPE).copy()
+        rest = size - 48 - ncp * 64 - 8
+        if len(cp) != ncp or rest < 0 or rest % 5 or rest // 5 not in (n, (n >> 3) + 1):
+            raise ValueError("%s: not a bwa-mem2 .bwt.2bit.64 file (reference_seq_len %d, %d bytes)" % (path, n, size))
+        f.seek(size - 8)
+        sentinel = int(np.frombuffer(f.read(8), dtype="<i8")[0])
+    return FmiIndex(n, [int(c) + 1 for c in head[1:6]], sentinel, cp)
+
+
 def write_reads(path, reads, fastq=True, wrap=0):
     """FASTQ (four lines per read) or FASTA (sequence lines wrapped at `wrap` bases when > 0) of an FmiReadSet."""
     letters = np.frombuffer(b"ACGTN", dtype=np.uint8)

@@ -247,6 +247,46 @@ def test_fmi_index_file_roundtrip_and_parallel_ingest(fmi_data):
             assert got["reads"] == rs.n_reads and got["max_readlength"] == L and got["fnv1a"] == want, (name, t)
 
 
+def test_fmi_driver_reads_a_bwa_mem2_index_by_prefix(fmi_data, tmp_path):
+    """The reference opens the index by prefix (fmi.cpp:79-80: FMI_search(argv[1]), load_index() reads
+    <prefix>.bwt.2bit.64).  save_bwa_mem2_index writes that layout as published (both sizes of the suffix-array sample
+    section), the Python reader and the driver's reader give back the tables save_index / load_index hold."""
+    from genomicsbench_amd import fmi as FM
+    d, idx, _ = fmi_data
+    own = json.loads(run([os.path.join(BIN, "fmi"), "--index-info", str(d / "genome.gbxfmi")]).stdout)
+    for compx in (3, 0):
+        prefix = str(tmp_path / ("genome_%d.fa" % compx))
+        path = FM.save_bwa_mem2_index(idx, prefix, sa_compx=compx)
+        n = idx.ref_seq_len
+        assert os.path.getsize(path) == 48 + ((n >> 6) + 1) * 64 + 5 * (((n >> 3) + 1) if compx else n) + 8
+        back = FM.load_bwa_mem2_index(prefix)
+        assert back.ref_seq_len == idx.ref_seq_len and list(back.count) == list(idx.count) and back.sentinel_index == idx.sentinel_index
+        assert np.array_equal(back.cp_occ.view(np.uint8), idx.cp_occ.view(np.uint8))
+        for arg in (prefix, path):                                   # by prefix, and the file itself
+            r = run([os.path.join(BIN, "fmi"), "--index-info", arg])
+            assert r.returncode == 0, r.stderr
+            assert json.loads(r.stdout) == own
+    bad = str(tmp_path / "bad.bwt.2bit.64")
+    open(bad, "wb").write(open(path, "rb").read()[:-3])
+    assert run([os.path.join(BIN, "fmi"), "--index-info", bad]).returncode != 0
+    with pytest.raises(ValueError):
+        FM.load_bwa_mem2_index(bad)
+
+
+@pytest.mark.gpu
+def test_fmi_driver_on_a_bwa_mem2_index(fmi_data, tmp_path):
+    from genomicsbench_amd import fmi as FM
+    d, idx, rs = fmi_data
+    prefix = str(tmp_path / "genome.fa")
+    FM.save_bwa_mem2_index(idx, prefix)
+    r = run([os.path.join(BIN, "fmi"), prefix, str(d / "reads.fastq"), "512", "19", "2", "--print"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    want, _ = O.fmi_oracle(idx, rs, FM.default_params(19))
+    k = next(i for i, ln in enumerate(lines) if ln.startswith("totalSmems"))
+    assert lines[k] == "totalSmems = %d" % len(want) and lines[k + 1:] == FM.smems_text(want)
+
+
 @pytest.mark.gpu
 def test_fmi_driver_prints_the_oracles_smems(fmi_data):
     from genomicsbench_amd import fmi as FM

@@ -147,3 +147,54 @@ def test_windows_with_long_sequences_take_the_second_launch():
     for sub in ([windows[3], windows[8]], [windows[0], windows[2], windows[7]]):
         w2 = PoaWindowSet.from_lists(sub)
         assert consensus_host(p, w2) == O.poa_oracle(p, w2, 2)
+
+
+# ---- the lock-step form (poa_kernels.hip: a slot per window, one launch per phase and sequence index).  Jobs with more
+# windows than the chip holds wavefronts take it by themselves ('large': tests/test_fullsize_gpu.py); GBX_POA_LOCKSTEP=1
+# forces it on the small jobs here.
+@pytest.mark.parametrize("tb_serial,occ", [("0", "5"), ("0", "6"), ("1", "5"), ("1", "6")])
+def test_lockstep_form_equals_the_window_kernel(monkeypatch, tb_serial, occ):
+    p = make_params()
+    sets = [gen_poa(48, 4001), random_windows(7, 24, 300, 7), random_windows(8, 30, 500, 9),
+            PoaWindowSet.from_lists([["ACGTACGTAC"] * 3, ["A", "C", "A"], ["ACGT"], ["GATTACA", "GATTACA", "GATTTACA", "GATTACA"]])]
+    want = [O.poa_oracle(p, ws, 8) for ws in sets]
+    mono = [consensus_host(p, ws) for ws in sets]
+    monkeypatch.setenv("GBX_POA_LOCKSTEP", "1")
+    monkeypatch.setenv("GBX_POA_TB_SERIAL", tb_serial)
+    monkeypatch.setenv("GBX_POA_DP_OCC", occ)
+    for ws, w, m in zip(sets, want, mono):
+        got = consensus_host(p, ws)
+        diff(got, w)
+        assert got == m
+
+
+def test_lockstep_form_edge_paths(monkeypatch):
+    """Under the lock-step form: the sort's fallback to global memory (state must survive the launches without root flags),
+    windows with long sequences beside it (second launch keeps the window kernel), the node-capacity redo of the host entry,
+    windows of one sequence and ragged sequence counts (a window leaves the launches when it runs out of sequences)."""
+    monkeypatch.setenv("GBX_POA_LOCKSTEP", "1")
+    p = make_params()
+    rng = np.random.default_rng(11)
+    base = "".join(rng.choice(list("ACGT"), 300))
+    ins = "".join(rng.choice(list("ACGT"), 900))
+    long_read = base[:150] + ins + base[150:]
+    ws = PoaWindowSet.from_lists([[base, long_read, base, long_read, base[:290]], [long_read, base, base], [base], [base[:40]] * 9])
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws))
+    rng = np.random.default_rng(5)
+    deep = ["".join(rng.choice(list("ACGT"), 200)) for _ in range(120)]
+    b2 = "".join(rng.choice(list("ACGT"), 180))
+    ws = PoaWindowSet.from_lists([[b2] * 4, deep, [b2[:170], b2, b2[5:]]])
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws, 4))
+    for tb in ("0", "1"):
+        monkeypatch.setenv("GBX_POA_TB_SERIAL", tb)
+        ws = random_windows(21, 40, 700, 6)                                     # some windows over 512 columns: second launch
+        diff(consensus_host(p, ws), O.poa_oracle(p, ws, 4))
+    # the device entry re-run on the same workspace (slots hold the previous run's headers and state bytes)
+    import torch
+    ws = gen_poa(32, 77)
+    d = DevicePoaWindowSet(ws, torch.device("cuda:0"))
+    want = O.poa_oracle(p, ws, 8)
+    for _ in range(2):
+        d.run(p, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert d.results() == want
