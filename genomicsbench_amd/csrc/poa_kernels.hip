@@ -367,8 +367,25 @@ struct PkMat { v2s ac, bd; };
 __device__ inline PkMat pk_mat(const Mat2 &m) { PkMat r; r.ac = pk_sat(m.a, m.c); r.bd = pk_sat(m.b, m.d); return r; }
 __device__ inline v2s pk_apply(const PkMat &m, v2s eq) { return pk_max(pk_add(m.ac, pk_lo(eq)), pk_add(m.bd, pk_hi(eq))); }
 
+// RING (round 4): the last POA_RING_ROWS rows of the matrix also stay in LDS.  A partial-order graph of thirty noisy reads is
+// wide: the topological order keeps the 2-7 letters of a column side by side, so a row's first predecessor is the row
+// before it in only 22 % of the cases - but within six rows in 97 % (second predecessors, 38 % of the rows have one: 95 %;
+// third ones, 18 %: 94 %; measured on the 'large' generator with the host model of the graph).  Without the ring every
+// such row came back from HBM: 1.15 row reads per row written, 4.6 of the kernel's 8.8 B per cell, and a DP phase bound
+// by HBM traffic (a launch of nothing but DP rows moves 3.7 TB/s, as much as the mixed kernel) with a third predecessor
+// costing a synchronous round trip in the middle of its row.  The ring shares the window's LDS with the topological sort's
+// arrays - the two are never live together; the sort's state bytes are parked in the slot meanwhile (st8save), its
+// previous ranks are n2r - so the twelve windows per CU stay.
+constexpr int POA_RING_ROWS = 6;
+constexpr int POA_RING_SLOT = 64 * 16 * 2 + 16;            // H vectors, deficit vectors (16 B per lane each), {F0, O0, -, H0}
+constexpr int POA_RING_BYTES = POA_RING_ROWS * POA_RING_SLOT;
+typedef __attribute__((address_space(3))) v8s lds_v8s;
+typedef __attribute__((address_space(3))) v4u lds_v4u;
+typedef __attribute__((address_space(3))) v2u lds_v2u;
+
+template <bool RING>
 __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
-                                 int &max_i, int &max_j)
+                                 int &max_i, int &max_j, char *lds_ring = nullptr)
 {
     constexpr int CPL = 8;
     const int lane = threadIdx.x & 63;
@@ -417,6 +434,21 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         x.fo = *(const v4u *)(M.F + b + j0);
         const v2u c0 = *(const v2u *)(M.H + b + POA_C0_F);      // {F0, O0 | pad, H0}
         x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
+    };
+    // row `prow` out of the ring (it was written at most POA_RING_ROWS rows ago and not overwritten since)
+    char *const ring_lane = lds_ring + lane * 16;
+    auto ring_fetch = [&](int prow, PoaPredIn &x) {
+        char *const sl = ring_lane + (prow % POA_RING_ROWS) * POA_RING_SLOT;
+        x.h = *(const lds_v8s *)sl;
+        x.fo = *(const lds_v4u *)(sl + 1024);
+        const v2u c0 = *(const lds_v2u *)(lds_ring + (prow % POA_RING_ROWS) * POA_RING_SLOT + 2048);
+        x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
+    };
+    // a predecessor row for the row `target` (prow < target, and not the row being computed): ring or memory
+    auto fetch_pred = [&](int prow_v, int computing, PoaPredIn &x) {
+        const int prow = __builtin_amdgcn_readfirstlane(prow_v);       // the same in every lane: a scalar branch, scalar slot arithmetic
+        if (RING && prow >= 1 && computing - prow <= POA_RING_ROWS) ring_fetch(prow, x);
+        else fetch(prow, x);
     };
     auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
         const int rr = min(r, n - 1);
@@ -509,15 +541,24 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         // row is read as well and ignored): a fixed number of loads per iteration.
         const int nic = (binfo >> 8) & 0xff;
         const bool nreg0 = r + 1 < n && nic >= 1 && bp0 == i, nreg1 = r + 1 < n && nic >= 2 && bp1 == i;
-        fetch(nic >= 1 && !nreg0 ? bp0 : 0, in0);
-        fetch(nic >= 2 && !nreg1 ? bp1 : 0, in1);
+        if (RING) {
+            // (the ring makes the fixed-loads-per-iteration rule pointless: a predecessor is an LDS read, or nothing when the
+            // row has none / it is this very row; the rare row from further back waits for memory)
+            const int snic = __builtin_amdgcn_readfirstlane(nic);
+            const bool s0 = __builtin_amdgcn_readfirstlane((int)nreg0) != 0, s1 = __builtin_amdgcn_readfirstlane((int)nreg1) != 0;
+            if (snic >= 1 && !s0) fetch_pred(bp0, i, in0); else if (r + 1 < n && snic == 0) fetch(0, in0);
+            if (snic >= 2 && !s1) fetch_pred(bp1, i, in1);
+        } else {
+            fetch(nic >= 1 && !nreg0 ? bp0 : 0, in0);
+            fetch(nic >= 2 && !nreg1 ? bp1 : 0, in1);
+        }
         // ---- predecessors beyond the second: read in place (rare)
         if (ic > 2) {
             const int node = g.r2n[r];
             for (int k = 2; k < ic; ++k) {
                 const int prow = k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1;
                 PoaPredIn x;
-                fetch(prow, x);
+                fetch_pred(prow, i, x);
                 po = max(po, x.o0); pf = max(pf, x.f0);
                 v2s F2[4], O2[4], H2[4];
                 pred_terms(x, sc, F2, O2, H2);
@@ -577,6 +618,16 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         last.fo.z = __builtin_amdgcn_perm(pk_bits(q1), pk_bits(q0), 0x06040200u);
         last.fo.w = __builtin_amdgcn_perm(pk_bits(q3), pk_bits(q2), 0x06040200u);
         *(v8s *)(M.H + ro + j0) = last.h; *(v4u *)(M.F + ro + j0) = last.fo;
+        if (RING) {
+            char *const sl = ring_lane + (i % POA_RING_ROWS) * POA_RING_SLOT;
+            *(lds_v8s *)sl = last.h;
+            *(lds_v4u *)(sl + 1024) = last.fo;
+            if (lane == 0) {
+                v2u c0;
+                c0.x = ((unsigned)F0 & 0xffffu) | ((unsigned)O0 << 16); c0.y = (unsigned)H0 << 16;
+                *(lds_v2u *)(lds_ring + (i % POA_RING_ROWS) * POA_RING_SLOT + 2048) = c0;
+            }
+        }
         if (sink) {                                            // H(i, len)
             const int cl = (len - 1) % CPL;
             v2s hv = hcol[0];
@@ -1476,7 +1527,9 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
             const uint8_t *seq = A.arena + A.seq_off[s];
             const int len = A.seq_len[s];
             g.n_path = 0;
+            bool ran_dp = false;
             if (g.n_nodes != 0 && len != 0 && g.err == 0) {
+                ran_dp = true;
                 const int wp = !LONG || len <= POA_PIPE_MAXLEN ? POA_PIPE_STRIDE : poa_row_stride(len);
                 const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
                 PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
@@ -1486,7 +1539,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 // The serial phases (one useful lane) are latency chains that lose issue slots to the other wavefronts' DP rows;
                 // the DP is throughput work that does not mind waiting.  Priority 3 for the former: 300.8 -> 294.7 ms.
                 __builtin_amdgcn_s_setprio(0);
-                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined<!LONG>(g, M, A, seq, len, mi, mj, lds_raw);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 __builtin_amdgcn_s_setprio(3);
@@ -1499,7 +1552,18 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
             }
             {
                 PH_T0
+                if (!LONG && T.use && ran_dp) {
+                    // the DP's row ring has used the sort's LDS: state bytes back from the slot, previous ranks = n2r
+                    const uint8_t *save = (const uint8_t *)(slot + L.st8save);
+                    for (int i = threadIdx.x & 63; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
                 if (g.err == 0) poa_add_alignment_wave<!LONG>(g, seq, len, T);
+                if (!LONG && T.use && s + 1 < s1) {
+                    uint8_t *save = (uint8_t *)(slot + L.st8save);
+                    for (int i = threadIdx.x & 63; i < g.n_nodes; i += 64) save[i] = T.st8[i];
+                }
                 PH_ACC(t_add)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1541,6 +1605,12 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
 // and what a window carries from launch to launch - the graph's counters, the alignment's end point and path, the state
 // bytes of the incremental sort - sits in its slot (PoaSlotHdr, st8save; the previous ranks are n2r).  The windows with a
 // sequence over 512 bases keep the window kernel (second launch, side stream), small jobs too.
+// MEASURED (round 4, 6 000 windows, profiles/r04b_poa_variants.txt): 310 ms (traceback with the DP, 5 wavefronts per SIMD),
+// 334 (6 per SIMD: all windows in flight), 327 / 334 (traceback with the serial phases) against 233 ms of the window kernel.
+// The DP launches alone take 5.5 ms x 39: a chip doing nothing but DP rows moves 3.7 TB/s, which is what the window kernel
+// averages WITH its serial phases hidden behind it - the DP is bound by its HBM traffic (8.8 B per cell), not by registers,
+// occupancy or issue slots (300 VALU instructions per row: 45 % of the issue rate), and lock-step only takes away the
+// overlap.  What the measurement pointed to instead is the traffic itself: poa_dp_pipelined's row ring.
 struct PoaSlotHdr { int n_nodes, n_codes, n_path, err, path_lo, path_hi, mi, mj, n_sorted, flags_ok, dp_ran, pad_[5]; };
 static_assert(sizeof(PoaSlotHdr) == 64, "one 64-byte line per window");
 
@@ -1581,7 +1651,8 @@ __global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLay
     if (DO_DP) {
         g.n_path = 0;
         if (g.n_nodes != 0 && len != 0 && g.err == 0) {
-            poa_dp_pipelined(g, M, A, seq, len, mi, mj);
+            extern __shared__ __attribute__((aligned(16))) char lds_dp[];
+            poa_dp_pipelined<true>(g, M, A, seq, len, mi, mj, lds_dp);     // the row ring: this kernel has no other use for LDS
             dp_ran = 1;
             if (lane == 0) atomicAdd(A.cells, (unsigned long long)g.n_nodes * (unsigned long long)len);
         }
@@ -1659,7 +1730,7 @@ int poa_waves_per_cu(int ncap)
     const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
     const bool lds_marks = lds_need != 0;
     int q = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false>, 64, lds_marks ? lds_need : 0) != hipSuccess || q < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false>, 64, std::max<size_t>(lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES)) != hipSuccess || q < 1) {
         (void)hipGetLastError();
         q = 8;
     }
@@ -1676,14 +1747,14 @@ int poa_waves_per_cu(int ncap)
     return q;
 }
 
-// The lock-step form needs a slot per window of the main list and pays for ~2 launches per sequence index: it is taken
-// when the job has more windows than the chip holds wavefronts of the window kernel (a job that fits runs every window
-// at once there anyway) and the plan gave every window a slot.  GBX_POA_LOCKSTEP=0 / 1 (test / tuning aid): never / whenever
-// the slots allow.
+// The lock-step form needs a slot per window of the main list and pays for ~2 launches per sequence index.  It is built,
+// tested and selectable (GBX_POA_LOCKSTEP=1 when the plan is made and at the launch) but NOT the default: see the measurement
+// at poa_phase_kernel.
 bool poa_lockstep_wanted(int64_t n_main, int64_t resident)
 {
     if (const char *e = getenv("GBX_POA_LOCKSTEP")) return atoi(e) != 0 && n_main > 0;
-    return n_main > resident;
+    (void)resident;
+    return false;          // measured (MI355X, 'large'): 310-334 ms against the window kernel's 233 - see the note at poa_phase_kernel
 }
 namespace {
 bool poa_use_lockstep(const gbx_poa_plan *plan, int64_t n_main)
@@ -1811,10 +1882,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         for (int sidx = 0; sidx < plan->max_seqs_per_window; ++sidx) {
             if (sidx > 0) {
                 Stage st("poa_dp", s);
-                if (tb_with_dp && occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 6>), grid, tb, 0, s, A, L, sidx);
-                else if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 5>), grid, tb, 0, s, A, L, sidx);
-                else if (occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 6>), grid, tb, 0, s, A, L, sidx);
-                else hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 5>), grid, tb, 0, s, A, L, sidx);
+                if (tb_with_dp && occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 6>), grid, tb, (size_t)POA_RING_BYTES, s, A, L, sidx);
+                else if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<true, true, false, 5>), grid, tb, (size_t)POA_RING_BYTES, s, A, L, sidx);
+                else if (occ >= 6) hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 6>), grid, tb, (size_t)POA_RING_BYTES, s, A, L, sidx);
+                else hipLaunchKernelGGL((poa_phase_kernel<true, false, false, 5>), grid, tb, (size_t)POA_RING_BYTES, s, A, L, sidx);
             }
             Stage st("poa_serial", s);
             if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<false, false, true, GBX_POA_SERIAL_WAVES>), grid, tb, lds, s, A, L, sidx);
@@ -1829,7 +1900,7 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         if (has_long && resident > 2 * (int64_t)plan->long_slots) resident -= plan->long_slots;
         const int grid = (int)std::min<int64_t>(n_windows - plan->n_long_windows, resident);
         Stage st("poa_window", s);
-        hipLaunchKernelGGL(poa_kernel<false>, dim3(grid), dim3(64), A.lds_marks ? lds_need : 0, s, A, L);
+        hipLaunchKernelGGL(poa_kernel<false>, dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
     }
     if (ss && (rc = ss->join(s))) return rc;
     GBX_HIP(hipGetLastError());
