@@ -493,9 +493,10 @@ class PoaWork:
         self.extra["dp_cells_per_gpu"] = int(self.units)
 
     def roofline_bytes(self, kernel):
-        # per cell: 4 B written (H int16 + one byte each of H-F and H-O) + 4 B x ~1.2 predecessor rows read = 8.8 B
-        # (measured, profiles/hbm_traffic.json: 747 GB per 6000-window launch = 8.4 B/cell)
-        return int(self.units * 8.8), self.units
+        # per cell: 4 B written (H int16 + one byte each of H-F and H-O: what the traceback and a far successor read) + 0.2 B
+        # read (1.6 predecessor rows per row, 3 % of them further back than the six rows of the LDS ring); before the ring
+        # (round 3) every predecessor row that was not the row before came from HBM: 8.8 B per cell
+        return int(self.units * 4.2), self.units
 
     def host_entry(self):
         """PCIe-inclusive rate of the same shard through gbx_poa_consensus_host."""
@@ -674,7 +675,16 @@ class FmiWork:
         import torch
         from genomicsbench_amd.fmi import DeviceFmi, build_index
         t0 = time.perf_counter()
-        self.index = build_index(self.genome_codes(), device=dev)
+        # ranks that share a GPU (GBX_BENCH_COMM=gloo test aid only) build their copies of the index one after the other: the
+        # suffix sort's temporaries (~25 GB) times eight do not fit beside eight ranks' workspaces on one device
+        share = _CTX.get("ranks_per_device", 1)
+        for turn in range(share):
+            if turn == _CTX.get("turn", 0):
+                self.index = build_index(self.genome_codes(), device=dev)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+            if share > 1:
+                _CTX["dist"].barrier()
         torch.cuda.synchronize()
         self.index_build_s = time.perf_counter() - t0
         self.d = DeviceFmi.from_tensors(self.index, (tensors["enc"], tensors["read_off"], tensors["read_len"]), dev)
@@ -1111,6 +1121,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "comm_dev": torch.device("cpu") if comm == "gloo" else dev,
            "comm": "rccl" if comm != "gloo" else "gloo (test aid)"}
+    if comm == "gloo" and world > 1:
+        ndev = torch.cuda.device_count()
+        _CTX.update(dist=dist, ranks_per_device=-(-world // ndev), turn=rank // ndev)
 
     if args.kernel:
         line = run_kernel(args.kernel, args, ctx, args.steps, args.warmup)
@@ -1144,6 +1157,7 @@ def main():
 
 
 S = None
+_CTX = {}
 
 if __name__ == "__main__":
     main()

@@ -74,11 +74,34 @@ int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream)
 }
 
 // The host entry keeps the device copy of an index between calls (a reference-side caller hands over the same
-// FMI_search tables for every batch of reads, fmi.cpp:218): keyed by the table's address and its scalars, one per device.
+// FMI_search tables for every batch of reads, fmi.cpp:218), one per device.  An entry is found by the index's CONTENT -
+// its scalars and a fingerprint of 256 checkpoints spread over the table - not by the caller's address: a buffer that
+// was freed and reused for another index of the same length is a different index.  Entries are reference-counted while a
+// call uses them (gbx_fmi_host_release leaves those alone) and at most four idle ones are kept per device.
 namespace {
-struct FmiCached { int dev; const void *host_cp; int64_t len, sentinel, count1; void *d_index; size_t bytes; };
+struct FmiCached { int dev; int64_t len, sentinel, count[5]; uint64_t fp; void *d_index; size_t bytes; int users; uint64_t last_use; };
 std::mutex g_fmi_mu;
 std::vector<FmiCached> g_fmi_cache;
+uint64_t g_fmi_clock = 0;
+
+uint64_t fmi_fingerprint(const gbx_fmi_index *idx)
+{
+    const int64_t ncp = (idx->ref_seq_len >> 6) + 1;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t k = 0; k < n; ++k) { h ^= b[k]; h *= 1099511628211ull; } };
+    const int64_t samples = ncp < 256 ? ncp : 256;
+    for (int64_t k = 0; k < samples; ++k) mix(&idx->cp_occ[(size_t)(k * (ncp - 1) / (samples > 1 ? samples - 1 : 1))], sizeof(gbx_fmi_cp_occ));
+    return h;
+}
+struct FmiUse {                       // holds a cache entry for the duration of a call
+    void *d_index = nullptr;
+    ~FmiUse()
+    {
+        if (!d_index) return;
+        std::lock_guard<std::mutex> lk(g_fmi_mu);
+        for (FmiCached &c : g_fmi_cache) if (c.d_index == d_index && c.users > 0) { --c.users; break; }
+    }
+};
 }
 
 // One device (the calling thread's current one).  `base` = index of read 0 in the caller's job (error texts only).
@@ -110,13 +133,29 @@ static int fmi_host_one(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64
     Lane *L = lane.l;
     hipStream_t s = L->compute;
     // the device index: cached, or uploaded in the reference's layout and re-laid on the device
+    FmiUse use;
     void *d_index = nullptr;
     {
+        const uint64_t fp = fmi_fingerprint(idx);
         std::lock_guard<std::mutex> lk(g_fmi_mu);
-        for (const FmiCached &c : g_fmi_cache)
-            if (c.dev == dev && c.host_cp == idx->cp_occ && c.len == idx->ref_seq_len && c.sentinel == idx->sentinel_index && c.count1 == idx->count[1])
-                d_index = c.d_index;
+        for (FmiCached &c : g_fmi_cache)
+            if (c.dev == dev && c.len == idx->ref_seq_len && c.sentinel == idx->sentinel_index && c.fp == fp &&
+                !memcmp(c.count, idx->count, sizeof(c.count))) {
+                d_index = c.d_index; ++c.users; c.last_use = ++g_fmi_clock;
+            }
         if (!d_index) {
+            // at most four idle entries per device: the least recently used goes first
+            for (;;) {
+                int idle = 0, victim = -1;
+                for (size_t k = 0; k < g_fmi_cache.size(); ++k)
+                    if (g_fmi_cache[k].dev == dev && g_fmi_cache[k].users == 0) {
+                        ++idle;
+                        if (victim < 0 || g_fmi_cache[k].last_use < g_fmi_cache[(size_t)victim].last_use) victim = (int)k;
+                    }
+                if (idle < 4) break;
+                (void)hipFree(g_fmi_cache[(size_t)victim].d_index);
+                g_fmi_cache.erase(g_fmi_cache.begin() + victim);
+            }
             const size_t bytes = fmi_index_bytes(idx->ref_seq_len);
             void *d_src = nullptr;
             GBX_HIP(hipMalloc(&d_index, bytes));
@@ -129,8 +168,11 @@ static int fmi_host_one(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64
             hipError_t e2 = hipStreamSynchronize(s);
             (void)hipFree(d_src);
             if (rc || e2 != hipSuccess) { (void)hipFree(d_index); return rc ? rc : hip_fail(e2, "fmi index build"); }
-            g_fmi_cache.push_back(FmiCached{dev, idx->cp_occ, idx->ref_seq_len, idx->sentinel_index, idx->count[1], d_index, bytes});
+            FmiCached c{dev, idx->ref_seq_len, idx->sentinel_index, {0, 0, 0, 0, 0}, fp, d_index, bytes, 1, ++g_fmi_clock};
+            memcpy(c.count, idx->count, sizeof(c.count));
+            g_fmi_cache.push_back(c);
         }
+        use.d_index = d_index;
     }
     DevBuf denc(L), doff(L), dlen(L), dout(L), dso(L), dn(L), dw(L);
     const char *cap_env = getenv("GBX_FMI_RAW_CAP");          /* test aid: records per read slot of the first pass */
@@ -271,8 +313,16 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
 int gbx_fmi_host_release(void)
 {
     std::lock_guard<std::mutex> lk(g_fmi_mu);
-    for (FmiCached &c : g_fmi_cache) (void)hipFree(c.d_index);
-    g_fmi_cache.clear();
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (size_t k = 0; k < g_fmi_cache.size();) {
+        if (g_fmi_cache[k].users > 0) { ++k; continue; }        // a call is using it: it goes at the next release
+        (void)hipSetDevice(g_fmi_cache[k].dev);
+        (void)hipFree(g_fmi_cache[k].d_index);
+        g_fmi_cache.erase(g_fmi_cache.begin() + (long)k);
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     return GBX_OK;
 }
 

@@ -395,7 +395,8 @@ typedef struct gbx_fmi_params {      /* fmi.cpp:135-140,178 */
 } gbx_fmi_params;
 void gbx_fmi_default_params(gbx_fmi_params *p, int32_t min_seed_len);
 
-/* Host-buffer entry: reads as base codes 0..3 (4 = ambiguous, fmi.cpp:113-124), read r = enc[read_off[r] ..+ read_len[r]).
+/* Host-buffer entry: reads as base codes 0..3 (4 = ambiguous, fmi.cpp:113-124; the CONTRACT is codes 0..4 - larger values are not
+ * checked and their treatment is unspecified), read r = enc[read_off[r] ..+ read_len[r]).
  * out receives the SMEMs (out_cap records; GBX_ERR_ARG with the needed count in gbx_last_error() when it is too small),
  * smem_off[n_reads + 1] (nullable) where each read's run starts, *n_out the total. */
 int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t n_reads, const uint8_t *enc, int64_t enc_bytes,
@@ -421,8 +422,9 @@ int gbx_fmi_smem_device(const gbx_fmi_index *idx, const void *d_index, const gbx
 int gbx_fmi_overflow(const void *d_work, int64_t *worst, void *stream);
 /* backwardExt calls (checkpoint look-ups: two 64-byte lines each) of the last gbx_fmi_smem_device call on this workspace. */
 int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream);
-/* gbx_fmi_smem_host keeps the device copy of an index between calls (keyed by the cp_occ address and the index scalars:
- * a caller hands over the same tables for every batch of reads, fmi.cpp:218); this frees them. */
+/* gbx_fmi_smem_host keeps the device copy of an index between calls (a caller hands over the same tables for every batch
+ * of reads, fmi.cpp:218), found again by content - the index scalars and a fingerprint of 256 checkpoints - not by address;
+ * at most four idle copies per device; this frees the ones no call is using. */
 int gbx_fmi_host_release(void);
 
 #ifdef __cplusplus

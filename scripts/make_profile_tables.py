@@ -80,8 +80,20 @@ def main():
         path = os.path.join(ROOT, "gpurun_out", "%s_%s_pmc.json" % (tag, k))
         if not os.path.exists(path):
             continue
-        stamps[k] = sha16(os.path.join(CSRC, KIND_SOURCE[k]))
-        for kname, v in json.load(open(path)).items():
+        table = json.load(open(path))
+        # the stamp is the one recorded when the counters were collected (scripts/pmc_summary.py); a file without one (older
+        # collections) is only accepted while the source still hashes to what the committed table says
+        cur = sha16(os.path.join(CSRC, KIND_SOURCE[k]))
+        rec = table.pop("_hip_sha16", None)
+        if rec is None and stamps.get(k) != cur:
+            print("skipping %s: no collection-time stamp and the source has changed" % path)
+            continue
+        stamps[k] = rec or cur
+        # entries of this kind carried over from earlier collections describe another source: drop them
+        for d in (traffic, busy, insts):
+            for name in [n for n in d if n.startswith(k + "_")]:
+                del d[name]
+        for kname, v in table.items():
             if not kname.startswith(("bsw_", "chain_", "phmm_", "poa_", "abea_", "fmi_")):
                 continue
             name = stage_name(kname)

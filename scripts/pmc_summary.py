@@ -18,4 +18,11 @@ for kn, d in agg.items():
     if "SQ_WAIT_INST_ANY" in d and d.get("SQ_WAVE_CYCLES"): d["wait_frac"] = d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"]
     out[kn] = {k: round(v, 3) for k, v in d.items()}
     print("%-36s launches %d" % (kn, L), {k: (round(v, 3) if v < 100 else int(v)) for k, v in d.items()})
+# the hash of the kernel source these counters were collected on, recorded HERE (at collection time, on the box that ran
+# them): scripts/make_profile_tables.py copies it, so that re-running that script later cannot re-stamp old counters
+import hashlib, os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_kind = os.path.basename(sys.argv[1].rstrip("/")).replace("pmc_", "")
+_src = os.path.join(_root, "genomicsbench_amd", "csrc", _kind + "_kernels.hip")
+if os.path.exists(_src): out["_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]
 if len(sys.argv) > 2: json.dump(out, open(sys.argv[2], "w"), indent=1)

@@ -35,6 +35,10 @@ def main():
     os.makedirs(out, exist_ok=True)
     base = os.path.join(out, "%s_%drank" % (tag, n))
     env = dict(os.environ, GBX_BENCH_COMM="gloo")
+    # (no caching allocator in the ranks: eight of them on one device otherwise strand ~6 GB each in reserved-but-unused
+    # segments, which is the difference between fitting 288 GB and not: 8 x (12.5 GB of fmi buffers + 18.4 GB of workspace))
+    env.setdefault("PYTORCH_NO_CUDA_MEMORY_CACHING", "1")
+    env.setdefault("PYTORCH_NO_HIP_MEMORY_CACHING", "1")
     peak = {"vram": 0, "rss": 0, "vram_idle": vram_used()}
     t0 = time.time()
     with open(base + "_bench.json", "w") as fo, open(base + "_stderr.log", "w") as fe:

@@ -248,3 +248,28 @@ def test_index_built_on_the_gpu_equals_the_cpu_build():
     a, b = build_index(g), build_index(g, device="cuda:0").host()
     assert a.count == b.count and a.sentinel_index == b.sentinel_index and a.ref_seq_len == b.ref_seq_len
     assert np.array_equal(a.cp_occ.view(np.uint8), b.cp_occ.view(np.uint8))
+
+
+def test_host_index_cache_is_keyed_by_content_not_by_address():
+    """gbx_fmi_smem_host keeps the device copy of an index between calls.  A caller that reuses the same host buffer for
+    another index of the same length (rebuilt in place) must get that index's SMEMs, not the cached one's; the cache
+    release is safe beside other entries and repeated."""
+    from genomicsbench_amd import _native as N
+    from genomicsbench_amd.fmi import FmiIndex
+    ga, gb = gen_fmi_genome(120_000, 6101), gen_fmi_genome(120_000, 6102)
+    ia, ib = build_index(ga), build_index(gb)
+    assert ia.ref_seq_len == ib.ref_seq_len
+    P = default_params(19)
+    ra, rb = gen_fmi_reads(ga, 800, 6103), gen_fmi_reads(gb, 800, 6104)
+    assert_same(smem_host(ia, ra, P), O.fmi_oracle(ia, ra, P, nthreads=4))
+    shared = FmiIndex(ia.ref_seq_len, ib.count, ib.sentinel_index, ia.cp_occ)     # A's buffer ...
+    shared.cp_occ[:] = ib.cp_occ                                                   # ... now holds B's tables: same address
+    assert_same(smem_host(shared, rb, P), O.fmi_oracle(ib, rb, P, nthreads=4))
+    for _ in range(2):
+        N.check(N.lib().gbx_fmi_host_release())
+    assert_same(smem_host(shared, rb, P), O.fmi_oracle(ib, rb, P, nthreads=4))
+    for seed in range(6):                                                          # more indexes than the cache keeps idle
+        g = gen_fmi_genome(40_000 + 1000 * seed, 6200 + seed)
+        ix, rs = build_index(g), gen_fmi_reads(g, 100, 6300 + seed)
+        assert_same(smem_host(ix, rs, P), O.fmi_oracle(ix, rs, P, nthreads=4))
+    N.check(N.lib().gbx_fmi_host_release())
