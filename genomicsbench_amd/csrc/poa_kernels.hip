@@ -376,18 +376,20 @@ __device__ inline v2s pk_apply(const PkMat &m, v2s eq) { return pk_max(pk_add(m.
 // costing a synchronous round trip in the middle of its row.  The ring shares the window's LDS with the topological sort's
 // arrays - the two are never live together; the sort's state bytes are parked in the slot meanwhile (st8save), its
 // previous ranks are n2r - so the twelve windows per CU stay.
-constexpr int POA_RING_ROWS = 6;
 constexpr int POA_RING_SLOT = 64 * 16 * 2 + 16;            // H vectors, deficit vectors (16 B per lane each), {F0, O0, -, H0}
-constexpr int POA_RING_BYTES = POA_RING_ROWS * POA_RING_SLOT;
+constexpr int POA_RING_DEFAULT = 6;                        // rows: 12.4 KB, what the sort's arrays take for 'large'
+constexpr int POA_RING_BYTES = POA_RING_DEFAULT * POA_RING_SLOT;
 typedef __attribute__((address_space(3))) v8s lds_v8s;
 typedef __attribute__((address_space(3))) v4u lds_v4u;
 typedef __attribute__((address_space(3))) v2u lds_v2u;
 
-template <bool RING>
+template <int POA_RING_ROWS>                                // 0: no ring
 __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
                                  int &max_i, int &max_j, char *lds_ring = nullptr)
 {
     constexpr int CPL = 8;
+    constexpr bool RING = POA_RING_ROWS > 0;
+    constexpr int RROWS = RING ? POA_RING_ROWS : 1;
     const int lane = threadIdx.x & 63;
     const PoaScore S = A.S;
     const int Wp = M.Wp;
@@ -438,16 +440,16 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     // row `prow` out of the ring (it was written at most POA_RING_ROWS rows ago and not overwritten since)
     char *const ring_lane = lds_ring + lane * 16;
     auto ring_fetch = [&](int prow, PoaPredIn &x) {
-        char *const sl = ring_lane + (prow % POA_RING_ROWS) * POA_RING_SLOT;
+        char *const sl = ring_lane + (prow % RROWS) * POA_RING_SLOT;
         x.h = *(const lds_v8s *)sl;
         x.fo = *(const lds_v4u *)(sl + 1024);
-        const v2u c0 = *(const lds_v2u *)(lds_ring + (prow % POA_RING_ROWS) * POA_RING_SLOT + 2048);
+        const v2u c0 = *(const lds_v2u *)(lds_ring + (prow % RROWS) * POA_RING_SLOT + 2048);
         x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
     };
     // a predecessor row for the row `target` (prow < target, and not the row being computed): ring or memory
     auto fetch_pred = [&](int prow_v, int computing, PoaPredIn &x) {
         const int prow = __builtin_amdgcn_readfirstlane(prow_v);       // the same in every lane: a scalar branch, scalar slot arithmetic
-        if (RING && prow >= 1 && computing - prow <= POA_RING_ROWS) ring_fetch(prow, x);
+        if (RING && prow >= 1 && computing - prow <= RROWS) ring_fetch(prow, x);
         else fetch(prow, x);
     };
     auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
@@ -619,13 +621,13 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         last.fo.w = __builtin_amdgcn_perm(pk_bits(q3), pk_bits(q2), 0x06040200u);
         *(v8s *)(M.H + ro + j0) = last.h; *(v4u *)(M.F + ro + j0) = last.fo;
         if (RING) {
-            char *const sl = ring_lane + (i % POA_RING_ROWS) * POA_RING_SLOT;
+            char *const sl = ring_lane + (i % RROWS) * POA_RING_SLOT;
             *(lds_v8s *)sl = last.h;
             *(lds_v4u *)(sl + 1024) = last.fo;
             if (lane == 0) {
                 v2u c0;
                 c0.x = ((unsigned)F0 & 0xffffu) | ((unsigned)O0 << 16); c0.y = (unsigned)H0 << 16;
-                *(lds_v2u *)(lds_ring + (i % POA_RING_ROWS) * POA_RING_SLOT + 2048) = c0;
+                *(lds_v2u *)(lds_ring + (i % RROWS) * POA_RING_SLOT + 2048) = c0;
             }
         }
         if (sink) {                                            // H(i, len)
@@ -1491,8 +1493,10 @@ __device__ __attribute__((always_inline)) inline void poa_bind_lds(PoaTopoLds &T
 // DP grew by a dozen instructions) takes `PoaGraph &` by reference: the graph's pointers then live in scratch memory,
 // lose their address space, and every access of the kernel becomes a FLAT instruction (993 of them, 397 instead of
 // 330 ms, found through SQ_INSTS_LDS dropping to nothing).
-template <bool LONG>
-__global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
+// WAVES / RROWS: wavefronts per SIMD the instance is compiled for and rows of the DP's LDS ring (main launch only): <3, 6> is
+// the default (168 VGPRs with spills, twelve windows per CU), <2, 9> the variant without spills (GBX_POA_OCC=2)
+template <bool LONG, int WAVES = 3, int RROWS = POA_RING_DEFAULT>
+__global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
 {
     char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
     PoaGraph g;
@@ -1539,7 +1543,7 @@ __global__ void __launch_bounds__(64, 3) poa_kernel(PoaArgs A, SlotLayout L)
                 // The serial phases (one useful lane) are latency chains that lose issue slots to the other wavefronts' DP rows;
                 // the DP is throughput work that does not mind waiting.  Priority 3 for the former: 300.8 -> 294.7 ms.
                 __builtin_amdgcn_s_setprio(0);
-                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined<!LONG>(g, M, A, seq, len, mi, mj, lds_raw);
+                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined<LONG ? 0 : RROWS>(g, M, A, seq, len, mi, mj, lds_raw);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 __builtin_amdgcn_s_setprio(3);
@@ -1652,7 +1656,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLay
         g.n_path = 0;
         if (g.n_nodes != 0 && len != 0 && g.err == 0) {
             extern __shared__ __attribute__((aligned(16))) char lds_dp[];
-            poa_dp_pipelined<true>(g, M, A, seq, len, mi, mj, lds_dp);     // the row ring: this kernel has no other use for LDS
+            poa_dp_pipelined<POA_RING_DEFAULT>(g, M, A, seq, len, mi, mj, lds_dp);     // the row ring: this kernel has no other use for LDS
             dp_ran = 1;
             if (lane == 0) atomicAdd(A.cells, (unsigned long long)g.n_nodes * (unsigned long long)len);
         }
@@ -1900,7 +1904,11 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         if (has_long && resident > 2 * (int64_t)plan->long_slots) resident -= plan->long_slots;
         const int grid = (int)std::min<int64_t>(n_windows - plan->n_long_windows, resident);
         Stage st("poa_window", s);
-        hipLaunchKernelGGL(poa_kernel<false>, dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
+        const char *oe = getenv("GBX_POA_OCC");             // tuning aid: 2 = the instance compiled for two wavefronts per SIMD (no spills, nine ring rows)
+        if (oe && atoi(oe) == 2)
+            hipLaunchKernelGGL((poa_kernel<false, 2, 9>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)9 * POA_RING_SLOT), s, A, L);
+        else
+            hipLaunchKernelGGL((poa_kernel<false>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
     }
     if (ss && (rc = ss->join(s))) return rc;
     GBX_HIP(hipGetLastError());

@@ -26,9 +26,21 @@ N.check(N.lib().gbx_host_prepare())
 t_end = time.time() + budget
 count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0, "fmi": 0}
 fmi_idx = {}                                                    # genome length -> (genome, index): built once per size
+n_multi = 0
 while time.time() < t_end:
     k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea", "fmi"])
     seed = int(rng.integers(1, 1 << 30))
+    # a third of the jobs through the multi-device layer of the host entries: 2-4 logical devices on this GPU, cut however
+    # small the job is (half of those) or only when it is large enough by the kernel's own threshold
+    ndev = int(rng.choice([2, 3, 4])) if rng.random() < 0.33 else 0
+    for v in ("GBX_DEVICE_MAP", "GBX_SHARD_MIN_UNITS"):
+        os.environ.pop(v, None)
+    if ndev:
+        os.environ["GBX_DEVICE_MAP"] = ",".join(["0"] * ndev)
+        if rng.random() < 0.5:
+            os.environ["GBX_SHARD_MIN_UNITS"] = "1"
+        n_multi += 1
+    N.check(N.lib().gbx_host_set_devices(ndev))
     if k == "bsw":
         n = int(rng.choice([1, 7, 64, 513, 4000, 16384, 16385, 40000, 260000]))
         adv = rng.random() < 0.4 and n <= 40000
@@ -63,7 +75,9 @@ while time.time() < t_end:
             fmi_idx[glen] = (g, build_index(g))
         g, idx = fmi_idx[glen]
         nr = int(rng.choice([1, 17, 500, 6000]))
-        rl = int(rng.choice([30, 76, 151, 250, 400]))
+        rl = int(rng.choice([30, 76, 151, 250, 400, 2500, 8100, 9000]))        # the last two: read in place, not staged in LDS
+        if rl > 1000:
+            nr = min(nr, 17)
         rs = gen_fmi_reads(g, nr, seed, read_len=min(rl, glen // 4))
         if rng.random() < 0.3:                                   # ragged lengths
             keep = rng.integers(1, rs.read_len[0] + 1, nr).astype(np.int32)
@@ -97,10 +111,20 @@ while time.time() < t_end:
         nw = int(rng.choice([1, 5, 40]))
         ws = gen_poa(nw, seed)
         pp = poa_params()
-        ok = consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
-        what = "windows=%d" % nw
+        lock = rng.random() < 0.4                                # the lock-step form (default: the window kernel with the row ring)
+        if lock:
+            os.environ["GBX_POA_LOCKSTEP"] = "1"
+            os.environ["GBX_POA_TB_SERIAL"] = str(int(rng.integers(0, 2)))
+            os.environ["GBX_POA_DP_OCC"] = str(int(rng.choice([5, 6])))
+        try:
+            ok = consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
+        finally:
+            for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC"):
+                os.environ.pop(v, None)
+        what = "windows=%d lockstep=%s" % (nw, lock)
+    what += " devices=%d min_units=%s" % (ndev, os.environ.get("GBX_SHARD_MIN_UNITS"))
     count[k] += 1
     if not ok:
         print("MISMATCH %s seed=%d %s" % (k, seed, what), flush=True)
         sys.exit(1)
-print("fuzz ok:", count, flush=True)
+print("fuzz ok:", count, "of which through 2-4 logical devices:", n_multi, flush=True)
