@@ -349,11 +349,23 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
             int sb = 0;                                           // unsorted calls: block of 64 x-values cached for the st scan
             uint64_t xs = n ? x[min(lane, n - 1)] : 0;
             int sib = 0;                                          // ib mod RING_PHYS (blocks are slab-aligned: 320 = 5 x 64)
+            // The anchors of block ib + 64 are requested while block ib is computed (round 4).  gfx9 counts loads and stores in
+            // one in-order counter: three loads each settled on the spot at the head of a block were three serial round
+            // trips, and each of those waits was also a wait for the acknowledgement of the previous block's output stores -
+            // about 6 us per 64 anchors of a kernel whose longest job decides everything.  The anchors are requested a block
+            // ahead, and a block's outputs are stored at the head of the NEXT block, behind the wait for its anchors (the
+            // compiler cannot count the memory operations of the inner loops, so that wait is a vmcnt(0): it must not find a
+            // young store in the queue - the ones it finds are a whole block old).
+            uint64_t nxa = 0, nya = 0;
+            int nstv = 0;
+            if (n > 0) { const int ia0 = min(lane, n - 1); nxa = x[ia0]; nya = y[ia0]; nstv = stp[ia0]; }
+            int pf_ = 0, pp_ = 0, pk_ = 0, pkmax = 0;             // the previous block's outputs, not yet stored
             for (int ib = 0; ib < n; ib += 64, sib = sib + 64 == RING_PHYS ? 0 : sib + 64) {
                 // this block's anchors, one per lane
-                const int ia = min(ib + lane, n - 1);
-                const uint64_t xa = settle(x[ia]), ya = settle(y[ia]);
-                const int stv = settle(stp[ia]) - cbase;          // st(i) >= cbase for every anchor of the job
+                const uint64_t xa = settle(nxa), ya = settle(nya);
+                const int stv = settle(nstv) - cbase;             // st(i) >= cbase for every anchor of the job
+                if (lane < pkmax) { f[ib - 64 + lane] = pf_; p[ib - 64 + lane] = pp_ >= 0 ? pp_ + cbase : pp_; pk[ib - 64 + lane] = pk_; }
+                if (ib + 64 < n) { const int ian = min(ib + 64 + lane, n - 1); nxa = x[ian]; nya = y[ian]; nstv = stp[ian]; }
                 const int kmax = min(64, n - ib);
                 const int live0 = ib - RING_LIVE;                 // anchors >= live0 are addressed in the ring during this block
                 // the slab this block fills holds the anchors [ib-320, ib-256): their targets are final (no anchor of this
@@ -575,10 +587,12 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                     if (lane == 0) rst[si] = make_int4(max_f, max_j, 0, pki);
                     STAMP(8);
                 }
-                if (lane < kmax) { f[ib + lane] = of_; p[ib + lane] = op_ >= 0 ? op_ + cbase : op_; pk[ib + lane] = ok_; }
+                pf_ = of_; pp_ = op_; pk_ = ok_; pkmax = kmax;
             }
-            // targets still in the ring: the anchors of the last five blocks
+            // the last block's outputs, and the targets still in the ring: the anchors of the last five blocks
             if (n > 0) {
+                const int ibp = (n - 1) & ~63;
+                if (lane < pkmax) { f[ibp + lane] = pf_; p[ibp + lane] = pp_ >= 0 ? pp_ + cbase : pp_; pk[ibp + lane] = pk_; }
                 const int ibl = (n - 1) & ~63;                    // start of the last block, whose slab is sib - 64 (mod 320)
                 const int sibl = sib == 0 ? RING_PHYS - 64 : sib - 64;
                 for (int a = max(0, ibl - RING_LIVE) + lane; a < n; a += 64) {

@@ -111,17 +111,17 @@ int side_streams(SideStreams **out)
     SideStreams *ss = new SideStreams();
     GBX_HIP(hipEventCreateWithFlags(&ss->ev_fork, hipEventDisableTiming));
     GBX_HIP(hipEventCreateWithFlags(&ss->ev_aux, hipEventDisableTiming));
-    // Stream priorities (GBX_SIDE_PRIO="-1,-1,0": one number per side stream, HIP's scale - lower = more urgent; default
-    // "-1,-1,0").  The launches of a call that are queued together share the chip; which of them gets the workgroup
-    // slots first decides which one is the call's tail.  bsw puts its longest-query classes on side streams 0 and 1: their
-    // wavefronts hold the most LDS and run at the lowest occupancy, so they should finish FIRST and leave the tail to
-    // the short-query classes, which fill a CU on their own.
+    // Stream priorities (GBX_SIDE_PRIO="-1,-1,0": one number per side stream, HIP's scale - lower = more urgent; default all
+    // 0).  A tuning aid that stayed one: bsw puts its longest-query classes on side streams 0 and 1 - their wavefronts hold
+    // the most LDS and run at the lowest occupancy, so they should finish first and leave the tail to the short-query
+    // classes - but on MI355X the priority of a stream did not move which launch gets the workgroup slots: "-1,-1,0",
+    // "-1,0,1", "-1,-1,-1" and "0,0,0" all gave 5.77-5.83 ms per step on 'large' (profiles/r04h_ab.txt).
     int prio[SideStreams::N];
     {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
         const char *e = getenv("GBX_SIDE_PRIO");
-        const char *q = e ? e : "-1,-1,0";
+        const char *q = e ? e : "0,0,0";
         for (int k = 0; k < SideStreams::N; ++k) {
             int v = atoi(q);
             v = v < greatest ? greatest : v > least ? least : v;

@@ -113,6 +113,15 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, b
 #ifndef GBX_POA_SERIAL_WAVES
 #define GBX_POA_SERIAL_WAVES 3      // ... and the serial-phase kernel (its LDS admits twelve windows per CU)
 #endif
+#ifndef GBX_POA_LONG_WAVES
+#define GBX_POA_LONG_WAVES 1        // the long-window instance: wavefronts per SIMD it is compiled for,
+#endif
+#ifndef GBX_POA_LONG_RING
+#define GBX_POA_LONG_RING 1         // ... whether its pipelined DP (sequences up to 512 columns) uses the row ring,
+#endif
+#ifndef GBX_POA_LONG_INC
+#define GBX_POA_LONG_INC 1          // ... and whether its topological sort is the incremental one
+#endif
 #ifndef GBX_POA_PLANES
 #define GBX_POA_PLANES 2
 #endif
@@ -412,9 +421,16 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     if (lane == 0) { M.H[POA_COL0 + POA_C0_F] = 0; M.H[POA_COL0 + POA_C0_O] = 0; }
     int32_t *d_pred = g.score, *d_info = g.pred;
     const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;
+    int32_t *d_pred3 = g.stack;                                // RING: the 4th predecessor's row (the sort's order buffer is free during the DP)
     {
         PoaGraph &gm = const_cast<PoaGraph &>(g);
-        for (int r = lane; r < n; r += 64) poa_rowdesc_one(gm, r);
+        for (int r = lane; r < n; r += 64) {
+            poa_rowdesc_one(gm, r);
+            if (RING) {
+                const int node = g.r2n[r];
+                d_pred3[r] = g.in_cnt[node] > 3 ? g.n2r[PG_IN_SRC(g, node, 3)] + 1 : 0;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -430,6 +446,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         for (int k = 0; k < 4; ++k) sqp[k] = pk2(sq[2 * k], sq[2 * k + 1]);
     }
 
+    auto wait_vm = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };   // vmcnt(0) only (lgkmcnt 15, expcnt 7: not waited for)
     auto fetch = [&](int prow, PoaPredIn &x) {
         const int64_t b = (int64_t)prow * Wp + POA_COL0;
         x.h = *(const v8s *)(M.H + b + j0);
@@ -450,11 +467,35 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     auto fetch_pred = [&](int prow_v, int computing, PoaPredIn &x) {
         const int prow = __builtin_amdgcn_readfirstlane(prow_v);       // the same in every lane: a scalar branch, scalar slot arithmetic
         if (RING && prow >= 1 && computing - prow <= RROWS) ring_fetch(prow, x);
-        else fetch(prow, x);
+        else {
+            fetch(prow, x);
+            if (RING) { wait_vm(); asm volatile("" : "+v"(x.h), "+v"(x.fo), "+v"(x.h0), "+v"(x.o0), "+v"(x.f0)); }
+        }
+    };
+    // RING: the row loop issues NO vector-memory load in its steady state.  gfx9 counts loads and stores in one in-order
+    // counter, so a wait for any load is also a wait for the acknowledgement of every store issued before it: with the
+    // descriptors of rows r+2 requested every iteration, and a wait for them every iteration, each row also waited for the
+    // HBM acknowledgement of the row stored before it (the ISA had four `s_waitcnt vmcnt(0)` per row).  The descriptors of
+    // 64 consecutive rows now sit in five registers (lane k = row qbase + k; a row's values are v_readlane'd, i.e. scalar),
+    // refilled once per 62 rows; a predecessor row is the previous row's registers, an LDS read of the ring, or - 3 % - a
+    // load that is waited for on the spot, inside its own branch, so that the merged code carries no wait.
+    int q_p0 = 0, q_p1 = 0, q_p2 = 0, q_p3 = 0, q_info = 0, qbase = 0;
+    auto refill = [&](int base) {
+        qbase = base;
+        const int rr = min(base + lane, n - 1);
+        q_p0 = d_pred[rr]; q_p1 = d_pred1[rr]; q_p2 = d_pred2[rr]; q_p3 = d_pred3[rr]; q_info = d_info[rr];
+        wait_vm();
+        asm volatile("" : "+v"(q_p0), "+v"(q_p1), "+v"(q_p2), "+v"(q_p3), "+v"(q_info));
     };
     auto desc = [&](int r, int &p0, int &p1, int &p2, int &info) {
         const int rr = min(r, n - 1);
-        p0 = d_pred[rr]; p1 = d_pred1[rr]; p2 = d_pred2[rr]; info = d_info[rr];
+        if (RING) {
+            const int l = rr - qbase;
+            p0 = __builtin_amdgcn_readlane(q_p0, l); p1 = __builtin_amdgcn_readlane(q_p1, l); p2 = __builtin_amdgcn_readlane(q_p2, l);
+            info = __builtin_amdgcn_readlane(q_info, l);
+        } else {
+            p0 = d_pred[rr]; p1 = d_pred1[rr]; p2 = d_pred2[rr]; info = d_info[rr];
+        }
     };
     auto settle_i = [](int &v) { asm volatile("" : "+v"(v)); };
     auto settle_in = [&](PoaPredIn &x) {
@@ -488,6 +529,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     if (n == 0) return;
     // descriptors: row r (a*), row r+1 (b*), row r+2 is requested inside the loop
     int ap0, ap1, ap2, ainfo, bp0, bp1, bp2, binfo;
+    if (RING) refill(0);
     desc(0, ap0, ap1, ap2, ainfo);
     desc(1, bp0, bp1, bp2, binfo);
     PoaPredIn in0, in1, last;
@@ -510,6 +552,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         const bool sink = (info >> 16) & 1;
         const int64_t ro = (int64_t)i * Wp + POA_COL0;
         int cp0, cp1, cp2, cinfo;                              // row r+2
+        if (RING && r + 2 >= qbase + 64 && r + 2 < n) refill(r);
         desc(r + 2, cp0, cp1, cp2, cinfo);
 
         // match / mismatch score of the lane's columns against this row's letter: m + (n-m) * (seq != letter)
@@ -548,7 +591,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
             // row has none / it is this very row; the rare row from further back waits for memory)
             const int snic = __builtin_amdgcn_readfirstlane(nic);
             const bool s0 = __builtin_amdgcn_readfirstlane((int)nreg0) != 0, s1 = __builtin_amdgcn_readfirstlane((int)nreg1) != 0;
-            if (snic >= 1 && !s0) fetch_pred(bp0, i, in0); else if (r + 1 < n && snic == 0) fetch(0, in0);
+            if (snic >= 1 && !s0) fetch_pred(bp0, i, in0); else if (r + 1 < n && snic == 0) fetch_pred(0, i, in0);
             if (snic >= 2 && !s1) fetch_pred(bp1, i, in1);
         } else {
             fetch(nic >= 1 && !nreg0 ? bp0 : 0, in0);
@@ -556,9 +599,16 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         }
         // ---- predecessors beyond the second: read in place (rare)
         if (ic > 2) {
-            const int node = g.r2n[r];
+            // (RING: the third and fourth come from the descriptor registers; a fifth and further ones - rarer still - walk the
+            // in-edge list in memory and wait for it here, inside the branch)
+            const int p3 = RING ? __builtin_amdgcn_readlane(q_p3, r - qbase) : 0;
+            int node = 0;
+            if (!RING || ic > 4) { node = g.r2n[r]; if (RING) { wait_vm(); asm volatile("" : "+v"(node)); } }
             for (int k = 2; k < ic; ++k) {
-                const int prow = k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1;
+                int prow;
+                if (k == 2) prow = p2;
+                else if (RING && k == 3) prow = p3;
+                else { prow = g.n2r[PG_IN_SRC(g, node, k)] + 1; if (RING) { wait_vm(); asm volatile("" : "+v"(prow)); } }
                 PoaPredIn x;
                 fetch_pred(prow, i, x);
                 po = max(po, x.o0); pf = max(pf, x.f0);
@@ -1415,8 +1465,23 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
     TOPO_TIMED(g)
 }
 
+// The main launch is held back until the long-window launch (queued beside it on a side stream) has its wavefronts on the
+// chip.  A long window is a serial job of the whole kernel's length, so it must start at once; but its instance is compiled
+// for fewer, larger wavefronts, and once the main grid has filled the SIMDs (three wavefronts of 168 VGPRs each) a larger
+// wavefront finds no room until main wavefronts retire - tens of milliseconds later.  One wavefront polls a counter the
+// long instance bumps on entry, for at most a couple of milliseconds (a launch that cannot get all its blocks resident
+// must not hold the main one back for ever).
+__global__ void poa_gate_kernel(const unsigned long long *started, unsigned target)
+{
+    for (int k = 0; k < 600; ++k) {
+        const unsigned long long v = __hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 constexpr int POA_SWEEPS = 8;
-constexpr int POA_CNT_MAIN = 14, POA_CUR_MAIN = 15, POA_CNT_LONG = 16, POA_CUR_LONG = 17, POA_NCOUNTERS = 32;
+constexpr int POA_CNT_MAIN = 14, POA_CUR_MAIN = 15, POA_CNT_LONG = 16, POA_CUR_LONG = 17, POA_LONG_STARTED = 18, POA_NCOUNTERS = 32;
 // Work lists (one block).  A window's cost grows with the square of its sequence count, so the main launch hands the
 // windows out heaviest class first (class = sequences per window against the job's mean: the kernel's tail is then made of
 // light windows); windows that hold a sequence of more than POA_PIPE_MAXLEN bases go to the second launch's list.
@@ -1505,6 +1570,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
     PoaTopoLds T;
     poa_bind_lds(T, lds_raw, A);
     poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
+    if (LONG && (threadIdx.x & 63) == 0) atomicAdd(A.cells + POA_LONG_STARTED, 1ull);      // poa_gate_kernel waits for these
 
     unsigned long long cells = 0;
 #ifdef GBX_POA_PHASE_STATS
@@ -1543,7 +1609,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
                 // The serial phases (one useful lane) are latency chains that lose issue slots to the other wavefronts' DP rows;
                 // the DP is throughput work that does not mind waiting.  Priority 3 for the former: 300.8 -> 294.7 ms.
                 __builtin_amdgcn_s_setprio(0);
-                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined<LONG ? 0 : RROWS>(g, M, A, seq, len, mi, mj, lds_raw);
+                if (!LONG || len <= POA_PIPE_MAXLEN) poa_dp_pipelined<(LONG && !GBX_POA_LONG_RING) ? 0 : RROWS>(g, M, A, seq, len, mi, mj, lds_raw);
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 __builtin_amdgcn_s_setprio(3);
@@ -1556,15 +1622,15 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
             }
             {
                 PH_T0
-                if (!LONG && T.use && ran_dp) {
+                if (T.use && ran_dp) {
                     // the DP's row ring has used the sort's LDS: state bytes back from the slot, previous ranks = n2r
                     const uint8_t *save = (const uint8_t *)(slot + L.st8save);
                     for (int i = threadIdx.x & 63; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                if (g.err == 0) poa_add_alignment_wave<!LONG>(g, seq, len, T);
-                if (!LONG && T.use && s + 1 < s1) {
+                if (g.err == 0) poa_add_alignment_wave<(!LONG || GBX_POA_LONG_INC)>(g, seq, len, T);
+                if (T.use && s + 1 < s1) {
                     uint8_t *save = (uint8_t *)(slot + L.st8save);
                     for (int i = threadIdx.x & 63; i < g.n_nodes; i += 64) save[i] = T.st8[i];
                 }
@@ -1869,7 +1935,9 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         B.work = wb + ws.lslots; B.slot_bytes = LL.total; B.wlist = d_llist; B.cnt_idx = POA_CNT_LONG; B.cur_idx = POA_CUR_LONG;
         hipStream_t sl = ss ? ss->side[0] : s;
         Stage st("poa_window_long", sl);
-        hipLaunchKernelGGL(poa_kernel<true>, dim3(plan->long_slots), dim3(64), A.lds_marks ? lds_need : 0, sl, B, LL);
+        // (compiled for one wavefront per SIMD: the handful of long windows of a job run a wavefront per CU at most, and with
+        // all 512 VGPRs the instance - column-block DP, ring, both sorts - has no spills; at 168 it spilled 222)
+        hipLaunchKernelGGL((poa_kernel<true, GBX_POA_LONG_WAVES>), dim3(plan->long_slots), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), sl, B, LL);
     }
     const int64_t n_main = n_windows - plan->n_long_windows;
     if (has_main && poa_use_lockstep(plan, n_main)) {
@@ -1903,6 +1971,12 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         int64_t resident = plan->n_slots;
         if (has_long && resident > 2 * (int64_t)plan->long_slots) resident -= plan->long_slots;
         const int grid = (int)std::min<int64_t>(n_windows - plan->n_long_windows, resident);
+        if (has_long && !(getenv("GBX_POA_GATE") && atoi(getenv("GBX_POA_GATE")) == 0)) {
+            int cus = 256, dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            hipLaunchKernelGGL(poa_gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long *)(A.cells + POA_LONG_STARTED),
+                               (unsigned)std::min<int64_t>(plan->long_slots, cus));
+        }
         Stage st("poa_window", s);
         const char *oe = getenv("GBX_POA_OCC");             // tuning aid: 2 = the instance compiled for two wavefronts per SIMD (no spills, nine ring rows)
         if (oe && atoi(oe) == 2)

@@ -86,7 +86,7 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             P.split_width, P.max_mem_intv = int(rng.integers(1, 30)), int(rng.integers(0, 60))
         os.environ["GBX_FMI_WIDE"] = "1" if rng.random() < 0.3 else "0"     # the 64-bit instance too
-        (go, goff), (wo, woff) = smem_host(idx, rs, P, out_cap=max(64, 200 * nr)), O.fmi_oracle(idx, rs, P, nthreads=8)
+        (go, goff), (wo, woff) = smem_host(idx, rs, P, out_cap=max(64, 200 * nr, nr * (rl + 64))), O.fmi_oracle(idx, rs, P, nthreads=8)
         ok = np.array_equal(goff, woff) and all(np.array_equal(go[f], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
         what = "genome=%d reads=%d len=%d minseed=%d wide=%s" % (glen, nr, rl, P.min_seed_len, os.environ["GBX_FMI_WIDE"])
     elif k == "phmm":
