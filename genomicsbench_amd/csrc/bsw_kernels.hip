@@ -764,12 +764,38 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         const int qlen = P.len2[pair], tlen = P.len1[pair], h0 = P.h0[pair];
         const uint8_t *q = P.qer + P.idq[pair];
         const uint8_t *t = P.ref + P.idr[pair];
-        // first row, :155-157, and the query codes (x 6: the bit offset of the score field in the matrix row word)
-        for (int j = 0; j <= qlen; ++j) {
-            const int hv = j == 0 ? h0 : max(h0 - oe_ins - (j - 1) * e_ins, 0);
-            const int qc = j < qlen ? min((int)q[j], 4) : 0;
-            if (COMPACT) { LCELL16(cell_at(j)) = (uint16_t)(hv << 8); LQ8(qb + (j >> 1) * 128 + (j & 1)) = (uint8_t)qc; }
-            else LCELL(cell_at(j)) = ((uint32_t)hv << 18) | (uint32_t)(qc * 6);
+        // first row, :155-157, and the query codes (x 6: the bit offset of the score field in the matrix row word).  The query
+        // comes in 16-byte pieces, the next one requested before the current one is unpacked (round 4: a byte load per column,
+        // each waited for on the spot, was ~130 serial memory round trips per chunk of pairs - a tenth of a long-query
+        // chunk's time, at 1.5 wavefronts per SIMD with little to hide it behind); the arenas are readable 16 bytes past
+        // their last base.  Compact format: a column pair is one dword of cells and one halfword of codes.
+        {
+            uint4 wq;
+            __builtin_memcpy(&wq, q, 16);
+            int hrun = h0 - oe_ins + e_ins;                 // h0 - oe_ins - (j - 1) e_ins at j = 0
+            for (int j0 = 0; j0 <= qlen; j0 += 16) {
+                const uint4 cur = wq;
+                if (j0 + 16 <= qlen) __builtin_memcpy(&wq, q + j0 + 16, 16);
+                const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {
+                    const int j = j0 + c;
+                    if (j <= qlen) {
+                        const uint32_t two = (ww[c >> 2] >> ((c & 3) * 8)) & 0xffffu;
+                        const int c0 = j < qlen ? min((int)(two & 0xffu), 4) : 0, c1 = j + 1 < qlen ? min((int)(two >> 8), 4) : 0;
+                        const int hv0 = j == 0 ? h0 : max(hrun, 0), hv1 = max(hrun - e_ins, 0);
+                        hrun -= 2 * e_ins;
+                        if (COMPACT) {
+                            // (cell j + 1 may lie one past qlen: it exists - look-ahead rows - and is never live)
+                            LCELL((j >> 1) * 256 + cb) = ((uint32_t)hv0 << 8) | ((uint32_t)hv1 << 24);
+                            LCELL16(qb + (j >> 1) * 128) = (uint16_t)(c0 | (c1 << 8));
+                        } else {
+                            LCELL(cell_at(j)) = ((uint32_t)hv0 << 18) | (uint32_t)(c0 * 6);
+                            if (j + 1 <= qlen) LCELL(cell_at(j + 1)) = ((uint32_t)hv1 << 18) | (uint32_t)(c1 * 6);
+                        }
+                    }
+                }
+            }
         }
         const int w = band_width(prm, qlen);
         int best = h0, best_i = -1, best_j = -1, g_i = -1, g_score = -1, off = 0;
@@ -814,19 +840,21 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                     left = h;
                     return cell;
                 };
-                int j = beg;
-                if ((j & 1) && j < end) {                  // odd first column: the high half of its dword, alone
-                    const int at = cell_at(j);
-                    const uint32_t cw = LCELL16(at);
-                    LCELL16(at) = (uint16_t)step((int)(cw >> 8), (int)(cw & 0xffu), LQ8(qb + (j >> 1) * 128 + 1), at);
-                    ++j;
-                }
+                // An odd first column is the high half of a column pair whose low half lies before the window.  It used to be a step
+                // of its own (25 instructions and two LDS round trips at the head of every row, nothing to overlap them with); now
+                // the pair runs as a whole with the low half's input cell forced to zero (round 4): a zero cell yields m = 0, h = 0,
+                // e = 0 and leaves f = 0, which is exactly the state the scalar loop enters column beg with (:183-186: h1 = 0 for
+                // beg > 0), its key (h = 0) never wins the row maximum, and what the step writes into the cell before the window
+                // is never read again: windows only move right (beg is non-decreasing, :230-233).
+                const bool odd_first = (beg & 1) && beg < end;
+                int j = odd_first ? beg - 1 : beg;
                 // Whole column pairs, four per trip, the loads two to four pairs ahead of their use (an LDS round trip is 100+
                 // cycles under load and the wavefront has nothing else to do meanwhile).  Two register sets take turns, so
                 // nothing is copied.  Loads past the window read cells that exist (look-ahead rows are part of the allocation)
                 // and are not used.
                 int pa = (j >> 1) * 256 + cb, qa = qb + (j >> 1) * 128;
                 uint32_t w0 = LCELL(pa), q0 = LCELL16(qa), w1 = LCELL(pa + 256), q1 = LCELL16(qa + 128);
+                w0 &= odd_first ? 0xffff0000u : 0xffffffffu;
                 for (; j + 7 < end; j += 8, pa += 1024, qa += 512) {
                     const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256), x1 = LCELL(pa + 768), y1 = LCELL16(qa + 384);
                     uint32_t kt;                            // the trip's maximum, positions relative to pa (eight constant registers)
