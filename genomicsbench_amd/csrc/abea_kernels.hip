@@ -127,11 +127,31 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
 
         bool tame = true;
         // ---- scaled model parameters per k-mer (kmer_ranks, :214-222 + log_probability_match_r9's per-state terms)
-        for (int k = lane; k < n_kmers; k += 64) {
+        // (round 4: the six bases of a k-mer come as one 8-byte load, the next k-mer's requested before this one's model is
+        // looked up - six byte loads, each waited for, then the model: seven serial round trips per 64 k-mers, 3 ms of the
+        // longest read's 42)
+        const int slen = n_kmers + KSZ - 1;
+        auto kmer_bytes = [&](int k) -> uint64_t {
+            uint64_t v = 0;
+            if (k + 8 <= slen) __builtin_memcpy(&v, seq + k, 8);
+            else for (int i = 0; i < KSZ; ++i) v |= (uint64_t)(uint8_t)seq[k + i] << (8 * i);      // the read's last k-mers: no byte past its end
+            return v;
+        };
+        auto rank_of = [](uint64_t kb) -> uint32_t {
             uint32_t rank = 0;
 #pragma unroll
-            for (int i = 0; i < KSZ; ++i) rank += base_rank(seq[k + KSZ - i - 1]) << (i << 1);
-            const gbx_abea_model m = A.models[rank];
+            for (int i = 0; i < KSZ; ++i) rank += base_rank((char)(kb >> (8 * (KSZ - i - 1)))) << (i << 1);
+            return rank;
+        };
+        // two stages: the bases of k-mer k + 128 and the model of k-mer k + 64 are on their way while k-mer k is stored (its
+        // store is issued after them, so waiting for them does not wait for it)
+        uint64_t nextb = lane + 64 < n_kmers ? kmer_bytes(lane + 64) : 0;
+        gbx_abea_model nextm = A.models[lane < n_kmers ? rank_of(kmer_bytes(lane)) : 0];
+        for (int k = lane; k < n_kmers; k += 64) {
+            const gbx_abea_model m = nextm;
+            const uint64_t kb1 = nextb;
+            if (k + 128 < n_kmers) nextb = kmer_bytes(k + 128);
+            if (k + 64 < n_kmers) nextm = A.models[rank_of(kb1)];
             const float gm = scale * m.level_mean + shift, gs = m.level_stdv * 1;
             // the refined reciprocal the float division starts from (v_rcp_f32 + one Newton step, exactly the first
             // three operations of the compiler's own x / gs), hoisted from the cells to the k-mer
@@ -141,7 +161,14 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
             kp[k] = make_float4(gm, gs, -0.918938f - m.level_log_stdv, r1);
             tame = tame && mid_range(gm) && mid_range(gs) && gs > 0.f;
         }
-        for (int i = lane; i < n_events; i += 64) tame = tame && mid_range(evm[i]);
+        {
+            int i = lane;
+            for (; i + 192 < n_events; i += 256) {              // four independent loads per trip
+                const float a = evm[i], b = evm[i + 64], c = evm[i + 128], d = evm[i + 192];
+                tame = (int)tame & (int)mid_range(a) & (int)mid_range(b) & (int)mid_range(c) & (int)mid_range(d);      // (no short circuit: the four loads stay in flight together)
+            }
+            for (; i < n_events; i += 64) tame = tame && mid_range(evm[i]);
+        }
         // every event, mean and stdv of the read is 0 or within 2^+-40 (stdv > 0): then no division of the read needs
         // v_div_scale's rescaling or v_div_fixup's special cases, and the five operations left of it are the division
         const bool fdiv = __builtin_amdgcn_ballot_w64(!tame) == 0;
