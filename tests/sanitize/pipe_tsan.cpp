@@ -25,6 +25,15 @@ RoctxRange::~RoctxRange() {}
 }  // namespace gbx
 
 #include "host_pipeline.h"
+// the multi-device layer of the host entries (csrc/host_multi.h, unmodified): the cut rule and the shard runner.  The
+// mock runtime has one device; the logical devices of a call all map onto it, as GBX_DEVICE_MAP=0,0,0 does on a GPU box.
+extern "C" const char *gbx_last_error(void) { return gbx::g_err; }
+#include "host_multi.h"
+namespace gbx {
+int host_device_set(int *map) { for (int k = 0; k < 3; ++k) map[k] = 0; return 3; }
+int host_next_small_call_device(int n) { static std::atomic<unsigned> rr{0}; return (int)(rr.fetch_add(1) % (unsigned)n); }
+bool host_multi_wanted() { return true; }
+}
 
 using namespace gbx;
 
@@ -209,6 +218,31 @@ int main(int argc, char **argv)
         std::thread a([] { CHECK(call_one_chunk((size_t)20 << 20, 4001, true) == GBX_OK, "large one-chunk call: %s", g_err); });
         std::thread b([] { CHECK(call_field_and_scatter(3000000, 4002) == GBX_OK, "large field / scatter call: %s", g_err); });
         a.join(); b.join();
+    }
+    // (d) the multi-device shape of an entry (host_multi.h): a job cut by cost into three shards, every shard a staged call on
+    //     a lane of its own from a thread of its own, two such jobs in flight at once; then a job one of whose shards fails:
+    //     the lowest failing shard's status and text come back on the calling thread, the other shards finish
+    {
+        auto multi_job = [](size_t units, uint64_t seed, int fail_shard) -> int {
+            std::vector<double> cost(units);
+            std::mt19937_64 r(seed);
+            for (auto &c : cost) c = (double)(r() % 1000);
+            const std::vector<int64_t> cuts = split_by_cost((int64_t)units, 3, [&](int64_t i) { return cost[(size_t)i]; });
+            CHECK(cuts[0] == 0 && cuts[3] == (int64_t)units && cuts[1] <= cuts[2], "cuts not monotone");
+            int map[MAX_HOST_DEVICES];
+            const int n = host_device_set(map);
+            return run_on_devices(n, map, "multi_job", [&](int k) -> int {
+                if (k == fail_shard) { set_error("shard %d was told to fail", k); return GBX_ERR_ARG; }
+                const size_t m = (size_t)(cuts[(size_t)k + 1] - cuts[(size_t)k]);
+                return m ? call_one_chunk(m * 64, seed + (uint64_t)k, true) : GBX_OK;
+            });
+        };
+        std::thread a([&] { CHECK(multi_job(40000, 5001, -1) == GBX_OK, "multi-device job: %s", g_err); });
+        std::thread b([&] { CHECK(multi_job(30000, 5002, -1) == GBX_OK, "multi-device job: %s", g_err); });
+        a.join(); b.join();
+        const int rc = multi_job(20000, 5003, 1);
+        CHECK(rc == GBX_ERR_ARG && strstr(g_err, "shard 1 was told to fail") && strstr(g_err, "[shard 1 of 3"), "failing shard: rc %d, text '%s'", rc, g_err);
+        CHECK(call_one_chunk((size_t)1 << 20, 5004, true) == GBX_OK, "call after a failed multi-device job: %s", g_err);
     }
     if (g_fail.load()) { fprintf(stderr, "pipe_tsan: %d check(s) failed\n", g_fail.load()); return 1; }
     printf("pipe_tsan: ok (%d caller threads x %d rounds)\n", threads, rounds);
