@@ -528,32 +528,48 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     max_i = -1; max_j = -1;
     if (n == 0) return;
     // descriptors: row r (a*), row r+1 (b*), row r+2 is requested inside the loop
-    int ap0, ap1, ap2, ainfo, bp0, bp1, bp2, binfo;
+    // (RING: none of this pipeline - a row reads its own descriptor out of the registers and its predecessors out of the ring at
+    // its top; the previous row is in the ring like any other, so the eleven-register hand-over of `last` and the 22 selects per
+    // row that chose between it and the prefetch registers are gone, and nothing but the ring lives across the iterations)
+    int ap0 = 0, ap1 = 0, ap2 = 0, ainfo = 0, bp0 = 0, bp1 = 0, bp2 = 0, binfo = 0;
     if (RING) refill(0);
-    desc(0, ap0, ap1, ap2, ainfo);
-    desc(1, bp0, bp1, bp2, binfo);
+    else {
+        desc(0, ap0, ap1, ap2, ainfo);
+        desc(1, bp0, bp1, bp2, binfo);
+    }
     PoaPredIn in0, in1, last;
     last.h = (v8s)0; last.fo = (v4u)0;
     last.h0 = last.o0 = last.f0 = 0;
+    in0 = last; in1 = last;
     bool reg0 = false, reg1 = false;                           // predecessor k of the row at hand is the previous row
-    {
+    if (!RING) {
         const int ic = (ainfo >> 8) & 0xff;
         fetch(ic ? ap0 : 0, in0);
         fetch(ic > 1 ? ap1 : 0, in1);
+        // nothing is in flight when the loop is entered: the loop's own issue order is then the only one the
+        // compiler has to reason about
+        settle_i(ap0); settle_i(ap1); settle_i(ap2); settle_i(ainfo); settle_i(bp0); settle_i(bp1); settle_i(bp2); settle_i(binfo);
+        settle_in(in0); settle_in(in1);
     }
-    // nothing is in flight when the loop is entered: the loop's own issue order is then the only one the
-    // compiler has to reason about
-    settle_i(ap0); settle_i(ap1); settle_i(ap2); settle_i(ainfo); settle_i(bp0); settle_i(bp1); settle_i(bp2); settle_i(binfo);
-    settle_in(in0); settle_in(in1);
     for (int r = 0; r < n; ++r) {
         const int i = r + 1;
-        const int p2 = ap2, info = __builtin_amdgcn_readfirstlane(ainfo);      // the row's descriptor is the same in every lane: scalar, so that what follows branches
+        int p2, info;
+        if (RING) {
+            if (r >= qbase + 64) refill(r);
+            const int l = r - qbase;
+            const int sp0 = __builtin_amdgcn_readlane(q_p0, l), sp1 = __builtin_amdgcn_readlane(q_p1, l);
+            p2 = __builtin_amdgcn_readlane(q_p2, l); info = __builtin_amdgcn_readlane(q_info, l);
+            const int ric = (info >> 8) & 0xff;
+            fetch_pred(ric >= 1 ? sp0 : 0, i, in0);           // (a row without predecessors hangs off the start row)
+            if (ric >= 2) fetch_pred(sp1, i, in1);
+        } else {
+            p2 = ap2; info = __builtin_amdgcn_readfirstlane(ainfo);      // the row's descriptor is the same in every lane: scalar, so that what follows branches
+        }
         const int letter = info & 0xff, ic = (info >> 8) & 0xff;
         const bool sink = (info >> 16) & 1;
         const int64_t ro = (int64_t)i * Wp + POA_COL0;
-        int cp0, cp1, cp2, cinfo;                              // row r+2
-        if (RING && r + 2 >= qbase + 64 && r + 2 < n) refill(r);
-        desc(r + 2, cp0, cp1, cp2, cinfo);
+        int cp0 = 0, cp1 = 0, cp2 = 0, cinfo = 0;              // row r+2
+        if (!RING) desc(r + 2, cp0, cp1, cp2, cinfo);
 
         // match / mismatch score of the lane's columns against this row's letter: m + (n-m) * (seq != letter)
         v2s sc[4];
@@ -566,7 +582,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         v2s Fa[4], Oa[4], Ha[4];
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
         {
-            const PoaPredIn &x = reg0 ? last : in0;
+            const PoaPredIn &x = RING ? in0 : reg0 ? last : in0;
             if (ic > 0) { po = max(po, x.o0); pf = max(pf, x.f0); }
             pred_terms(x, sc, Fa, Oa, Ha);
         }
@@ -574,7 +590,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
             // second predecessor: its registers are requested for every row (a fixed number of loads per iteration; the
             // start row stands in when there is none) and used only here, under a scalar branch (258 instead of 265 ms on
             // 'large'; branching on "the predecessor is the previous row" as well, instead of selecting, gave part of that back)
-            const PoaPredIn &x = reg1 ? last : in1;
+            const PoaPredIn &x = RING ? in1 : reg1 ? last : in1;
             po = max(po, x.o0); pf = max(pf, x.f0);
             v2s F2[4], O2[4], H2[4];
             pred_terms(x, sc, F2, O2, H2);
@@ -587,12 +603,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         const int nic = (binfo >> 8) & 0xff;
         const bool nreg0 = r + 1 < n && nic >= 1 && bp0 == i, nreg1 = r + 1 < n && nic >= 2 && bp1 == i;
         if (RING) {
-            // (the ring makes the fixed-loads-per-iteration rule pointless: a predecessor is an LDS read, or nothing when the
-            // row has none / it is this very row; the rare row from further back waits for memory)
-            const int snic = __builtin_amdgcn_readfirstlane(nic);
-            const bool s0 = __builtin_amdgcn_readfirstlane((int)nreg0) != 0, s1 = __builtin_amdgcn_readfirstlane((int)nreg1) != 0;
-            if (snic >= 1 && !s0) fetch_pred(bp0, i, in0); else if (r + 1 < n && snic == 0) fetch_pred(0, i, in0);
-            if (snic >= 2 && !s1) fetch_pred(bp1, i, in1);
+            // (nothing: the next row fetches its own inputs at its top)
         } else {
             fetch(nic >= 1 && !nreg0 ? bp0 : 0, in0);
             fetch(nic >= 2 && !nreg1 ? bp1 : 0, in1);
