@@ -1990,7 +1990,9 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         }
         Stage st("poa_window", s);
         const char *oe = getenv("GBX_POA_OCC");             // tuning aid: 2 = the instance compiled for two wavefronts per SIMD (no spills, nine ring rows)
-        if (oe && atoi(oe) == 2)
+        if (oe && atoi(oe) == 4)
+            hipLaunchKernelGGL((poa_kernel<false, 4, 6>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
+        else if (oe && atoi(oe) == 2)
             hipLaunchKernelGGL((poa_kernel<false, 2, 9>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)9 * POA_RING_SLOT), s, A, L);
         else
             hipLaunchKernelGGL((poa_kernel<false>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
