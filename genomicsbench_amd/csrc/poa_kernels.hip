@@ -1811,7 +1811,11 @@ int poa_waves_per_cu(int ncap)
     const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
     const bool lds_marks = lds_need != 0;
     int q = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false>, 64, std::max<size_t>(lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES)) != hipSuccess || q < 1) {
+    const char *oe_ = getenv("GBX_POA_OCC");
+    const bool occ4 = oe_ && atoi(oe_) == 4;                 // tuning aid: the 128-VGPR / four-ring-row instance
+    const hipError_t qe = occ4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false, 4, 4>, 64, std::max<size_t>(lds_marks ? lds_need : 0, (size_t)4 * POA_RING_SLOT))
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, poa_kernel<false>, 64, std::max<size_t>(lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES));
+    if (qe != hipSuccess || q < 1) {
         (void)hipGetLastError();
         q = 8;
     }
@@ -1990,8 +1994,8 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         }
         Stage st("poa_window", s);
         const char *oe = getenv("GBX_POA_OCC");             // tuning aid: 2 = the instance compiled for two wavefronts per SIMD (no spills, nine ring rows)
-        if (oe && atoi(oe) == 4)
-            hipLaunchKernelGGL((poa_kernel<false, 4, 6>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
+        if (oe && atoi(oe) == 4)          // with GBX_POA_NODE_FACTOR=4 GBX_POA_MAX_WAVES=16: sixteen windows per CU (128 VGPRs, four ring rows)
+            hipLaunchKernelGGL((poa_kernel<false, 4, 4>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)4 * POA_RING_SLOT), s, A, L);
         else if (oe && atoi(oe) == 2)
             hipLaunchKernelGGL((poa_kernel<false, 2, 9>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)9 * POA_RING_SLOT), s, A, L);
         else
