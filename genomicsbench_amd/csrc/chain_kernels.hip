@@ -29,8 +29,6 @@
 // one segment id takes the narrow 32-bit path even when its call as a whole could not.
 // Jobs are handed out longest-first from a cursor (the longest job bounds the kernel's makespan).
 #include "gbx_internal.h"
-#include <atomic>
-#include <mutex>
 
 namespace gbx {
 namespace {
@@ -76,9 +74,7 @@ constexpr unsigned UBIAS = 1u << 30;                           // scores and ski
 struct ChainWork {
     int32_t *counts;    // [NBUCKET] jobs per size bucket
     int32_t *cursors;   // [NBUCKET]
-    int32_t *next;      // [0] the DP kernel's job cursor, [4] ring choice, [5] number of jobs; the team kernel: [6] its cursor,
-                        // [7] jobs of at least this many anchors are its own, [8] list slots that may hold such jobs,
-                        // [9] workgroups of it that have started, [10] anchors of the longest job
+    int32_t *next;      // [0] the DP kernel's job cursor, [4] ring choice, [5] number of jobs
     int32_t *order;     // [max_jobs] jobs, longest bucket first
     unsigned long long *evaluated;   // predecessor pairs visited (the benchmark's "cell")
     int32_t *st;        // [n_anchors] first predecessor of every anchor (chain_st_kernel)
@@ -107,7 +103,7 @@ __global__ void __launch_bounds__(256) chain_order_kernel(ChainWork W, int pass)
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= W.next[5]) return;
     const int b = bucket_of(W.job_n[c]);
-    if (pass == 0) { atomicAdd(&W.counts[b], 1); atomicMax(&W.next[10], W.job_n[c]); return; }
+    if (pass == 0) { atomicAdd(&W.counts[b], 1); return; }
     int base = 0;
     for (int k = 0; k < b; ++k) base += W.counts[k];
     W.order[base + atomicAdd(&W.cursors[b], 1)] = (int)c;
@@ -291,50 +287,14 @@ __global__ void __launch_bounds__(256) chain_jobs_kernel(int n_calls, const int6
 // bound by its longest call when that call alone takes longer than the whole job spread over the calls the chip keeps
 // in flight with the long ring (6 per CU): longest > anchors / (CUs x 6).  The longest call is known to within a factor
 // of two from the size buckets; the test uses the bucket's lower bound.
-//
-// The team kernel's share (round 5): the jobs that would be the tail of the launch.  A job of n anchors takes n x 1.3 us on
-// one wavefront and about half of that on a team of four, so the launch ends soonest when the jobs of at least half the
-// longest job's length go to teams: team_min = max(floor, longest / 2) - unless that many jobs are long (more than
-// `team_cap` in the size buckets concerned): then they fill the chip as ordinary jobs and no job is a tail.
-// team_min_env: 0 = the rule above, > 0 = that threshold (test / tuning aid), < 0 = no teams.
-__global__ void chain_pick_kernel(ChainWork W, long long n_anchors, int cus, int force, int team_min_env, int team_floor, int team_cap)
+__global__ void chain_pick_kernel(ChainWork W, long long n_anchors, int cus, int force)
 {
     if (threadIdx.x || blockIdx.x) return;
+    if (force >= 0) { W.next[4] = force; return; }
     int top = -1;                                           // bucket 0 holds the longest calls (bucket_of)
     for (int b = NBUCKET - 1; b >= 0; --b) if (W.counts[b] > 0) top = b;
-    {
-        const int longest_n = W.next[10];
-        int tm = 0x7fffffff;
-        if (team_min_env > 0) tm = team_min_env;
-        else if (team_min_env == 0 && top >= 0) {
-            tm = max(team_floor, longest_n / 2);
-            int cnt = 0;
-            for (int b = top; b <= bucket_of(tm); ++b) cnt += W.counts[b];
-            if (cnt > team_cap) {                           // only the longest bucket, if that is few enough
-                const int lg = NBUCKET - 1 - top;
-                tm = W.counts[top] <= team_cap && (1 << lg) >= team_floor ? max(tm, 1 << lg) : 0x7fffffff;
-            }
-        }
-        int slots = 0;
-        if (tm != 0x7fffffff) for (int b = 0; b <= bucket_of(tm); ++b) slots += W.counts[b];
-        W.next[7] = tm;
-        W.next[8] = slots;
-    }
-    if (force >= 0) { W.next[4] = force; return; }
     const long long longest = top < 0 ? 0 : 1ll << (NBUCKET - 1 - top);
     W.next[4] = longest * (long long)cus * 6 > n_anchors ? 1 : 0;
-}
-
-// waits (bounded) until the team kernel's workgroups have started: they need a CU's whole LDS each and the persistent grid
-// of chain_kernel that follows leaves none
-__global__ void chain_gate_kernel(ChainWork W, int expect)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    if (W.next[8] == 0) return;                             // no job for the teams
-    for (int k = 0; k < 2000; ++k) {
-        if (__hip_atomic_load(&W.next[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= expect) return;
-        __builtin_amdgcn_s_sleep(32);
-    }
 }
 
 template <int RING_LIVE>
@@ -368,7 +328,6 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
         const int call = W.job_call[job];
         const int64_t o = W.job_start[job];                   // the job's anchors are [o, o + n) of the concatenated arrays
         const int n = W.job_n[job];
-        if (n >= W.next[7] && (W.unsorted[call] | W.job_flag[job]) == 0) continue;      // a team's job (chain_team_kernel)
         const int cbase = (int)(o - off[call]);               // ... and [cbase, cbase + n) of their call: indices below are
                                                               // job-relative, parents and targets leave with cbase added
         const uint64_t *x = ax + o, *y = ay + o;
@@ -674,269 +633,6 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
     }
 }
 
-// ---- chain_team_kernel (round 5): one job per workgroup of TW wavefronts, for the few jobs that are the launch's tail.
-// chain_kernel walks an anchor's look-back chunk after chunk on one wavefront - 1 300 cycles a chunk, 2.45 chunks per anchor
-// on the longest call of 'large', all of it dependent instructions of a lone wavefront.  Here the chunks of a round go to
-// the TW wavefronts of the team side by side (wavefront w: chunk r TW + w) and the sequential semantics of host_kernel.cpp:
-// 59-90 are put back together from per-wavefront summaries, two or three barriers per round:
-//   A  every wavefront has scored its chunk (:59-80), written its tentative parent marks (mk[], below) and published the
-//      maximum of its candidates;
-//   B  with the maxima of the wavefronts before it a wavefront knows its improving lanes (:81) and its bumps (:84-87), and
-//      publishes the walk of n_skip over its chunk as (sum, lowest prefix sum): n_out = sum + max(n_in, -lowest) composes
-//      from wavefront to wavefront; if n_skip cannot pass max_skip anywhere in the round the result is complete;
-//   C  otherwise every wavefront finds its first breaking lane from its exact n_in and the last improving lane before it.
-// "targets[j] == i" (:84) can only come from this anchor's own marks, and marks only matter to lanes visited later, which
-// are visited only if no break came first: so marks are tentative writes of the anchor's id into a plane of their own
-// (mk[], one word per ring slot) by every lane that is not skipped, before barrier A, and the targets proper (:89) are
-// written after the break is known.  The ring holds the whole look-back (max_iter anchors, narrow 32-bit words: 148 KB of
-// LDS, a CU to itself) - jobs with several segment ids / upper x words or unsorted x stay with chain_kernel.
-#ifndef GBX_CHAIN_TEAM_W
-#define GBX_CHAIN_TEAM_W 4
-#endif
-constexpr int TEAM_LIVE = (GBX_CHAIN_MAX_ITER + 63) / 64 * 64;      // anchors addressed in the ring during a block
-constexpr int TEAM_PHYS = TEAM_LIVE + 64;
-constexpr size_t team_lds_bytes(int tw) { return (size_t)TEAM_PHYS * 8 + (size_t)(TEAM_PHYS + 64 * tw) * 20 + 96 * 4; }
-
-__device__ inline void team_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int TW>
-__global__ void __launch_bounds__(64 * TW) chain_team_kernel(const int64_t *__restrict__ off, const uint64_t *__restrict__ ax,
-                                                             const uint64_t *__restrict__ ay, const gbx_chain_call *__restrict__ hdr,
-                                                             int32_t *score, int32_t *parent, int32_t *target, int32_t *peak, ChainWork W)
-{
-    constexpr int PHYS = TEAM_PHYS, LIVE = TEAM_LIVE, NT = 64 * TW;
-    extern __shared__ __align__(16) unsigned char team_lds[];
-    uint2 *rxy = (uint2 *)team_lds;                          // low words of x and y
-    int4 *rst = (int4 *)(rxy + PHYS);                        // {score, parent, target, peak}; + a dump entry per thread
-    int *mk = (int *)(rst + PHYS + NT);                      // id of the last anchor that marked this one (tentatively)
-    int *pub = mk + PHYS + NT;                               // [0] job slot, [8+v] maxima, [16+8v..] B, [48+4v..] C
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int max_skip = GBX_CHAIN_MAX_SKIP;
-    if (tid == 0) atomicAdd(&W.next[9], 1);
-    const int n_slots = W.next[8], team_min = W.next[7];
-    for (;;) {
-        if (tid == 0) pub[0] = atomicAdd(&W.next[6], 1);
-        team_sync();
-        const int slot = __builtin_amdgcn_readfirstlane(pub[0]);
-        team_sync();
-        if (slot >= n_slots) break;
-        const int job = W.order[slot];
-        const int call = W.job_call[job];
-        const int n = W.job_n[job];
-        if (n < team_min || (W.unsorted[call] | W.job_flag[job]) != 0) continue;
-        const int64_t o = W.job_start[job];
-        const int cbase = (int)(o - off[call]);
-        const uint64_t *x = ax + o, *y = ay + o;
-        int32_t *f = score + o, *p = parent + o, *t = target + o, *pk = peak + o;
-        const int32_t *stp = W.st + o;
-        const gbx_chain_call h = hdr[call];
-        const int max_dist_x = h.max_dist_x, max_dist_y = h.max_dist_y, bw = h.bw, n_segs = h.n_segs;
-        const double avg_qspan = (double)h.avg_qspan;
-        for (int a = tid; a < PHYS + NT; a += NT) mk[a] = -1;  // never an anchor id
-        unsigned long long visited = 0;
-        unsigned wxl = 0, wyl = 0;                             // wavefront 0: the first chunk in registers (see chain_kernel)
-        int wf = 0, wp = -1, wk = 0;
-        uint64_t nxa = 0, nya = 0;
-        int nstv = 0;
-        { const int ia0 = min(lane, n - 1); nxa = x[ia0]; nya = y[ia0]; nstv = stp[ia0]; }
-        int pf_ = 0, pp_ = 0, pk_ = 0, pkmax = 0, sib = 0;
-        for (int ib = 0; ib < n; ib += 64, sib = sib + 64 == PHYS ? 0 : sib + 64) {
-            const uint64_t xa = settle(nxa), ya = settle(nya);
-            const int stv = settle(nstv) - cbase;
-            team_sync();                                       // the previous block's target writes have landed
-            if (wv == 0) {
-                if (lane < pkmax) { f[ib - 64 + lane] = pf_; p[ib - 64 + lane] = pp_ >= 0 ? pp_ + cbase : pp_; pk[ib - 64 + lane] = pk_; }
-                if (ib >= PHYS) t[ib - PHYS + lane] = rst[sib + lane].z;
-                rxy[sib + lane] = make_uint2((unsigned)xa, (unsigned)ya);
-            }
-            if (ib + 64 < n) { const int ian = min(ib + 64 + lane, n - 1); nxa = x[ian]; nya = y[ian]; nstv = stp[ian]; }
-            const int kmax = min(64, n - ib);
-            const int live0 = ib - LIVE;
-            int of_ = 0, op_ = 0, ok_ = 0;
-            for (int k = 0; k < kmax; ++k) {
-                const int i = ib + k, si = sib + k, iabs = i + cbase;
-                const unsigned ril = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)xa, k);
-                const uint64_t yi = readlane64(ya, k);
-                const int qi = (int)yi, q_span = (int)(yi >> 32 & 0xff);
-                const int st = __builtin_amdgcn_readlane(stv, k);
-                auto slot_of = [&](int a) -> int { const int v = si - (i - a); return v < 0 ? v + PHYS : v; };
-                int max_f = q_span, max_j = -1, max_pk = 0, n_skip = 0;
-                bool broke = false;
-                const int npred = i - st;
-                for (int c0 = 0; c0 * 64 < npred && !broke; c0 += TW) {
-                    const int jhi = i - 1 - 64 * (c0 + wv);
-                    const bool active = jhi >= st;             // wave-uniform
-                    bool skip = true, any = false;
-                    int sc = 0, pj = -1, kj = 0, rs = PHYS + tid;
-                    unsigned cand = 0, pm = 0;
-                    // ---- scores of the chunk (:59-80, the narrow form of chain_kernel), tentative marks, the chunk's maximum
-                    if (active) {
-                        const int j = jhi - lane;
-                        const bool valid = j >= st;
-                        rs = slot_of(valid ? j : st);
-                        unsigned xj, yjl;
-                        int fj;
-                        if (wv == 0 && c0 == 0) { xj = wxl; yjl = wyl; fj = wf; pj = wp; kj = wk; }
-                        else { const uint2 wxy = rxy[rs]; const int4 wst = rst[rs]; xj = wxy.x; yjl = wxy.y; fj = wst.x; pj = wst.y; kj = wst.w; }
-                        const unsigned dr = ril - xj;
-                        const int dq = qi - (int)yjl;
-                        skip = !valid || dr == 0 || dq <= 0 || dq > max_dist_y || dq > max_dist_x;
-                        const bool gt = dr > (unsigned)dq;
-                        const int dd = gt ? (int)(dr - (unsigned)dq) : (int)((unsigned)dq - dr);
-                        skip = skip || dd > bw;
-                        skip = skip || (n_segs > 1 && (max_dist_y < 0 || dr > (unsigned)max_dist_y));
-                        mk[(!skip && pj >= st) ? slot_of(pj) : PHYS + tid] = iabs;
-                        const int min_d = gt ? dq : (int)dr;
-                        sc = min_d > q_span ? q_span : min_d;
-                        const int log_dd = dd ? 31 - __builtin_clz((unsigned)dd) : 0;
-                        const int c_lin = (int)((double)dd * .01 * avg_qspan);
-                        sc -= c_lin + (log_dd >> 1);
-                        sc += fj;
-                        cand = skip ? 0u : (unsigned)sc + UBIAS;
-                        any = __ballot(cand > (unsigned)max_f + UBIAS) != 0;
-                        if (any) pm = wave_scan_umax(cand);
-                        if (lane == 63) pub[8 + wv] = (int)(any ? pm : 0u);
-                    } else if (lane == 63) pub[8 + wv] = 0;
-                    team_sync();                               // ---- A
-                    bool improving = false, bump = false;
-                    unsigned long long bmask = 0, imask = 0;
-                    if (active) {
-                        const bool hit = mk[rs] == iabs;
-                        unsigned m_in = (unsigned)max_f + UBIAS;
-                        for (int v = 0; v < wv; ++v) m_in = max(m_in, (unsigned)__builtin_amdgcn_readfirstlane(pub[8 + v]));
-                        if (!any || __ballot(cand > m_in) == 0) {
-                            bump = !skip && hit;
-                        } else {
-                            unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);
-                            pmx = lane == 0 ? 0u : pmx;
-                            improving = !skip && cand > max(m_in, pmx);
-                            bump = !skip && !improving && hit;
-                        }
-                        bmask = __ballot(bump); imask = __ballot(improving);
-                        int lowest = 0;                        // lowest prefix sum of the walk (+1 bump, -1 improving); >= 0 counts as 0
-                        if (imask) {
-                            const unsigned long long first_b = bmask & (0 - bmask);
-                            const unsigned long long lead = first_b ? first_b - 1 : ~0ull;
-                            if ((imask & ~lead) == 0) lowest = -(int)__builtin_popcountll(imask);
-                            else {
-                                const int bcnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bmask, 0u));
-                                const int icnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(imask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)imask, 0u));
-                                const int P = bcnt - icnt + (bump ? 1 : 0) - (improving ? 1 : 0);
-                                const unsigned mx = wave_scan_umax((unsigned)(-P) + UBIAS);
-                                lowest = -(int)((unsigned)__builtin_amdgcn_readlane((int)mx, 63) - UBIAS);
-                            }
-                        }
-                        const int li = imask ? 63 - __builtin_clzll(imask) : -1;
-                        const int s_li = __builtin_amdgcn_readlane(sc, li < 0 ? 0 : li), k_li = __builtin_amdgcn_readlane(kj, li < 0 ? 0 : li);
-                        if (lane == 0) {
-                            int *q = pub + 16 + 8 * wv;
-                            q[0] = (int)__builtin_popcountll(bmask) - (int)__builtin_popcountll(imask);
-                            q[1] = lowest; q[2] = (int)__builtin_popcountll(bmask); q[3] = li; q[4] = s_li; q[5] = k_li;
-                        }
-                    } else if (lane == 0) {
-                        int *q = pub + 16 + 8 * wv;
-                        q[0] = 0; q[1] = 0; q[2] = 0; q[3] = -1;
-                    }
-                    team_sync();                               // ---- B
-                    int nin[TW + 1], tot_nb = 0;
-                    nin[0] = n_skip;
-    #pragma unroll
-                    for (int v = 0; v < TW; ++v) {
-                        const int a_v = __builtin_amdgcn_readfirstlane(pub[16 + 8 * v]), lo_v = __builtin_amdgcn_readfirstlane(pub[17 + 8 * v]);
-                        tot_nb += __builtin_amdgcn_readfirstlane(pub[18 + 8 * v]);
-                        nin[v + 1] = a_v + max(nin[v], -lo_v);
-                    }
-                    int my_bl = 64;                            // lanes of this wavefront before this one were visited
-                    if (n_skip + tot_nb <= max_skip) {
-                        // no break in this round: the last improving lane of the last wavefront that has one
-    #pragma unroll
-                        for (int v = 0; v < TW; ++v) {
-                            const int liv = __builtin_amdgcn_readfirstlane(pub[19 + 8 * v]);
-                            if (liv >= 0) {
-                                max_f = __builtin_amdgcn_readfirstlane(pub[20 + 8 * v]);
-                                max_pk = __builtin_amdgcn_readfirstlane(pub[21 + 8 * v]);
-                                max_j = i - 1 - 64 * (c0 + v) - liv;
-                            }
-                        }
-                    } else {
-                        if (active) {
-                            int my_n = nin[0];
-    #pragma unroll
-                            for (int v = 1; v < TW; ++v) my_n = wv == v ? nin[v] : my_n;
-                            const int bcnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bmask, 0u));
-                            const int icnt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(imask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)imask, 0u));
-                            const int S = my_n + bcnt - icnt + (bump ? 1 : 0) - (improving ? 1 : 0);
-                            const unsigned mx = wave_scan_umax((unsigned)(-S) + UBIAS);
-                            const int nl = S - min(0, -(int)(mx - UBIAS));
-                            const unsigned long long brk = __ballot(bump && nl > max_skip);
-                            my_bl = brk ? __builtin_ctzll(brk) : 64;
-                            const unsigned long long before = my_bl >= 64 ? ~0ull : ((1ull << my_bl) - 1);
-                            const unsigned long long imp = imask & before;
-                            const int li = imp ? 63 - __builtin_clzll(imp) : -1;
-                            const int s_li = __builtin_amdgcn_readlane(sc, li < 0 ? 0 : li), k_li = __builtin_amdgcn_readlane(kj, li < 0 ? 0 : li);
-                            if (lane == 0) { int *q = pub + 48 + 4 * wv; q[0] = my_bl; q[1] = li; q[2] = s_li; q[3] = k_li; }
-                        } else if (lane == 0) { int *q = pub + 48 + 4 * wv; q[0] = 64; q[1] = -1; }
-                        team_sync();                           // ---- C
-                        int vb = TW, bl_b = 64;
-    #pragma unroll
-                        for (int v = 0; v < TW; ++v) {
-                            if (vb < TW) break;
-                            const int blv = __builtin_amdgcn_readfirstlane(pub[48 + 4 * v]), liv = __builtin_amdgcn_readfirstlane(pub[49 + 4 * v]);
-                            if (liv >= 0) {
-                                max_f = __builtin_amdgcn_readfirstlane(pub[50 + 4 * v]);
-                                max_pk = __builtin_amdgcn_readfirstlane(pub[51 + 4 * v]);
-                                max_j = i - 1 - 64 * (c0 + v) - liv;
-                            }
-                            if (blv < 64) { vb = v; bl_b = blv; }
-                        }
-                        if (vb < TW) {
-                            broke = true;
-                            my_bl = wv < vb ? 64 : wv == vb ? my_bl : 0;
-                            visited += (unsigned long long)(64 * (c0 + vb) + bl_b + 1);
-                        }
-                    }
-                    n_skip = nin[TW];
-                    // ---- :89 for the lanes visited before the break
-                    if (active) {
-                        const bool wr = !skip && pj >= 0 && lane < my_bl;
-                        rst[wr && pj >= live0 ? slot_of(pj) : PHYS + tid].z = iabs;
-                        if (__ballot(wr && pj < live0)) {       // rare: the parent left the ring; waited for, so that a later
-                            if (wr && pj < live0) t[pj] = iabs; // anchor's store from another wavefront cannot overtake it
-                            __builtin_amdgcn_s_waitcnt(0x0F70);
-                        }
-                    }
-                }
-                if (!broke) visited += (unsigned long long)npred;
-                const int pki = (max_j >= 0 && max_pk > max_f) ? max_pk : max_f;
-                if (wv == 0) {
-                    const bool mine = lane == k;
-                    of_ = mine ? max_f : of_;
-                    op_ = mine ? max_j : op_;
-                    ok_ = mine ? pki : ok_;
-                    if (lane == 0) rst[si] = make_int4(max_f, max_j, 0, pki);
-                    wxl = (unsigned)dppi<0x138>((int)ril, (int)wxl); wyl = (unsigned)dppi<0x138>((int)(unsigned)yi, (int)wyl);
-                    wf = dppi<0x138>(max_f, wf); wp = dppi<0x138>(max_j, wp); wk = dppi<0x138>(pki, wk);
-                }
-            }
-            pf_ = of_; pp_ = op_; pk_ = ok_; pkmax = kmax;
-        }
-        team_sync();
-        {
-            const int ibl = (n - 1) & ~63;
-            if (wv == 0 && lane < pkmax) { f[ibl + lane] = pf_; p[ibl + lane] = pp_ >= 0 ? pp_ + cbase : pp_; pk[ibl + lane] = pk_; }
-            const int sibl = sib == 0 ? PHYS - 64 : sib - 64;
-            for (int a = max(0, ibl - LIVE) + tid; a < n; a += NT) {
-                int v = sibl + (a - ibl);
-                v = v < 0 ? v + PHYS : v;
-                t[a] = rst[v].z;
-            }
-        }
-        if (tid == 0) atomicAdd(W.evaluated, visited);
-        team_sync();
-    }
-}
-
 }  // namespace
 
 // Workspace, in 8-byte words first: [header 3*NBUCKET ints | blk_diff[n_blk] u64 | job_start[max_jobs] i64 |
@@ -1070,52 +766,16 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     const int di = dev_id >= 0 && dev_id < CHAIN_MAX_DEVICES ? dev_id : 0;
     const int64_t blocks_s = std::min<int64_t>(L.max_jobs, (int64_t)cus * std::min(wcap, occ_short[di]));
     const int64_t blocks_l = std::min<int64_t>(L.max_jobs, (int64_t)cus * std::min(wcap, occ_long[di]));
-    // The team kernel (chain_team_kernel: the few jobs that would be the tail, four wavefronts each) goes to a side stream
-    // ahead of the persistent grid and the caller's stream waits at a gate until its workgroups have started: each needs a
-    // CU's whole LDS.  GBX_CHAIN_TEAM_MIN: 0 (default) = the device's rule (chain_pick_kernel), n > 0 = jobs of at least n
-    // anchors (test / tuning aid), -1 = no teams; GBX_CHAIN_TEAM_GRID = workgroups (default 48); GBX_CHAIN_TEAM_CAP.
-    static const int team_env = getenv("GBX_CHAIN_TEAM_MIN") ? atoi(getenv("GBX_CHAIN_TEAM_MIN")) : 0;
-    static const int team_grid_env = getenv("GBX_CHAIN_TEAM_GRID") ? atoi(getenv("GBX_CHAIN_TEAM_GRID")) : 48;
-    static const int team_cap_env = getenv("GBX_CHAIN_TEAM_CAP") ? atoi(getenv("GBX_CHAIN_TEAM_CAP")) : 64;
-    static const int team_floor_env = getenv("GBX_CHAIN_TEAM_FLOOR") ? atoi(getenv("GBX_CHAIN_TEAM_FLOOR")) : 8192;
-    const char *team_now = getenv("GBX_CHAIN_TEAM_MIN_NOW");   // read per call: the tests vary it
-    const int team_min = team_now ? atoi(team_now) : team_env;
-    const int team_grid = std::max(1, std::min(team_grid_env, cus));
-    SideStreams *ss = nullptr;
-    if (team_min >= 0) {
-        static std::atomic<uint64_t> attr_set[2];
-        const uint64_t bit = (uint64_t)1 << (dev_id & 63);
-        if (dev_id < 0 || dev_id >= 128 || !(attr_set[dev_id >> 6].load(std::memory_order_acquire) & bit)) {
-            GBX_HIP(hipFuncSetAttribute((const void *)chain_team_kernel<GBX_CHAIN_TEAM_W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)team_lds_bytes(GBX_CHAIN_TEAM_W)));
-            if (dev_id >= 0 && dev_id < 128) attr_set[dev_id >> 6].fetch_or(bit, std::memory_order_release);
-        }
-        int rc = side_streams(&ss);
-        if (rc) return rc;
-    }
     {
         Stage st("chain_dp", s);
         // both instances are queued; the one the job did not pick returns at once (no host round trip for the choice)
         const char *renv = getenv("GBX_CHAIN_RING");         // test / tuning aid: "short" or "long" for every job
         const int force = renv ? (renv[0] == 'l' ? 1 : renv[0] == 's' ? 0 : -1) : -1;
-        hipLaunchKernelGGL(chain_pick_kernel, dim3(1), dim3(64), 0, s, W, (long long)n_anchors, cus, force, team_min, team_floor_env, team_cap_env);
-        if (ss) {
-            std::lock_guard<std::mutex> lk(ss->mu);
-            GBX_HIP(hipEventRecord(ss->ev_fork, s));
-            GBX_HIP(hipStreamWaitEvent(ss->side[0], ss->ev_fork, 0));
-            hipLaunchKernelGGL(chain_team_kernel<GBX_CHAIN_TEAM_W>, dim3((unsigned)team_grid), dim3(64 * GBX_CHAIN_TEAM_W), team_lds_bytes(GBX_CHAIN_TEAM_W),
-                               ss->side[0], d_off, d_ax, d_ay, d_hdr, d_score, d_parent, d_target, d_peak, W);
-            GBX_HIP(hipEventRecord(ss->ev_join[0], ss->side[0]));
-            hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, s, W, team_grid);
-        }
+        hipLaunchKernelGGL(chain_pick_kernel, dim3(1), dim3(64), 0, s, W, (long long)n_anchors, cus, force);
         hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3((unsigned)blocks_s), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
                            d_score, d_parent, d_target, d_peak, W);
         hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3((unsigned)blocks_l), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
                            d_score, d_parent, d_target, d_peak, W);
-        if (ss) {
-            std::lock_guard<std::mutex> lk(ss->mu);
-            GBX_HIP(hipStreamWaitEvent(s, ss->ev_join[0], 0));
-        }
     }
     GBX_HIP(hipGetLastError());
     return GBX_OK;

@@ -1,5 +1,5 @@
 // Single-wavefront issue cost of dependent instruction chains on gfx950 (clocks per instruction by s_memtime), the
-// numbers behind abea's per-band estimate in DESIGN.md.  build: hipcc --offload-arch=gfx950 -O2 issue_cost.hip -o issue_cost
+// numbers behind the per-band (abea) and per-chunk (chain) estimates in DESIGN.md; where the wavefronts of a workgroup land.  build: hipcc --offload-arch=gfx950 -O2 issue_cost.hip -o issue_cost
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -83,7 +83,7 @@ int main()
     for (int extra : {0, 32}) {
         uint64_t h = 0;
         for (int k = 0; k < 2; ++k) { hipLaunchKernelGGL(exchange, dim3(1), dim3(256), 0, 0, o, c, 1000, extra); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost); }
-        printf("team of 4 wavefronts: LDS write + barrier + 4 broadcast reads + %d dependent adds: %.0f ticks per step\n", extra, (double)h / 1000);
+        printf("team of 4 wavefronts: LDS write + barrier + 4 broadcast reads + a %d-trip loop of one add (4 instructions a trip): %.0f ticks per step\n", extra, (double)h / 1000);
     }
     {
         unsigned *hw; uint64_t *ck; hipMalloc(&hw, 4096); hipMalloc(&ck, 8192);

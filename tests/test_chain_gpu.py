@@ -53,32 +53,6 @@ def test_goldens_without_cuts_and_on_the_general_path(name, mode, monkeypatch):
     assert_same(chain_host(*case), [g[:, 0], g[:, 1], g[:, 2], g[:, 3]])
 
 
-@pytest.mark.parametrize("team_min", ["1", "300", "-1"])
-@pytest.mark.parametrize("name", ["mixed", "dense_maxiter", "multiseg", "cuts", "realistic"])
-def test_goldens_through_the_team_kernel(name, team_min, monkeypatch):
-    """chain_team_kernel (four wavefronts per job: the chunks of a round side by side, the ordered max / skip / break logic
-    put together from per-wavefront summaries) on every job it can take (sorted x, one segment id and upper x word: "1"),
-    on the jobs of 300 anchors and more, and switched off ("-1") - the goldens of the reference either way."""
-    monkeypatch.setenv("GBX_CHAIN_TEAM_MIN_NOW", team_min)
-    case, g = load_chain_golden(name)
-    assert_same(chain_host(*case), [g[:, 0], g[:, 1], g[:, 2], g[:, 3]])
-
-
-@pytest.mark.parametrize("realistic", [False, True])
-def test_team_kernel_on_generated_calls_and_its_pair_count(realistic, monkeypatch):
-    """600 generated calls with every eligible job on a team: the four arrays and the evaluated-pair count equal the oracle's
-    (the count comes from the break position the wavefronts agree on)."""
-    import torch
-    monkeypatch.setenv("GBX_CHAIN_TEAM_MIN_NOW", "1")
-    case = gen_chain(600, 909, realistic=realistic)
-    want = O.chain_oracle(*case, nthreads=8, return_pairs=True)
-    d = DeviceChainBatch(*case, torch.device("cuda:0"))
-    d.run(torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert_same(d.results(), want[:4])
-    assert d.evaluated_pairs() == int(want[4])
-
-
 def test_realistic_calls_are_cut_into_jobs_and_equal_the_oracle():
     """400 calls of the realistic generator (20 % isolated hits, repeat copies on other strands / references): identical
     to the oracle, and the evaluated-pair count (the benchmark's work unit) equals the oracle's too."""
