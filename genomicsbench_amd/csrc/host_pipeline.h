@@ -79,7 +79,10 @@ struct DevBlock { void *p; size_t cap; };
 struct Lane {
     std::vector<DevBlock> dev_cache;       // device blocks of earlier calls of this lane, reused by DevBuf
     static constexpr int MAX_WORKERS = 8;
-    static constexpr size_t PIECE = (size_t)8 << 20;        // upload piece = worker slab
+#ifndef GBX_PIECE_MB
+#define GBX_PIECE_MB 8
+#endif
+    static constexpr size_t PIECE = (size_t)GBX_PIECE_MB << 20;   // upload piece = worker slab
     static constexpr size_t DOWN = (size_t)16 << 20;        // download slab
     int dev = 0;
     // Two streams only.  The runtime maps all streams of a process onto four hardware queues, and streams that
