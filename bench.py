@@ -1058,6 +1058,8 @@ def main():
     ap.add_argument("--cpu-units", type=int, default=0, help="units in the CPU-baseline sample (0 = kernel default)")
     ap.add_argument("--verify-units", type=int, default=0, help="units per shard checked against the oracle after the gather")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of chain / phmm / poa / abea in the all-kernel run")
+    ap.add_argument("--full-kernels", action="store_true", help="the other kernels' records in full inside the line (default: short form in the line, "
+                    "full records on stderr)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="print the argv / environment of the ranks `--gpus N` would start, start nothing")
@@ -1148,12 +1150,40 @@ def main():
                 st["scaling"] = "strong"
                 others["poa"]["config4_strong"] = st
         if line is not None:
-            line["kernels"] = others
+            # the headline line stays as measured; the five other kernels ride along in short form (what a reader of the
+            # line's tail needs: value, time, roofline figures, what was checked) and in full on stderr
+            if rank == 0 and not args.full_kernels:
+                print("kernels in full: " + json.dumps(others), file=sys.stderr, flush=True)
+            keep = ("shard_units", "scatter_ms", "gather_ms", "rccl_ranks", "comm") if world > 1 else ()      # the sharding's own figures
+            line["kernels"] = others if args.full_kernels else {k: compact_entry(v, keep=keep) for k, v in others.items()}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_COMPACT_DROP = {"n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline", "data", "rccl_ranks", "comm", "parallelism", "inputs", "mode",
+                 "traffic_source", "valu_busy_source", "dataset_gen_s", "shard_units", "scatter_ms", "gather_ms", "first_call_ms", "what", "cell",
+                 "algorithmic_bytes_per_launch", "cells_per_s_dominant_kernel", "job_lane_ops_per_s", "valu_roof_lane_ops_per_s", "valu"}
+
+
+def compact_entry(v, key=None, depth=0, keep=()):
+    """Short form of a per-kernel record for the all-kernels line: no nulls, no keys that repeat the headline's, strings cut
+    at 100 characters, floats at five significant digits, the three longest stages of kernels_ms."""
+    if isinstance(v, dict):
+        if key == "kernels_ms":
+            v = dict(sorted(v.items(), key=lambda kv: -kv[1])[:3])
+        if "scaling" in v and v["scaling"] != "weak":
+            v = dict(v, strong_scaling=True)
+        return {k: compact_entry(x, k, depth + 1, keep) for k, x in v.items() if x is not None and (k not in _COMPACT_DROP or k in keep)}
+    if isinstance(v, float):
+        return float("%.5g" % v)
+    if isinstance(v, str):
+        return v if len(v) <= 100 else v[:97] + "..."
+    if isinstance(v, (list, tuple)):
+        return [compact_entry(x, None, depth + 1, keep) for x in v[:8]]
+    return v
 
 
 S = None

@@ -7,7 +7,7 @@ tag=${1:-rXX}; kinds=${2:-"bsw poa"}
 out=gpurun_out; mkdir -p $out
 (time timeout 1500 python -m pytest tests -m gpu -x -q) > $out/${tag}_pytest_gpu.log 2>&1; tail -4 $out/${tag}_pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1; tail -1 $out/${tag}_smoke.log
-timeout 1500 python bench.py > $out/${tag}_bench_all_kernels.json 2> $out/${tag}_bench.err; python3 scripts/show_bench_line.py < $out/${tag}_bench_all_kernels.json 2>/dev/null | cut -c1-400 | head -8
+timeout 1500 python bench.py > $out/${tag}_bench_all_kernels.json 2> $out/${tag}_bench.err; grep "^kernels in full: " $out/${tag}_bench.err | cut -c18- > $out/${tag}_bench_kernels_full.json; python3 scripts/show_bench_line.py < $out/${tag}_bench_all_kernels.json 2>/dev/null | cut -c1-400 | head -8
 for k in $kinds; do
   bash scripts/kstats.sh $k > $out/${tag}_${k}_kstats.txt 2>&1
   cp $out/kstats_$k.csv $out/${tag}_${k}_large_kernel_stats.csv 2>/dev/null

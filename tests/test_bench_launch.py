@@ -71,3 +71,24 @@ def test_torchrun_launch_still_works():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["world"] == 2 and line["omp_num_threads"] == str(os.cpu_count())
+
+
+def test_short_form_of_the_other_kernels_records():
+    """The all-kernels line carries chain / phmm / poa / abea / fmi in short form (the full records go to stderr): no nulls, no
+    keys that repeat the headline's, long strings cut, the three longest stages; the sharding's own figures stay for N > 1."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rec = {"metric": "x", "value": 1.23456789, "unit": "GCUPS", "n_gpus": 2, "scaling": "weak", "vs_baseline": None, "ms_per_step": 2.0,
+           "config": {"workload": "w" * 300, "parallelism": "p", "calls": 7},
+           "roofline": {"bound": "hbm", "traffic": None, "traffic_source": "s", "frac": 0.123456789, "valu": {"a": 1}},
+           "kernels_ms": {"a": 1.0, "b": 5.0, "c": 3.0, "d": 0.1}, "shard_units": [5, 5], "scatter_ms": 1.5,
+           "config4_strong": {"scaling": "strong", "value": 2.0, "shard_units": [1, 2]}}
+    c = m.compact_entry(rec)
+    assert "n_gpus" not in c and "vs_baseline" not in c and "shard_units" not in c and "scatter_ms" not in c
+    assert c["value"] == 1.2346 and len(c["config"]["workload"]) == 100 and c["config"]["calls"] == 7 and "parallelism" not in c["config"]
+    assert c["roofline"] == {"bound": "hbm", "frac": 0.12346} and list(c["kernels_ms"]) == ["b", "c", "a"]
+    k = m.compact_entry(rec, keep=("shard_units", "scatter_ms"))
+    assert k["shard_units"] == [5, 5] and k["scatter_ms"] == 1.5 and k["config4_strong"]["shard_units"] == [1, 2] and k["config4_strong"]["strong_scaling"]
+    assert len(json.dumps(c)) < len(json.dumps(rec))
