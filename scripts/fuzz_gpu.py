@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU: host entries of the six kernels against the oracle on random jobs of random
-sizes (small-job modes, class modes, staged and packed transfers all get hit).  usage: fuzz_gpu.py [seconds] [seed]"""
+sizes (small-job modes, class modes, staged and packed transfers all get hit).  usage: fuzz_gpu.py [seconds] [seed]
+FUZZ_LOG=<file>: every job's description is appended (and synced) before it runs - after a hang the last line is the culprit;
+FUZZ_SKIP_UNTIL=<n>: the first n-1 jobs are drawn but not run (replays the random stream up to a job of interest)."""
 import os
 import sys
 import time
@@ -25,11 +27,26 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N.check(N.lib().gbx_host_prepare())
 t_end = time.time() + budget
 count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0, "fmi": 0}
+skip_until = int(os.environ.get("FUZZ_SKIP_UNTIL", "0"))       # replay aid: draw the first jobs without running them
+job_no = 0
+
+
+def announce(text):
+    """the job about to run, flushed before it runs: a hang leaves its description as the last line (FUZZ_LOG=file)"""
+    path = os.environ.get("FUZZ_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write("job %d %s\n" % (job_no, text))
+            fh.flush()
+            os.fsync(fh.fileno())
+    return job_no >= skip_until
 fmi_idx = {}                                                    # genome length -> (genome, index): built once per size
 n_multi = 0
 while time.time() < t_end:
     k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea", "fmi"])
     seed = int(rng.integers(1, 1 << 30))
+    job_no += 1
+    ok, what = True, ""
     # a third of the jobs through the multi-device layer of the host entries: 2-4 logical devices on this GPU, cut however
     # small the job is (half of those) or only when it is large enough by the kernel's own threshold
     ndev = int(rng.choice([2, 3, 4])) if rng.random() < 0.33 else 0
@@ -50,13 +67,14 @@ while time.time() < t_end:
                                                   mat=fill_scmat(int(rng.integers(1, 4)), int(rng.integers(1, 6)), -int(rng.integers(0, 3))))
         p = bsw_params(**kw)
         lane = rng.random() < 0.5                                # the lane kernels (large jobs take them by default) on this job too
+        what = "n=%d adversarial=%s lane=%s kw=%s" % (n, adv, lane, kw)
+        run = announce("bsw seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what))
         if lane:
             os.environ["GBX_BSW_LANE"] = "1"
         try:
-            ok = np.array_equal(extend_host(p, b), O.bsw_oracle(p, b, 8))
+            ok = not run or np.array_equal(extend_host(p, b), O.bsw_oracle(p, b, 8))
         finally:
             os.environ.pop("GBX_BSW_LANE", None)
-        what = "n=%d adversarial=%s lane=%s kw=%s" % (n, adv, lane, kw)
     elif k == "chain":
         nc = int(rng.choice([1, 3, 40, 300]))
         real = bool(rng.random() < 0.5)                          # minimap2's strand / reference structure: calls cut into jobs
@@ -65,9 +83,10 @@ while time.time() < t_end:
             case[2][:] |= (rng.integers(0, 2, len(case[2])).astype(np.uint64) << np.uint64(48))
             case[3]["n_segs"] = 2
             case[3]["max_dist_y"] = 800
-        got, want = chain_host(*case), O.chain_oracle(*case, nthreads=8)
-        ok = all(np.array_equal(g, w) for g, w in zip(got, want))
         what = "calls=%d realistic=%s n_segs=%d" % (nc, real, int(case[3]["n_segs"][0]))
+        if announce("chain seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
+            got, want = chain_host(*case), O.chain_oracle(*case, nthreads=8)
+            ok = all(np.array_equal(g, w) for g, w in zip(got, want))
     elif k == "fmi":
         glen = int(rng.choice([3000, 200000, 3000000]))
         if glen not in fmi_idx:
@@ -86,27 +105,33 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             P.split_width, P.max_mem_intv = int(rng.integers(1, 30)), int(rng.integers(0, 60))
         os.environ["GBX_FMI_WIDE"] = "1" if rng.random() < 0.3 else "0"     # the 64-bit instance too
-        (go, goff), (wo, woff) = smem_host(idx, rs, P, out_cap=max(64, 200 * nr, nr * (rl + 64))), O.fmi_oracle(idx, rs, P, nthreads=8)
-        ok = np.array_equal(goff, woff) and all(np.array_equal(go[f], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
-        what = "genome=%d reads=%d len=%d minseed=%d wide=%s" % (glen, nr, rl, P.min_seed_len, os.environ["GBX_FMI_WIDE"])
+        what = "genome=%d reads=%d len=%d minseed=%d wide=%s split_width=%d max_mem_intv=%d ragged=%s" % (
+            glen, nr, rl, P.min_seed_len, os.environ["GBX_FMI_WIDE"], P.split_width, P.max_mem_intv, bool((rs.read_len != rs.read_len[0]).any()))
+        if announce("fmi seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
+            (go, goff), (wo, woff) = smem_host(idx, rs, P, out_cap=max(64, 200 * nr, nr * (rl + 64))), O.fmi_oracle(idx, rs, P, nthreads=8)
+            ok = np.array_equal(goff, woff) and all(np.array_equal(go[f], wo[f]) for f in ("rid", "m", "n", "k", "l", "s"))
     elif k == "phmm":
         nb = int(rng.choice([1, 2, 9, 40, 90]))
         bs = gen_phmm(nb, seed)
-        want, _ = O.phmm_oracle(bs, 8, True)
-        got = forward_host(bs)
-        ok = bool(np.all(np.abs(got - want) <= 1e-5 * np.maximum(1, np.abs(want)) + 5e-7))
         what = "batches=%d pairs=%d" % (nb, bs.n_pairs)
+        if announce("phmm seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
+            want, _ = O.phmm_oracle(bs, 8, True)
+            got = forward_host(bs)
+            ok = bool(np.all(np.abs(got - want) <= 1e-5 * np.maximum(1, np.abs(want)) + 5e-7))
     elif k == "abea":
         nr = int(rng.choice([1, 3, 24, 150, 700]))             # 700 reads: the staged transfers and the packed download
-        rs = gen_abea(nr, seed % 100000, first=int(rng.integers(0, 5000)))
-        if rng.random() < 0.3:                                   # push some reads out of the fast-division range
+        first = int(rng.integers(0, 5000))
+        rs = gen_abea(nr, seed % 100000, first=first)
+        extreme = rng.random() < 0.3
+        if extreme:                                              # push some reads out of the fast-division range
             ev = rs.event_mean
             for r in rng.choice(nr, size=max(1, nr // 4), replace=False):
                 a, b = int(rs.event_off[r]), int(rs.event_off[r + 1])
                 ev[a + int(rng.integers(0, b - a))] = np.float32(rng.choice([1e-30, 3e13, 0.0]))
-        (go, gn), (wo, wn) = align_host(rs), O.abea_oracle(rs, 16)
-        ok = np.array_equal(gn, wn) and all(np.array_equal(g, w) for g, w in zip(rs.split_pairs(go, gn), rs.split_pairs(wo, wn)))
-        what = "reads=%d" % nr
+        what = "reads=%d first=%d extreme_events=%s" % (nr, first, extreme)
+        if announce("abea seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
+            (go, gn), (wo, wn) = align_host(rs), O.abea_oracle(rs, 16)
+            ok = np.array_equal(gn, wn) and all(np.array_equal(g, w) for g, w in zip(rs.split_pairs(go, gn), rs.split_pairs(wo, wn)))
     else:
         nw = int(rng.choice([1, 5, 40]))
         ws = gen_poa(nw, seed)
@@ -116,12 +141,13 @@ while time.time() < t_end:
             os.environ["GBX_POA_LOCKSTEP"] = "1"
             os.environ["GBX_POA_TB_SERIAL"] = str(int(rng.integers(0, 2)))
             os.environ["GBX_POA_DP_OCC"] = str(int(rng.choice([5, 6])))
+        what = "windows=%d lockstep=%s tb_serial=%s dp_occ=%s" % (nw, lock, os.environ.get("GBX_POA_TB_SERIAL"), os.environ.get("GBX_POA_DP_OCC"))
+        run = announce("poa seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what))
         try:
-            ok = consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
+            ok = not run or consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
         finally:
             for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC"):
                 os.environ.pop(v, None)
-        what = "windows=%d lockstep=%s" % (nw, lock)
     what += " devices=%d min_units=%s" % (ndev, os.environ.get("GBX_SHARD_MIN_UNITS"))
     count[k] += 1
     if not ok:
