@@ -112,6 +112,9 @@ __global__ void __launch_bounds__(256) chain_order_kernel(ChainWork W, int pass)
 // -DGBX_CHAIN_STAMPS: s_memtime stamps around the parts of an anchor, accumulated by the block that runs the longest
 // call (slot 0) and read back with gbx_debug_chain_stamps (scripts/dbg_chain_stamps.py).  A stamp is read through
 // lgkmcnt, so it also drains the LDS reads issued before it: a part is charged its own LDS latency.
+#ifndef GBX_CHAIN_QUIET
+#define GBX_CHAIN_QUIET 1
+#endif
 #ifndef GBX_CHAIN_WINDOW
 #define GBX_CHAIN_WINDOW 1
 #endif
@@ -349,7 +352,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
             const unsigned dr_lim = n_segs > 1 ? (max_dist_y < 0 ? 0u : (unsigned)max_dist_y) : 0xffffffffu;
 
     #ifdef GBX_CHAIN_STAMPS
-            unsigned long long acc_[12] = {0}, last_ = 0, n_chunks_ = 0;
+            unsigned long long acc_[12] = {0}, last_ = 0, n_chunks_ = 0, n_quiet_ = 0, n_scan_ = 0, n_break_ = 0;
     #endif
             int st = 0;
             int sb = 0;                                           // unsorted calls: block of 64 x-values cached for the st scan
@@ -415,6 +418,15 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
 
                     STAMP(0);
                     int max_f = q_span, max_j = -1, max_pk = 0, n_skip = 0, last_bl = 64;   // max_pk: peak of anchor max_j (:92)
+                    // :89 for the lanes of a chunk visited before the break (lane < bl): targets[parents[j]] = i, in the ring while the
+                    // parent's block is live, straight to the output (already flushed there) when it is older
+                    auto mark_targets = [&](bool skip, int pj, int bl) {
+                        // live_lo = max(live0, 0): "has a parent that is still in the ring" is one compare
+                        const bool vis = !skip && lane < bl;
+                        rst[vis && pj >= live_lo ? slot_of(pj) : RING_PHYS + lane].z = iabs;   // non-writers: their dump entry
+                        if (live0 > 0 && __ballot(vis && pj >= 0 && pj < live0))            // rare: the parent left the ring
+                            if (vis && pj >= 0 && pj < live0) t[pj] = iabs;
+                    };
                     // One 64-wide chunk of the look-back, lane 0 = anchor jhi.  Returns true when the max_skip break fired.
                     // The anchor words and DP state of the chunk arrive as arguments, so that the ring path below is
                     // made of LDS reads only.
@@ -510,9 +522,21 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                             improving = false;
                             bump = !skip && hit;
                             const unsigned long long bm = __ballot(bump);
+                            if (GBX_CHAIN_QUIET && bm == 0) {
+                                // ... and nobody is marked either: max_f, n_skip and the break are as they were, only :89 is left
+                                last_bl = 64;
+    #ifdef GBX_CHAIN_STAMPS
+                                ++n_quiet_;
+    #endif
+                                mark_targets(skip, pj, 64);
+                                return false;
+                            }
                             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
                             nl = n_skip + below + (bump ? 1 : 0);
                         } else {
+    #ifdef GBX_CHAIN_STAMPS
+                            ++n_scan_;
+    #endif
                             const unsigned pm = wave_scan_umax(cand);                 // inclusive prefix max of candidates
                             unsigned pmx = (unsigned)dppi<0x138>(0, (int)pm);         // exclusive (wave_shr:1)
                             pmx = lane == 0 ? 0u : pmx;
@@ -556,15 +580,12 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         STAMP(5);
                         // ---- phase 4: targets[parents[j]] = i for lanes visited before the break (:89): in the ring while
                         // the parent's block is live, straight to the output (already flushed there) when it is older
-                        {
-                            // live_lo = max(live0, 0): "has a parent that is still in the ring" is one compare
-                            const bool vis = !skip && lane < bl;
-                            rst[vis && pj >= live_lo ? slot_of(pj) : RING_PHYS + lane].z = iabs;   // non-writers: their dump entry
-                            if (live0 > 0 && __ballot(vis && pj >= 0 && pj < live0))            // rare: the parent left the ring
-                                if (vis && pj >= 0 && pj < live0) t[pj] = iabs;
-                        }
+                        mark_targets(skip, pj, bl);
                         n_skip = __builtin_amdgcn_readlane(nl, 63);
                         STAMP(6);
+    #ifdef GBX_CHAIN_STAMPS
+                        if (bl < 64) ++n_break_;
+    #endif
                         return bl < 64;
                     };
                     int jhi = i - 1;
@@ -636,6 +657,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
             if (lane == 0 && (unsigned long long)n >= g_chain_stamps[13]) {      // the longest call finishes last
                 for (int k = 0; k < 9; ++k) g_chain_stamps[k] = acc_[k];
                 g_chain_stamps[12] = n_chunks_; g_chain_stamps[13] = (unsigned long long)n;
+                g_chain_stamps[9] = n_quiet_; g_chain_stamps[10] = n_scan_; g_chain_stamps[11] = n_break_;
             }
     #endif
         };

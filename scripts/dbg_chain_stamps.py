@@ -19,6 +19,8 @@ v = list(out)
 names = ["st advance", "ring/global loads (wait)", "phase1 math", "phase2 marks", "phase3 scans", "ballots/readlane", "phase4 stores", "loop overhead/exit", "outputs+ring update"]
 tot = sum(v[:9]); na = v[13]; nch = v[12]
 print("chunks past the ring (global loads)", v[14])
+print("of the chunks: quiet (nobody improves, nobody is marked) %.1f %%, with a prefix-max scan (somebody improves) %.1f %%, ending in the max_skip break %.1f %% (%.2f breaks per anchor)"
+      % (100.0 * v[9] / max(v[12], 1), 100.0 * v[10] / max(v[12], 1), 100.0 * v[11] / max(v[12], 1), v[11] / max(v[13], 1)))
 print("anchors", na, "chunks", nch, "chunks/anchor %.2f" % (nch / max(na, 1)), "cycles/anchor %.0f" % (tot / max(na, 1)))
 for k, nm in enumerate(names):
     per = v[k] / max(nch if 1 <= k <= 6 else na, 1)
