@@ -44,6 +44,9 @@ constexpr int ROW = 64;                       // trace bytes per band (one per l
 #define ABEA_NEG_INF (-__builtin_inff())
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef GBX_ABEA_ASM_DIV
+#define GBX_ABEA_ASM_DIV 1
+#endif
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) v4u lds_v4u;
 
@@ -258,7 +261,39 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
             }
             // lp_match (:143-147) of the lane's two cells
             float lpeA, lpeB;
-            if constexpr (FDIV) {
+            // the candidates' first sums, (double)diag + lp_step and (double)up + lp_stay (:371-372), do not depend on the emission
+            double pdA = 0, puA = 0, pdB = 0, puB = 0;
+            bool pre_sums = false;
+            if constexpr (FDIV && GBX_ABEA_ASM_DIV) {
+                // The packed division chain (see the branch below) is eight dependent v_pk_* operations, and a dependent packed
+                // operation needs a wait state: the compiler filled seven of them with s_nop - issue slots of their own for a
+                // lone wavefront (scripts/issue_cost.hip), a tenth of the longest read's band.  Written out here with the
+                // conversions and first sums of the candidates in those slots.
+                v2f a, q0, t, q1, q, h, l;
+                asm("v_pk_add_f32 %[a], %[ev], %[km] neg_lo:[0,1] neg_hi:[0,1]\n"
+                    "v_cvt_f64_f32 %[pdA], %[dgA]\n"
+                    "v_pk_mul_f32 %[q0], %[a], %[kr]\n"
+                    "v_cvt_f64_f32 %[puA], %[upA]\n"
+                    "v_pk_fma_f32 %[t], %[ks], %[q0], %[a] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+                    "v_add_f64 %[pdA], %[pdA], %[step]\n"
+                    "v_pk_fma_f32 %[q1], %[t], %[kr], %[q0]\n"
+                    "v_add_f64 %[puA], %[puA], %[stay]\n"
+                    "v_pk_fma_f32 %[t], %[ks], %[q1], %[a] neg_lo:[1,0,0] neg_hi:[1,0,0]\n"
+                    "v_cvt_f64_f32 %[pdB], %[dgB]\n"
+                    "v_pk_fma_f32 %[q], %[t], %[kr], %[q1]\n"
+                    "v_cvt_f64_f32 %[puB], %[upB]\n"
+                    "v_pk_mul_f32 %[h], %[q], -0.5 op_sel_hi:[1,0]\n"
+                    "v_add_f64 %[pdB], %[pdB], %[step]\n"
+                    "v_pk_mul_f32 %[h], %[h], %[q]\n"
+                    "v_add_f64 %[puB], %[puB], %[stay]\n"
+                    "v_pk_add_f32 %[l], %[kc], %[h]\n"
+                    : [a] "=&v"(a), [q0] "=&v"(q0), [t] "=&v"(t), [q1] "=&v"(q1), [q] "=&v"(q), [h] "=&v"(h), [l] "=&v"(l),
+                      [pdA] "=&v"(pdA), [puA] "=&v"(puA), [pdB] "=&v"(pdB), [puB] "=&v"(puB)
+                    : [ev] "v"(ev), [km] "v"(km), [kr] "v"(kr), [ks] "v"(ks), [kc] "v"(kc), [dgA] "v"(dgA), [upA] "v"(upA), [dgB] "v"(dgB), [upB] "v"(upB),
+                      [step] "v"(lp_step), [stay] "v"(lp_stay));
+                lpeA = l.x; lpeB = l.y;
+                pre_sums = true;
+            } else if constexpr (FDIV) {
                 // both cells at once on the packed-float pipe: q = a / gs as the compiler's division computes it once
                 // its rescaling is the identity - a first quotient and two residual corrections against gs
                 const v2f a = ev - km;
@@ -272,9 +307,9 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
                 lpeA = kc.x + (-0.5f * aA * aA);
                 lpeB = kc.y + (-0.5f * aB * aB);
             }
-            auto cell = [&](int o, float diag, float up, float left, float lpe, float &val, int &from) {
-                const float score_d = (float)(((double)diag + lp_step) + (double)lpe);       // :371-373
-                const float score_u = (float)(((double)up + lp_stay) + (double)lpe);
+            auto cell = [&](int o, float diag, float up, float left, float lpe, double pd, double pu, float &val, int &from) {
+                const float score_d = (float)((pre_sums ? pd : (double)diag + lp_step) + (double)lpe);       // :371-373
+                const float score_u = (float)((pre_sums ? pu : (double)up + lp_stay) + (double)lpe);
                 const float score_l = (float)((double)left + lp_skip);
                 float max_score = score_d;
                 int f = 0;                                                                    // FROM_D
@@ -303,8 +338,8 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
             };
             float na, nb;
             int fa, fb;
-            cell(oA, dgA, upA, lfA, lpeA, na, fa);
-            cell(oB, dgB, upB, lfB, lpeB, nb, fb);
+            cell(oA, dgA, upA, lfA, lpeA, pdA, puA, na, fa);
+            cell(oB, dgB, upB, lfB, lpeB, pdB, puB, nb, fb);
             // two back-pointers per lane; bits 4 and 5 of every byte of the row say "this band / the band before it
             // moved to the right", which is how the traceback follows the band corners without a per-band corner array
             tring[lane * 16 + (b & 15)] = (uint8_t)(fa | (fb << 2) | (right ? 16 : 0) | (prev_right ? 32 : 0));
