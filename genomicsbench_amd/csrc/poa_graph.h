@@ -287,7 +287,11 @@ PG_HD int poa_consensus(PoaGraph &g, uint8_t *out, int cap)
         g.score[id] = sc; g.pred[id] = pr;
         if (g.score[max_id] < sc) max_id = id;
     }
-    while (g.out_cnt[max_id] != 0) max_id = poa_branch_completion(g, g.n2r[max_id]);
+    // (every completion moves to a node of higher rank: at most n_nodes of them; the bound only matters on a corrupted graph)
+    for (int guard = 0; g.out_cnt[max_id] != 0; ++guard) {
+        if (guard > g.n_nodes) { g.err |= POA_ERR_STACK; break; }
+        max_id = poa_branch_completion(g, g.n2r[max_id]);
+    }
     // backtrack, then emit reversed
     int len = 0;
     while (g.pred[max_id] != -1) { g.cons_path[len++] = max_id; max_id = g.pred[max_id]; if (len >= g.ncap) { g.err |= POA_ERR_STACK; break; } }
