@@ -997,6 +997,80 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
     return line
 
 
+def predict_shards(kind, args, ctx, parts, steps, warmup, whole_ms=None):
+    """BASELINE config 4 on ONE GPU: ONE 'large' job cut into `parts` shards exactly as the N-GPU strong-scaling leg
+    (`config4_strong`) cuts it, every shard run ALONE on this GPU through the same device entry (upload = the scatter's
+    stand-in, timed steps, download, front of the shard checked against the oracle).  A rank of the N-GPU run holds one
+    shard on a GPU of its own, so the slowest shard alone is what the N-GPU step would take (no data-path collective;
+    scatter / gather are outside the timed region there as here): predicted_ms_per_step = max over shards,
+    predicted_speedup = the whole job on this GPU / that."""
+    import torch
+    from genomicsbench_amd import _native as N
+    dev = ctx["dev"]
+    stream = torch.cuda.current_stream().cuda_stream
+    sub = argparse.Namespace(**vars(args))
+    sub.size = 0
+    probe = WORKLOADS[kind](sub)
+    full = probe.generate(0, probe.n)
+    verify = args.verify_units or {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8, "fmi": 20000}[kind]
+
+    def one(host_shard, lo, hi):
+        w = WORKLOADS[kind](sub)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        buf, meta = S.pack_arrays(w.to_arrays(host_shard))
+        tensors = S.unpack_tensor(torch.from_numpy(buf).to(dev), meta)
+        torch.cuda.synchronize()
+        up_ms = (time.perf_counter() - t0) * 1e3
+        w.attach(tensors, dev, host_shard)
+        for _ in range(warmup):
+            w.run(stream)
+        torch.cuda.synchronize()
+        N.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.run(stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        stages = N.profile_end()
+        if hasattr(w, "finish"):
+            w.finish(stream)
+        t0 = time.perf_counter()
+        out = w.output_tensor().contiguous().cpu()
+        down_ms = (time.perf_counter() - t0) * 1e3
+        rec = {"units": hi - lo, "ms_per_step": ms, "upload_ms": up_ms, "download_ms": down_ms, "work_units": w.units,
+               "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1][0])[:3]}}
+        rec.update({k: v for k, v in w.extra.items() if k in ("longest_job_anchors", "jobs_this_gpu")})
+        if verify:
+            rec["verified"] = w.check_gathered(full, [(lo, hi)], [out], verify)
+        del w, tensors, out
+        torch.cuda.empty_cache()
+        return rec
+
+    if whole_ms is None:
+        n_all = probe.n_units(probe.shards(full, 1)[0])
+        whole = one(probe.shards(full, 1)[0], 0, n_all)
+        whole_ms = whole["ms_per_step"]
+    shards = probe.shards(full, parts)
+    sizes = [probe.n_units(sh) for sh in shards]
+    recs, lo = [], 0
+    for sh, n in zip(shards, sizes):
+        recs.append(one(sh, lo, lo + n))
+        lo += n
+    worst = max(range(parts), key=lambda k: recs[k]["ms_per_step"])
+    pred = recs[worst]["ms_per_step"]
+    total_units = sum(r["work_units"] or 0.0 for r in recs)
+    ok = all("DIFFER" not in r.get("verified", "") for r in recs)
+    return {"what": "ONE %s 'large' job cut into %d shards as config4_strong cuts it; every shard alone on this GPU" % (kind, parts),
+            "parts": parts, "steps": steps, "shard_units": sizes, "shard_ms": [round(r["ms_per_step"], 3) for r in recs],
+            "whole_job_ms_1gpu": whole_ms, "predicted_ms_per_step": pred, "predicted_speedup": whole_ms / pred,
+            "predicted_value": total_units / (pred * 1e-3) / 1e9, "unit": probe.unit, "slowest_shard": worst,
+            "slowest_shard_kernels_ms": recs[worst]["kernels_ms"],
+            "scatter_standin_ms_max": max(r["upload_ms"] for r in recs), "gather_standin_ms_max": max(r["download_ms"] for r in recs),
+            "verified": ("front %d units of every shard vs oracle: " % verify) + ("identical" if ok else "DIFFER"),
+            **({"longest_job_anchors": max(r.get("longest_job_anchors", 0) for r in recs)} if kind == "chain" else {})}
+
+
 def launch_plan(args, argv):
     """argv + environment of every rank a plain `python bench.py --gpus N` starts (one process per GPU, rendezvous on
     127.0.0.1, the same variables torch.distributed.run sets).  Pure: no torch, no GPU."""
@@ -1061,6 +1135,10 @@ def main():
     ap.add_argument("--full-kernels", action="store_true", help="the other kernels' records in full inside the line (default: short form in the line, "
                     "full records on stderr)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--predict-shards", type=int, default=0,
+                    help="N=1 only, with --kernel K: cut ONE 'large' job into this many shards as the N-GPU strong-scaling leg does, run "
+                         "every shard alone, print per-shard ms and the predicted N-GPU step (BASELINE config 4 is poa over 8)")
+    ap.add_argument("--no-predict", action="store_true", help="skip poa's config4_predicted leg of the all-kernel run")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="print the argv / environment of the ranks `--gpus N` would start, start nothing")
     ap.add_argument("--launch-echo", action="store_true",
@@ -1127,7 +1205,12 @@ def main():
         ndev = torch.cuda.device_count()
         _CTX.update(dist=dist, ranks_per_device=-(-world // ndev), turn=rank // ndev)
 
-    if args.kernel:
+    if args.kernel and args.predict_shards:
+        if world != 1:
+            raise SystemExit("bench.py: --predict-shards is a one-GPU measurement")
+        line = {"metric": WORKLOADS[args.kernel].metric + "_predicted_%dgpu" % args.predict_shards, "n_gpus": 1, "scaling": "strong",
+                "config4_predicted": predict_shards(args.kernel, args, ctx, args.predict_shards, args.steps, args.warmup)}
+    elif args.kernel:
         line = run_kernel(args.kernel, args, ctx, args.steps, args.warmup)
     else:
         line = run_kernel("bsw", args, ctx, args.steps, args.warmup)
@@ -1149,6 +1232,10 @@ def main():
             if st is not None:
                 st["scaling"] = "strong"
                 others["poa"]["config4_strong"] = st
+        # ... and at N = 1 its prediction: the eight shards of that cut, each alone on this GPU (the slowest one is the 8-GPU step)
+        if world == 1 and args.mode != "local" and not args.size and not args.no_predict:
+            torch.cuda.empty_cache()
+            others["poa"]["config4_predicted"] = predict_shards("poa", args, ctx, 8, 2, 1, whole_ms=others["poa"]["ms_per_step"])
         if line is not None:
             # the headline line stays as measured; the five other kernels ride along in short form (what a reader of the
             # line's tail needs: value, time, roofline figures, what was checked) and in full on stderr
