@@ -122,6 +122,12 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, b
 #ifndef GBX_POA_LONG_INC
 #define GBX_POA_LONG_INC 1          // ... and whether its topological sort is the incremental one
 #endif
+#ifndef GBX_POA_TEAM_WAVES
+#define GBX_POA_TEAM_WAVES 3        // the team kernel (a window per workgroup of four wavefronts): wavefronts per SIMD of the main-list instance
+#endif
+#ifndef GBX_POA_TEAM_LONG_WAVES
+#define GBX_POA_TEAM_LONG_WAVES 1   // ... and of the long-window instance (column-block DP for sequences over 512 bases)
+#endif
 #ifndef GBX_POA_PLANES
 #define GBX_POA_PLANES 2
 #endif
@@ -703,6 +709,302 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
         ap2 = bp2; ainfo = binfo;
         bp0 = cp0; bp1 = cp1; bp2 = cp2; binfo = cinfo;
     }
+}
+
+
+// ---- the TEAM form of the pipelined DP (round 5): one window on NW wavefronts of a workgroup -------------------------------------
+// A window that has a SIMD to itself - every window of BASELINE config 4's 8-GPU leg: 750 windows per GPU on 1 024 SIMDs - is a
+// serial job: a lone wavefront issues one instruction per ~8 clocks whatever its kind (scripts/issue_cost.hip), 2 400 clocks per DP
+// row, 77 ms per window, of which the DP is 60 % (profiles/r05a_poa_lone_windows.txt).  The rows of a partial-order graph are only
+// partially ordered: a row needs its predecessor rows and nothing else, and the graph of thirty noisy reads is several letters wide
+// (a row's first predecessor is the row before it in 22 % of the cases).  So the NW wavefronts of a workgroup take the rows of the
+// topological order in turn (row i belongs to wavefront (i - 1) % NW) and run them as a DATAFLOW: a row starts when its predecessor
+// rows are complete.  The row arithmetic is poa_dp_pipelined's, unchanged; what is new is the hand-over between the wavefronts:
+//   * the last RR rows live in an LDS ring shared by the team (slot i % RR; one more slot holds row 0); a predecessor at most K rows
+//     back is read from there, behind its owner's progress word prog[w] = last row wavefront w has completed (LDS: written after the
+//     ring slot, and the LDS serves a wavefront's operations in order);
+//   * a row further back comes from HBM with NO wait: row i starts only when every row <= i - BOUND is complete (BOUND = RR - K: that
+//     is also what keeps a ring slot from being overwritten while a reader may still want it), and a wavefront completes a row only
+//     after `s_waitcnt vmcnt(3)` behind that row's three stores, i.e. after the stores of its PREVIOUS row are acknowledged.  With
+//     K >= BOUND + NW - 1 the owner of a far row p has completed row p + NW by then: the far row's stores are visible by construction
+//     (all wavefronts of a workgroup share the CU's vector L1, which is write-through).
+// A waiting wavefront sleeps (s_sleep) and polls one LDS word per owner; the smallest incomplete row never waits for anything, so the
+// team always makes progress.
+struct PoaTeamSync {
+    int prog[4];                 // last DP row (1-based) wavefront w has completed
+    int best[4], best_i[4];      // best sink score of wavefront w's rows and its row
+    int n_nodes, err, widx, pad_;    // the team's view of the window: graph size and error bits after the last add_alignment, work item
+};
+typedef __attribute__((address_space(3))) PoaTeamSync lds_team;
+typedef __attribute__((address_space(3))) int lds_i32;
+
+template <int NW, int RR, int K>
+__device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len, int n,
+                                                           char *lds_ring, lds_team *sy, int wave, int &max_i, int &max_j)
+{
+    static_assert(NW == 2 || NW == 4, "row owner = (i - 1) & (NW - 1)");
+    static_assert((RR & (RR - 1)) == 0, "ring slot = i & (RR - 1)");
+    constexpr int CPL = 8, NT = 64 * NW, BOUND = RR - K;
+    static_assert(BOUND >= NW && K >= BOUND + NW - 1, "far rows must be acknowledged by construction");
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const PoaScore S = A.S;
+    const int Wp = M.Wp;
+    const Mat2 *Tc = A.Tc[0];
+    const PkMat T0 = pk_mat(Tc[0]), T1 = pk_mat(Tc[1]), T2 = pk_mat(Tc[2]), T3 = pk_mat(Tc[3]);
+    const PkMat P16 = pk_mat(mp_pow(Tc[0], (lane & 15) + 1));
+    const PkMat P32 = pk_mat(mp_pow(Tc[0], (lane & 31) + 1));
+    const PkMat PC = pk_mat(mp_pow(Tc[0], lane));
+    const v2s G2 = pk2(S.g, S.g), E2 = pk2(S.e, S.e), Q2 = pk2(S.q, S.q), C2 = pk2(S.c, S.c);
+    const v2s GQ = pk2(S.g, S.q), EC = pk2(S.e, S.c), NM = pk2(S.n - S.m, S.n - S.m), MM = pk2(S.m, S.m);
+    const v2s NEG2 = pk2(PK_NEG, PK_NEG);
+    const int j0 = lane * CPL + 1;
+    const bool mine = j0 <= len;
+
+    // ---- set-up by all NT threads: row 0 (`initialize`) in memory and in the ring's extra slot, the row descriptors
+    for (int j = tid; j <= len; j += NT) {
+        const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
+        M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
+    }
+    uint8_t *const FO = (uint8_t *)M.F;
+    for (int j = tid; j < POA_PIPE_STRIDE * 2; j += NT) FO[j] = 255;
+    if (tid == 0) { M.H[POA_COL0 + POA_C0_F] = 0; M.H[POA_COL0 + POA_C0_O] = 0; }
+    int32_t *d_pred = g.score, *d_info = g.pred;
+    const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;
+    int32_t *d_pred3 = g.stack;
+    {
+        PoaGraph &gm = const_cast<PoaGraph &>(g);
+        for (int r = tid; r < n; r += NT) {
+            poa_rowdesc_one(gm, r);
+            const int node = g.r2n[r];
+            d_pred3[r] = g.in_cnt[node] > 3 ? g.n2r[PG_IN_SRC(g, node, 3)] + 1 : 0;
+        }
+    }
+    char *const ring_lane = lds_ring + lane * 16;
+    if (wave == 0) {
+        v8s h0v;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { const int j = j0 + c; h0v[c] = (short)max(max(S.g + (j - 1) * S.e, S.q + (j - 1) * S.c), -32768); }
+        char *const sl = ring_lane + RR * POA_RING_SLOT;
+        *(lds_v8s *)sl = h0v;
+        v4u ff; ff.x = ff.y = ff.z = ff.w = 0xffffffffu;
+        *(lds_v4u *)(sl + 1024) = ff;
+        if (lane == 0) { v2u c0; c0.x = 0; c0.y = 0; *(lds_v2u *)(lds_ring + RR * POA_RING_SLOT + 2048) = c0; }
+        if (lane < NW) sy->prog[lane] = 0;
+    }
+    __syncthreads();
+
+    v2s sqp[4];
+    {
+        int sq[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = j <= len ? seq[j - 1] : 0x7fff; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sqp[k] = pk2(sq[2 * k], sq[2 * k + 1]);
+    }
+    auto wait_vm = [] { __builtin_amdgcn_s_waitcnt(0x0F70); };
+    auto fetch = [&](int prow, PoaPredIn &x) {
+        const int64_t b = (int64_t)prow * Wp + POA_COL0;
+        x.h = *(const v8s *)(M.H + b + j0);
+        x.fo = *(const v4u *)(M.F + b + j0);
+        const v2u c0 = *(const v2u *)(M.H + b + POA_C0_F);
+        x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
+    };
+    auto ring_fetch = [&](int slot, PoaPredIn &x) {
+        char *const sl = ring_lane + slot * POA_RING_SLOT;
+        x.h = *(const lds_v8s *)sl;
+        x.fo = *(const lds_v4u *)(sl + 1024);
+        const v2u c0 = *(const lds_v2u *)(lds_ring + slot * POA_RING_SLOT + 2048);
+        x.f0 = (int)(short)(c0.x & 0xffffu); x.o0 = (int)(short)(c0.x >> 16); x.h0 = (int)(short)(c0.y >> 16);
+    };
+    // a predecessor row of row `computing` (complete: the caller has waited for it)
+    auto fetch_pred = [&](int prow_v, int computing, PoaPredIn &x) {
+        const int prow = __builtin_amdgcn_readfirstlane(prow_v);
+        if (prow == 0) ring_fetch(RR, x);
+        else if (computing - prow <= K) ring_fetch(prow & (RR - 1), x);
+        else {
+            fetch(prow, x);
+            wait_vm(); asm volatile("" : "+v"(x.h), "+v"(x.fo), "+v"(x.h0), "+v"(x.o0), "+v"(x.f0));
+        }
+    };
+    // the descriptors of 64 of this wavefront's rows in five registers: lane k = row qbase + k * NW
+    int q_p0 = 0, q_p1 = 0, q_p2 = 0, q_p3 = 0, q_info = 0;
+    auto refill = [&](int base) {
+        const int rr = min(base + lane * NW, n - 1);
+        q_p0 = d_pred[rr]; q_p1 = d_pred1[rr]; q_p2 = d_pred2[rr]; q_p3 = d_pred3[rr]; q_info = d_info[rr];
+        wait_vm();
+        asm volatile("" : "+v"(q_p0), "+v"(q_p1), "+v"(q_p2), "+v"(q_p3), "+v"(q_info));
+    };
+    auto pred_terms = [&](const PoaPredIn &x, const v2s (&sc)[4], v2s (&F)[4], v2s (&O)[4], v2s (&H)[4]) {
+        const v2s hp[4] = {pk_pair<0>(x.h), pk_pair<1>(x.h), pk_pair<2>(x.h), pk_pair<3>(x.h)};
+        const v2s dfp[4] = {pk_from(__builtin_amdgcn_perm(0u, x.fo.x, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.x, 0x0c030c02u)),
+                            pk_from(__builtin_amdgcn_perm(0u, x.fo.y, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.y, 0x0c030c02u))};
+        const v2s dqp[4] = {pk_from(__builtin_amdgcn_perm(0u, x.fo.z, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.z, 0x0c030c02u)),
+                            pk_from(__builtin_amdgcn_perm(0u, x.fo.w, 0x0c010c00u)), pk_from(__builtin_amdgcn_perm(0u, x.fo.w, 0x0c030c02u))};
+        unsigned left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk_bits(hp[3]), 0x138, 0xf, 0xf, false);
+        if (lane == 0) left = (unsigned)x.h0 << 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            F[k] = pk_add(hp[k], pk_max(G2, E2 - dfp[k]));
+            O[k] = pk_add(hp[k], pk_max(Q2, C2 - dqp[k]));
+            const unsigned prev = k ? pk_bits(hp[k - 1]) : left;
+            const v2s hs = pk_from(__builtin_amdgcn_alignbit(pk_bits(hp[k]), prev, 16));
+            H[k] = pk_add(hs, sc[k]);
+        }
+    };
+    lds_i32 *const prog_mine = (lds_i32 *)&sy->prog[lane & (NW - 1)];
+    // row x (1-based; x <= 0: nothing to wait for) is complete according to the snapshot pv (lane l = prog[l & (NW - 1)])
+    auto done = [&](int pv, int x) -> bool { return __builtin_amdgcn_readlane(pv, (x - 1) & (NW - 1)) >= x; };      // (progress words are never negative)
+
+    int best = POA_NEG_INF, best_i = -1;
+    int t = 0;                                                     // this wavefront's row counter
+    for (int r = wave; r < n; r += NW, ++t) {
+        const int i = r + 1;
+        if ((t & 63) == 0) refill(r);
+        const int l = t & 63;
+        const int sp0 = __builtin_amdgcn_readlane(q_p0, l), sp1 = __builtin_amdgcn_readlane(q_p1, l);
+        const int p2 = __builtin_amdgcn_readlane(q_p2, l), p3 = __builtin_amdgcn_readlane(q_p3, l);
+        const int info = __builtin_amdgcn_readlane(q_info, l);
+        const int letter = info & 0xff, ic = (info >> 8) & 0xff;
+        const bool sink = (info >> 16) & 1;
+        // ---- wait: every row up to i - BOUND, and this row's predecessors.  Lane l (mod NW) works out the row wavefront l must have
+        // completed - its latest row at or below i - BOUND, or a predecessor of this row that it owns - and compares it with that
+        // wavefront's progress word: one LDS read and one ballot per poll, no scalar branch per row waited for.
+        {
+            const int own = lane & (NW - 1);
+            auto need_of = [&](int x) { return ((x - 1) & (NW - 1)) == own ? x : 0; };
+            const int X = i - BOUND;
+            int need = X - ((X - 1 - own) & (NW - 1));
+            need = max(need, max(max(need_of(ic >= 1 ? sp0 : 0), need_of(ic >= 2 ? sp1 : 0)), max(need_of(ic >= 3 ? p2 : 0), need_of(ic >= 4 ? p3 : 0))));
+            while (__ballot(*(volatile lds_i32 *)prog_mine < need) != 0) __builtin_amdgcn_s_sleep(1);
+        }
+        PoaPredIn in0, in1;
+        fetch_pred(ic >= 1 ? sp0 : 0, i, in0);
+        if (ic >= 2) fetch_pred(sp1, i, in1);
+        const int64_t ro = (int64_t)i * Wp + POA_COL0;
+        v2s sc[4];
+        {
+            const v2s LL = pk2(letter, letter);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sc[k] = __builtin_elementwise_min(sqp[k] ^ LL, pk2(1, 1)) * NM + MM;
+        }
+        v2s Fa[4], Oa[4], Ha[4];
+        int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
+        if (ic > 0) { po = max(po, in0.o0); pf = max(pf, in0.f0); }
+        pred_terms(in0, sc, Fa, Oa, Ha);
+        if (ic > 1) {
+            po = max(po, in1.o0); pf = max(pf, in1.f0);
+            v2s F2[4], O2[4], H2[4];
+            pred_terms(in1, sc, F2, O2, H2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { Fa[k] = pk_max(Fa[k], F2[k]); Oa[k] = pk_max(Oa[k], O2[k]); Ha[k] = pk_max(Ha[k], H2[k]); }
+        }
+        if (ic > 2) {
+            int node = 0;
+            if (ic > 4) { node = g.r2n[r]; wait_vm(); asm volatile("" : "+v"(node)); }
+            for (int k = 2; k < ic; ++k) {
+                int prow;
+                if (k == 2) prow = p2;
+                else if (k == 3) prow = p3;
+                else {
+                    prow = g.n2r[PG_IN_SRC(g, node, k)] + 1; wait_vm(); asm volatile("" : "+v"(prow));
+                    prow = __builtin_amdgcn_readfirstlane(prow);
+                    for (;;) {                                     // (a fifth predecessor: rare; its row may be one of the last few)
+                        const int pv = *(volatile lds_i32 *)prog_mine;
+                        if (done(pv, prow)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                PoaPredIn x;
+                fetch_pred(prow, i, x);
+                po = max(po, x.o0); pf = max(pf, x.f0);
+                v2s F2[4], O2[4], H2[4];
+                pred_terms(x, sc, F2, O2, H2);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { Fa[q] = pk_max(Fa[q], F2[q]); Oa[q] = pk_max(Oa[q], O2[q]); Ha[q] = pk_max(Ha[q], H2[q]); }
+            }
+        }
+        const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
+        const v2s cEQ = pk2(H0 + S.g, H0 + S.q);
+        v2s Aa[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Aa[k] = mine ? pk_max(Ha[k], pk_max(Fa[k], Oa[k])) : NEG2;
+        v2s bEQ = NEG2;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const v2s a = (c & 1) ? pk_hi(Aa[c >> 1]) : pk_lo(Aa[c >> 1]);
+            const v2s h = pk_max(a, pk_max(bEQ, pk_swap(bEQ)));
+            bEQ = pk_max(pk_add(h, GQ), pk_add(bEQ, EC));
+        }
+        v2s x = bEQ;
+        x = pk_max(x, pk_apply(T0, pk_dpp<0x111>(NEG2, x)));
+        x = pk_max(x, pk_apply(T1, pk_dpp<0x112>(NEG2, x)));
+        x = pk_max(x, pk_apply(T2, pk_dpp<0x114>(NEG2, x)));
+        x = pk_max(x, pk_apply(T3, pk_dpp<0x118>(NEG2, x)));
+        x = pk_max(x, pk_apply(P16, pk_dpp<0x142, 0xa>(NEG2, x)));
+        x = pk_max(x, pk_apply(P32, pk_dpp<0x143, 0xc>(NEG2, x)));
+        v2s vEQ = pk_dpp<0x138>(NEG2, x);
+        if (lane == 0) vEQ = NEG2;
+        vEQ = pk_max(vEQ, pk_apply(PC, cEQ));
+        v2s hcol[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const v2s a = (c & 1) ? pk_hi(Aa[c >> 1]) : pk_lo(Aa[c >> 1]);
+            const v2s h = pk_max(a, pk_max(vEQ, pk_swap(vEQ)));
+            hcol[c] = h;
+            vEQ = pk_max(pk_add(h, GQ), pk_add(vEQ, EC));
+        }
+        v2s Hn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Hn[k] = __builtin_shufflevector(hcol[2 * k], hcol[2 * k + 1], 0, 3);
+        const v8s hrow = pk_join(Hn[0], Hn[1], Hn[2], Hn[3]);
+        const v2s d0 = Hn[0] - Fa[0], d1 = Hn[1] - Fa[1], d2 = Hn[2] - Fa[2], d3 = Hn[3] - Fa[3];
+        const v2s q0 = Hn[0] - Oa[0], q1 = Hn[1] - Oa[1], q2 = Hn[2] - Oa[2], q3 = Hn[3] - Oa[3];
+        v4u forow;
+        forow.x = __builtin_amdgcn_perm(pk_bits(d1), pk_bits(d0), 0x06040200u);
+        forow.y = __builtin_amdgcn_perm(pk_bits(d3), pk_bits(d2), 0x06040200u);
+        forow.z = __builtin_amdgcn_perm(pk_bits(q1), pk_bits(q0), 0x06040200u);
+        forow.w = __builtin_amdgcn_perm(pk_bits(q3), pk_bits(q2), 0x06040200u);
+        v2u c0;
+        c0.x = ((unsigned)F0 & 0xffffu) | ((unsigned)O0 << 16); c0.y = (unsigned)H0 << 16;
+        // ring first (what the next rows are waiting for), then the three stores of the row and a wait for everything issued before
+        // them - the previous row's stores: `complete` then also means "my row before this one is acknowledged"
+        {
+            char *const sl = ring_lane + (i & (RR - 1)) * POA_RING_SLOT;
+            *(lds_v8s *)sl = hrow;
+            *(lds_v4u *)(sl + 1024) = forow;
+            if (lane == 0) *(lds_v2u *)(lds_ring + (i & (RR - 1)) * POA_RING_SLOT + 2048) = c0;
+        }
+        {
+            poa_cell_t *const pH = M.H + ro + j0, *const pF = M.F + ro + j0, *const pC = M.H + ro + POA_C0_F;     // (column 0: every lane stores the same 8 bytes)
+            asm volatile("global_store_dwordx4 %0, %3, off\n\t"
+                         "global_store_dwordx4 %1, %4, off\n\t"
+                         "global_store_dwordx2 %2, %5, off\n\t"
+                         "s_waitcnt vmcnt(3) lgkmcnt(0)"
+                         :: "v"(pH), "v"(pF), "v"(pC), "v"(hrow), "v"(forow), "v"(c0) : "memory");
+        }
+        if (lane == 0) *(volatile lds_i32 *)&sy->prog[wave] = i;
+        if (sink) {
+            const int cl = (len - 1) % CPL;
+            v2s hv = hcol[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) hv = c == cl ? hcol[c] : hv;
+            const int hlast = (int)(short)__builtin_amdgcn_readlane((int)pk_bits(hv), (len - 1) / CPL);
+            if (best < hlast) { best = hlast; best_i = i; }
+        }
+    }
+    if (lane == 0) { sy->best[wave] = best; sy->best_i[wave] = best_i; }
+    // (the row stores were issued from an asm block: the compiler's wait-count bookkeeping has not seen them, so the barrier's own
+    // release fence may have been relaxed - the traceback reads what the other wavefronts stored)
+    wait_vm();
+    __syncthreads();
+    // NW: the best sink at the last column; ties go to the first row in topological order (the serial loop's strict `<`)
+    int b = POA_NEG_INF, bi = -1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int v = *(volatile lds_i32 *)&sy->best[w], vi = *(volatile lds_i32 *)&sy->best_i[w];
+        if (vi != -1 && (bi == -1 || v > b || (v == b && vi < bi))) { b = v; bi = vi; }
+    }
+    max_i = bi; max_j = bi == -1 ? -1 : len;
 }
 
 #ifdef GBX_POA_PHASE_STATS
@@ -1674,6 +1976,98 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
 }
 
 
+// ---- the team kernel (round 5): one window per WORKGROUP of NW wavefronts ---------------------------------------------------------
+// poa_kernel's window loop with the DP of a sequence run by all NW wavefronts (poa_dp_team) and everything else - traceback,
+// add_alignment with the sort, consensus - by wavefront 0 while the others wait at a barrier (a waiting wavefront takes no issue
+// slots).  For jobs with fewer windows than the chip has SIMDs (a shard of BASELINE config 4: 750 windows on 1 024 SIMDs) and for the
+// windows of the long launch, which are few by definition: there the job is as long as its slowest window, and a window on one
+// wavefront is a serial program.  LONG: a sequence over 512 bases runs poa_dp<8> / poa_traceback on wavefront 0 (column blocks,
+// five-plane slots).  TEAM_RR / TEAM_K: rows of the shared LDS ring and how far back a predecessor is read from it.
+constexpr int POA_TEAM_NW = 4, POA_TEAM_RR = 16, POA_TEAM_K = 10;
+constexpr int POA_TEAM_RING_BYTES = (POA_TEAM_RR + 1) * POA_RING_SLOT;
+
+template <bool LONG, int WAVES>
+__global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaArgs A, SlotLayout L, int sync_off)
+{
+    constexpr int NW = POA_TEAM_NW;
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    PoaGraph g;
+    poa_bind_graph(g, slot, L, A);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    PoaTopoLds T;
+    poa_bind_lds(T, lds_raw, A);
+    lds_team *const sy = (lds_team *)((lds_u8 *)lds_raw + sync_off);
+    poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (LONG && threadIdx.x == 0) atomicAdd(A.cells + POA_LONG_STARTED, 1ull);      // poa_gate_kernel waits for these
+
+    unsigned long long cells = 0;
+    const unsigned nwork = (unsigned)A.cells[A.cnt_idx];
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const unsigned long long wq = atomicAdd(A.cells + A.cur_idx, 1ull);
+            *(volatile lds_i32 *)&sy->widx = (int)(wq < 0x7fffffffull ? wq : 0x7fffffffull);
+        }
+        __syncthreads();
+        const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->widx);
+        if (q32 >= nwork) break;
+        const int64_t w = (int64_t)A.wlist[q32];
+        if (wave == 0) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; }
+        int n_nodes = 0, err = 0;                                  // the team's view of the graph (wavefront 0 owns the PoaGraph registers)
+        const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+        for (int64_t s = s0; s < s1; ++s) {
+            const uint8_t *seq = A.arena + A.seq_off[s];
+            const int len = A.seq_len[s];
+            if (wave == 0) g.n_path = 0;
+            bool ran_dp = false;
+            if (n_nodes != 0 && len != 0 && err == 0) {
+                ran_dp = true;
+                const bool piped = !LONG || len <= POA_PIPE_MAXLEN;
+                const int wp = piped ? POA_PIPE_STRIDE : poa_row_stride(len);
+                const int64_t plane = (int64_t)(n_nodes + 1) * wp;
+                PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
+                int mi = -1, mj = -1;
+                if (wave == 0) cells += (unsigned long long)n_nodes * (unsigned long long)len;
+                __builtin_amdgcn_s_setprio(0);
+                if (piped) poa_dp_team<NW, POA_TEAM_RR, POA_TEAM_K>(g, M, A, seq, len, n_nodes, lds_raw, sy, wave, mi, mj);
+                else if (wave == 0) poa_dp<8>(g, M, A, seq, len, mi, mj);
+                if (wave == 0) {
+                    __builtin_amdgcn_s_setprio(3);
+                    if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+                    else poa_traceback(g, M, A.S, seq, mi, mj);
+                }
+            }
+            if (wave == 0) {
+                if (T.use && ran_dp) {
+                    // the DP's ring has used the sort's LDS: state bytes back from the slot, previous ranks = n2r
+                    const uint8_t *save = (const uint8_t *)(slot + L.st8save);
+                    for (int i = lane; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                if (g.err == 0) poa_add_alignment_wave<true>(g, seq, len, T);
+                if (T.use && s + 1 < s1) {
+                    uint8_t *save = (uint8_t *)(slot + L.st8save);
+                    for (int i = lane; i < g.n_nodes; i += 64) save[i] = T.st8[i];
+                }
+                if (lane == 0) { *(volatile lds_i32 *)&sy->n_nodes = g.n_nodes; *(volatile lds_i32 *)&sy->err = g.err; }
+            }
+            __syncthreads();                                       // the graph as wavefront 0 left it, for everybody
+            n_nodes = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->n_nodes);
+            err = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->err);
+        }
+        if (wave == 0) {
+            int clen = 0;
+            if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+            if (lane == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+        }
+        __syncthreads();                                           // (nobody is still reading this window's work item when the next one is written)
+    }
+    if (threadIdx.x == 0) atomicAdd(A.cells, cells);
+}
+
+
 // ---- the lock-step form (round 4): every window resident, one launch per phase and sequence index ----------------
 // poa_kernel keeps a window in one wavefront from its first sequence to its consensus: the DP (throughput work: packed
 // arithmetic and row traffic), the traceback (one dependent row fetch per step) and add_alignment / the sort (chains of
@@ -1852,6 +2246,17 @@ bool poa_use_lockstep(const gbx_poa_plan *plan, int64_t n_main)
 }
 }  // namespace
 
+// windows of a main list up to which the team kernel takes it: what the chip keeps resident as team workgroups (three per CU at
+// 168 VGPRs; beyond that the workgroups queue and one wavefront per window, twelve per CU, is the better use of the SIMDs)
+static int64_t poa_team_max_windows()
+{
+    if (const char *e = getenv("GBX_POA_TEAM_MAX")) return atoll(e);          // tuning aid
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    else (void)hipGetLastError();
+    return (int64_t)cus * GBX_POA_TEAM_WAVES;
+}
+
 // workspace = main slots | counter block | main work list | long-window list | long slots
 size_t poa_slot_bytes(int ncap, int deg, int lmax, bool long_slot) { return (size_t)make_layout(ncap, deg, lmax, long_slot).total; }
 namespace {
@@ -1944,7 +2349,24 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         side_lock = std::unique_lock<std::mutex>(ss->mu);
         if ((rc = ss->fork(s))) return rc;
     }
-    if (has_long) {
+    // the team kernel (a window per workgroup of four wavefronts): for the windows of the long launch, and for a main list with
+    // fewer windows than the chip keeps team workgroups resident (a job as long as its slowest window: see poa_team_kernel)
+    const bool team_on = !(getenv("GBX_POA_TEAM") && atoi(getenv("GBX_POA_TEAM")) == 0);
+    const size_t team_ring = std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_TEAM_RING_BYTES);
+    const int team_sync_off = (int)((team_ring + 15) & ~(size_t)15);
+    const size_t team_lds = (size_t)team_sync_off + sizeof(PoaTeamSync);
+    // (the team form of the long launch takes a whole CU per window - 512 VGPRs per wavefront - which a job of many windows would
+    // rather give to its main launch: there the long windows, a wavefront each, end well before it anyway: 165 against 215 ms on
+    // 'large'; measured with the team form: 81 ms for them, 226-231 for the job)
+    const bool team_long = team_on && n_windows - plan->n_long_windows <= 4 * poa_team_max_windows();
+    if (has_long && team_long) {
+        const SlotLayout LL = make_layout(ncap, deg, lmax, true);
+        PoaArgs B = A;
+        B.work = wb + ws.lslots; B.slot_bytes = LL.total; B.wlist = d_llist; B.cnt_idx = POA_CNT_LONG; B.cur_idx = POA_CUR_LONG;
+        hipStream_t sl = ss ? ss->side[0] : s;
+        Stage st("poa_window_long", sl);
+        hipLaunchKernelGGL((poa_team_kernel<true, GBX_POA_TEAM_LONG_WAVES>), dim3(plan->long_slots), dim3(64 * POA_TEAM_NW), team_lds, sl, B, LL, team_sync_off);
+    } else if (has_long) {
         const SlotLayout LL = make_layout(ncap, deg, lmax, true);
         PoaArgs B = A;
         B.work = wb + ws.lslots; B.slot_bytes = LL.total; B.wlist = d_llist; B.cnt_idx = POA_CNT_LONG; B.cur_idx = POA_CUR_LONG;
@@ -1978,6 +2400,18 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
             if (tb_with_dp) hipLaunchKernelGGL((poa_phase_kernel<false, false, true, GBX_POA_SERIAL_WAVES>), grid, tb, lds, s, A, L, sidx);
             else hipLaunchKernelGGL((poa_phase_kernel<false, true, true, GBX_POA_SERIAL_WAVES>), grid, tb, lds, s, A, L, sidx);
         }
+    } else if (has_main && team_on && n_main <= poa_team_max_windows()) {
+        const SlotLayout L = make_layout(ncap, deg, lmax, false);
+        A.slot_bytes = L.total;
+        const int grid = (int)std::min<int64_t>(n_main, plan->n_slots);
+        if (has_long && !(getenv("GBX_POA_GATE") && atoi(getenv("GBX_POA_GATE")) == 0)) {
+            int cus = 256, dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            hipLaunchKernelGGL(poa_gate_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long *)(A.cells + POA_LONG_STARTED),
+                               (unsigned)std::min<int64_t>(plan->long_slots, cus));
+        }
+        Stage st("poa_window_team", s);
+        hipLaunchKernelGGL((poa_team_kernel<false, GBX_POA_TEAM_WAVES>), dim3(grid), dim3(64 * POA_TEAM_NW), team_lds, s, A, L, team_sync_off);
     } else if (has_main) {
         const SlotLayout L = make_layout(ncap, deg, lmax, false);
         A.slot_bytes = L.total;
