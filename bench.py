@@ -49,6 +49,16 @@ PHMM_CLASS.update({"phmm_f32_rpl4": (249, 256), "phmm_f32_rpl6": (257, 384), "ph
 
 
 # ------------------------------------------------------------------------------------------ workloads
+def _cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max), or None: os.cpu_count() counts the host's hardware
+    threads, which a quota does not change - a baseline on "256 cores" of a box with a 16-core quota ran on sixteen."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def _host_timed(fn, reps=4):
     ms = []
     res = None
@@ -155,6 +165,46 @@ class BswWork:
         return {"first_call_ms": ms[0], "best_ms": min(ms), "value": self.batch.nominal_cells / (min(ms) * 1e-3) / 1e9,
                 "unit": "GCUPS", "what": "gbx_bsw_extend_host on the rank-0 shard: H2D + kernels + D2H from pageable memory",
                 "same_as_device_entry": bool(np.array_equal(np.asarray(got), out))}
+
+    def e2e(self):
+        """SURVEY 8d leg (iii): the GPU driver (reference CLI, genomicsbench_amd/bin/bsw) on the same pairs as the reference's input
+        file, `-t <host cores>`: conversion of the text + H2D + kernels + D2H, once with the parse and the device calls
+        overlapped in four slices (--overlap 4) and once one after the other.  A process of its own (its own HIP context)."""
+        import subprocess, tempfile
+        from genomicsbench_amd.datagen import write_bsw_pairs_fast
+        exe = os.path.join(ROOT, "genomicsbench_amd", "bin", "bsw")
+        if not os.path.exists(exe):
+            return {"error": "genomicsbench_amd/bin/bsw is not built"}
+        cores = os.cpu_count() or 1
+        d = tempfile.mkdtemp(prefix="gbx_bsw_e2e_")
+        path = os.path.join(d, "pairs.txt")
+        try:
+            size = write_bsw_pairs_fast(path, self.batch)
+            recs = {}
+            for name, extra in (("overlapped", ["--overlap", "4"]), ("serial", [])):
+                best = None
+                for _ in range(2):
+                    r = subprocess.run([exe, "-pairs", path, "-t", str(min(cores, 64)), "-b", str(self.batch.n)] + extra, capture_output=True, text=True, timeout=300)
+                    if r.returncode != 0:
+                        return {"error": (r.stderr or r.stdout)[-200:]}
+                    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                    if best is None or j["e2e_seconds"] < best["e2e_seconds"]:
+                        best = j
+                recs[name] = best
+        finally:
+            try:
+                os.remove(path)
+                os.rmdir(d)
+            except OSError:
+                pass
+        o, q = recs["overlapped"], recs["serial"]
+        # (measured, profiles/r05k_bsw_e2e.txt: on the pool's boxes - 16 cores of CPU quota - the overlapped flow is the slower
+        # one: every slice's call pays for fresh device buffers and shares the cores with the conversion; both are reported)
+        return {"e2e_ms": min(o["e2e_seconds"], q["e2e_seconds"]) * 1e3, "e2e_ms_overlapped": o["e2e_seconds"] * 1e3,
+                "e2e_ms_parse_then_call": q["e2e_seconds"] * 1e3, "ingest_ms": q["ingest_seconds"] * 1e3,
+                "call_ms_in_driver": q["seconds"] * 1e3, "ingest_threads": o["ingest_threads"], "input_file_mb": round(size / 1e6, 1),
+                "what": "genomicsbench_amd/bin/bsw -pairs <file> -t %d: text conversion + H2D + kernels + D2H, file already in memory"
+                        % o["ingest_threads"]}
 
     def cpu_baseline(self, max_units):
         """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
@@ -991,9 +1041,17 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         # the host-buffer entry first, on quiet host cores (the CPU baseline runs OpenMP teams on all of them)
         if hasattr(work, "host_entry"):
             line["host_entry"] = work.host_entry()
+            # SURVEY 8d's three timing legs, flat: (i) device-resident = `value`, (ii) H2D + kernels + D2H through the host entry,
+            # (iii) end to end including the parse (bsw: the driver on the reference's input format)
+            line["host_entry_ms"] = line["host_entry"]["best_ms"]
+            line["host_entry_" + ("gcups" if work.unit == "GCUPS" else "value")] = line["host_entry"]["value"]
+        if hasattr(work, "e2e"):
+            line["e2e"] = work.e2e()
+            line["e2e_ms"] = line["e2e"].get("e2e_ms")
         if hasattr(work, "realistic"):
             line["realistic"] = work.realistic(stream)
         line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
+        line["cpu_baseline"]["cgroup_cpu_quota_cores"] = _cpu_quota()      # `cores` = threads used; this is what they could run on
     return line
 
 

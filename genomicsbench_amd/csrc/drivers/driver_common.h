@@ -44,8 +44,23 @@ static inline bool slurp(const char *path, std::vector<char> &buf)
 // are stitched by a prefix sum, and the records are then parsed independently.
 #include <omp.h>
 
-// start and length of every '\n'-terminated line of [p, p+n)
-static inline void split_lines(const char *p, size_t n, int threads, std::vector<const char *> &line, std::vector<int> &llen)
+// An array whose pages are first touched by whoever fills it (std::vector's resize() zero-fills on the calling thread: for the
+// 0.4 GB of arrays of a 2 M-pair bsw job that was most of the ingest).  Trivial element types only.
+template <class T> struct RawVec {
+    T *p = nullptr; size_t n = 0;
+    RawVec() {}
+    explicit RawVec(size_t k) { resize(k); }
+    RawVec(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    void resize(size_t k) { free(p); p = k ? (T *)malloc(k * sizeof(T)) : nullptr; n = k; if (k && !p) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); } }
+    T *data() { return p; } const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t k) { return p[k]; } const T &operator[](size_t k) const { return p[k]; }
+};
+
+// start and length of every '\n'-terminated line of [p, p+n) (LV / IV: std::vector or RawVec of const char * / int)
+template <class LV, class IV>
+static inline void split_lines(const char *p, size_t n, int threads, LV &line, IV &llen)
 {
     if (threads < 1) threads = 1;
     std::vector<std::vector<size_t>> nl((size_t)threads);
@@ -54,6 +69,7 @@ static inline void split_lines(const char *p, size_t n, int threads, std::vector
         const int t = omp_get_thread_num(), T = omp_get_num_threads();
         const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
         std::vector<size_t> &v = nl[(size_t)t];
+        v.reserve((hi - lo) / 24 + 64);                       // (a guess that spares most of the regrowth; any line length works)
         for (const char *q = p + lo, *e = p + hi; q < e;) {
             const char *f = (const char *)memchr(q, '\n', (size_t)(e - q));
             if (!f) break;

@@ -155,7 +155,16 @@ struct HostLane {
         Lane *n = new Lane();
         n->dev = dev;
         hipError_t e = hipStreamCreateWithFlags(&n->compute, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&n->copy, hipStreamNonBlocking);
+        // the copy stream at high priority: the runtime gives such a stream a hardware queue of its own class, so that the marker
+        // packets behind its DMAs (the events the upload workers wait on before they reuse a slab) are not queued behind a
+        // kernel stream's long launches (round 5: uploads of chunk k+1 stood still while chunk k's kernels ran)
+        if (e == hipSuccess) {
+            int least = 0, greatest = 0;
+            const bool hi = !(getenv("GBX_COPY_PRIO") && atoi(getenv("GBX_COPY_PRIO")) == 0);
+            if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+                e = hipStreamCreateWithPriority(&n->copy, hipStreamNonBlocking, greatest);
+            else { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&n->copy, hipStreamNonBlocking); }
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[0], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[1], hipEventDisableTiming);

@@ -2003,6 +2003,9 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
     if (LONG && threadIdx.x == 0) atomicAdd(A.cells + POA_LONG_STARTED, 1ull);      // poa_gate_kernel waits for these
 
     unsigned long long cells = 0;
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long t_dp = 0, t_tb = 0, t_add = 0, t_cons = 0, n_rows = 0, n_steps = 0;
+#endif
     const unsigned nwork = (unsigned)A.cells[A.cnt_idx];
     for (;;) {
         if (threadIdx.x == 0) {
@@ -2029,16 +2032,23 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
                 PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
                 int mi = -1, mj = -1;
                 if (wave == 0) cells += (unsigned long long)n_nodes * (unsigned long long)len;
+                PH_T0
                 __builtin_amdgcn_s_setprio(0);
                 if (piped) poa_dp_team<NW, POA_TEAM_RR, POA_TEAM_K>(g, M, A, seq, len, n_nodes, lds_raw, sy, wave, mi, mj);
                 else if (wave == 0) poa_dp<8>(g, M, A, seq, len, mi, mj);
+                PH_ACC(t_dp)
                 if (wave == 0) {
                     __builtin_amdgcn_s_setprio(3);
                     if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                     else poa_traceback(g, M, A.S, seq, mi, mj);
+                    PH_ACC(t_tb)
+#ifdef GBX_POA_PHASE_STATS
+                    n_rows += (unsigned long long)n_nodes; n_steps += (unsigned long long)g.n_path;
+#endif
                 }
             }
             if (wave == 0) {
+                PH_T0
                 if (T.use && ran_dp) {
                     // the DP's ring has used the sort's LDS: state bytes back from the slot, previous ranks = n2r
                     const uint8_t *save = (const uint8_t *)(slot + L.st8save);
@@ -2052,19 +2062,26 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
                     for (int i = lane; i < g.n_nodes; i += 64) save[i] = T.st8[i];
                 }
                 if (lane == 0) { *(volatile lds_i32 *)&sy->n_nodes = g.n_nodes; *(volatile lds_i32 *)&sy->err = g.err; }
+                PH_ACC(t_add)
             }
             __syncthreads();                                       // the graph as wavefront 0 left it, for everybody
             n_nodes = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->n_nodes);
             err = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->err);
         }
         if (wave == 0) {
+            PH_T0
             int clen = 0;
             if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
             if (lane == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+            PH_ACC(t_cons)
         }
         __syncthreads();                                           // (nobody is still reading this window's work item when the next one is written)
     }
     if (threadIdx.x == 0) atomicAdd(A.cells, cells);
+#ifdef GBX_POA_PHASE_STATS
+    // (wavefront 0's clocks: the DP's are the team's wall clock for it, the other phases are its own)
+    if (threadIdx.x == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 2, t_tb); atomicAdd(A.cells + 3, t_add); atomicAdd(A.cells + 4, t_cons); atomicAdd(A.cells + 12, n_rows); atomicAdd(A.cells + 13, n_steps); }
+#endif
 }
 
 
@@ -2254,7 +2271,7 @@ static int64_t poa_team_max_windows()
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     else (void)hipGetLastError();
-    return (int64_t)cus * GBX_POA_TEAM_WAVES;
+    return (int64_t)cus * (GBX_POA_TEAM_WAVES + 1);          // (measured: 1 024 windows 85 against 91 ms, 1 500 windows 120 against 96)
 }
 
 // workspace = main slots | counter block | main work list | long-window list | long slots

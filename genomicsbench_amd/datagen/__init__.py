@@ -71,6 +71,16 @@ def gen_bsw(n_pairs, seed, first=0):
     return BswBatch(ref, qer, idr, idq, len1, len2, h0)
 
 
+def write_bsw_pairs_fast(path, b):
+    """The reference's bsw input file for a BswBatch (same bytes as io.write_bsw_pairs, written by the C library)."""
+    L = _L()
+    L.gbx_write_bsw_pairs.restype = C.c_int64
+    got = L.gbx_write_bsw_pairs(str(path).encode(), C.c_int64(b.n), _p(b.ref), _p(b.idr), _p(b.len1), _p(b.qer), _p(b.idq), _p(b.len2), _p(b.h0))
+    if got < 0:
+        raise OSError("cannot write %s" % path)
+    return got
+
+
 def gen_chain(n_calls, seed, first=0, n_override=None, realistic=False):
     """chain 'large' = (10_000, seed 2001).  Returns (anchor_off, ax, ay, hdr).  realistic=True: the same call sizes with
     minimap2's structure inside a call (both strands, six reference ids in the upper x word, repeat copies, isolated

@@ -114,6 +114,7 @@ static int cmp_anchor(const void *a, const void *b)
 }
 
 #include <stdlib.h>
+#include <stdio.h>
 void gbx_gen_chain_fill(uint64_t seed, int64_t call, int64_t n, uint64_t *ax, uint64_t *ay)
 {
     rng_t r;
@@ -521,4 +522,31 @@ void gbx_gen_fmi_reads(uint64_t seed, int64_t first, int64_t n_reads, const uint
                 q[b] = x > 3 ? x : (uint8_t)(3 - x);
             }
     }
+}
+
+/* ------------------------------------------------------ input files (bench)
+ * The reference's bsw input format (main_banded.cpp:131-141: seed score, target digits, query digits, one line each),
+ * written from the generated arrays with one buffered writer: bench.py times the driver end to end on this file.
+ * Returns bytes written, or -1.
+ */
+int64_t gbx_write_bsw_pairs(const char *path, int64_t n, const uint8_t *ref, const int64_t *idr, const int32_t *len1,
+                            const uint8_t *qer, const int64_t *idq, const int32_t *len2, const int32_t *h0)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    static char iobuf[1 << 22];
+    setvbuf(f, iobuf, _IOFBF, sizeof(iobuf));
+    char line[1 << 16];
+    int64_t total = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        int o = snprintf(line, 32, "%d\n", h0[k]);
+        if (len1[k] + len2[k] + o + 4 > (int)sizeof(line)) { fclose(f); return -1; }
+        for (int l = 0; l < len1[k]; ++l) line[o++] = (char)(ref[idr[k] + l] + 48);
+        line[o++] = '\n';
+        for (int l = 0; l < len2[k]; ++l) line[o++] = (char)(qer[idq[k] + l] + 48);
+        line[o++] = '\n';
+        if (fwrite(line, 1, (size_t)o, f) != (size_t)o) { fclose(f); return -1; }
+        total += o;
+    }
+    return fclose(f) == 0 ? total : -1;
 }

@@ -2,7 +2,7 @@
 `rocprofv3 --kernel-trace --memory-copy-trace` so that every DMA and kernel of the call has a start and an end.
 usage: python3 scripts/dbg_bsw_host_one.py [calls]"""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from genomicsbench_amd import _native as N
 from genomicsbench_amd.bsw import extend_host, make_params

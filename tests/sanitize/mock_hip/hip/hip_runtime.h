@@ -76,6 +76,8 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
     mock_streams().push_back(*s);
     return hipSuccess;
 }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new MockEvent(); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t s)

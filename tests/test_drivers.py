@@ -153,6 +153,21 @@ def test_bsw_driver_end_to_end(data):
 
 
 @pytest.mark.gpu
+def test_bsw_driver_overlapped_ingest(data):
+    """--overlap S: the pairs converted in S slices, slice k through the host entry (re-based arena stretch, a caller thread of
+    its own) while slice k+1 is converted: the same results as one call, and the e2e record."""
+    d, b = data[0], data[1]
+    want = O.bsw_oracle(make_params(), gio.read_bsw_pairs(str(d / "pairs.txt")), 4)
+    for slices, threads in ((3, 1), (4, 4), (7, 2)):
+        out = d / ("bsw_ov%d.out" % slices)
+        r = run([os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", str(threads), "-b", "512", "--overlap", str(slices), "--dump", str(out)])
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.loadtxt(str(out), dtype=np.int32), want)
+        rec = json.loads(r.stdout.strip().split("\n")[-1])
+        assert rec["pairs"] == b.n and rec["overlap_slices"] == slices and rec["e2e_seconds"] >= rec["ingest_seconds"] > 0
+
+
+@pytest.mark.gpu
 def test_chain_driver_end_to_end(data):
     d, c = data[0], data[2]
     r = run([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", str(d / "chain.out"), "--print"])
