@@ -302,6 +302,24 @@ class ChainWork:
         jobs, longest = self.d.job_stats(stream)
         self.extra["jobs_this_gpu"], self.extra["longest_job_anchors"] = jobs, longest
 
+    def longest_job(self, stream, steps=3):
+        """The floor of the job: its longest call run ALONE (one wavefront: the recurrence over a call's anchors is serial).
+        A chain job cannot end before this, on one GPU or on eight."""
+        import torch
+        from genomicsbench_amd.chain import DeviceChainBatch
+        off, ax, ay, hdr = self.case
+        c = int(np.argmax(np.diff(off)))
+        a, b = int(off[c]), int(off[c + 1])
+        d = DeviceChainBatch(np.array([0, b - a], dtype=np.int64), ax[a:b], ay[a:b], hdr[c:c + 1], self.d.off.device)
+        d.run(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            d.run(stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        return {"call": c, "anchors": b - a, "ms_alone": ms, "us_per_anchor": ms * 1e3 / max(b - a, 1)}
+
     def realistic(self, stream, steps=3):
         """The same call sizes with minimap2's structure inside a call (both strands, six reference ids in the upper x
         word, repeat copies, isolated hits: datagen.c gbx_gen_chain_fill_real) - the SURVEY 8d workload has one strand and
@@ -841,8 +859,9 @@ _KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": 
 
 
 def _hip_sha16(kind):
-    import hashlib
-    return hashlib.sha256(open(os.path.join(ROOT, "genomicsbench_amd", "csrc", _KIND_SOURCE[kind]), "rb").read()).hexdigest()[:16]
+    """hash over every file of the kind's kernel translation unit (<kind>_kernels.hip + the headers it includes)"""
+    from genomicsbench_amd.srchash import tu_sha16
+    return tu_sha16(kind)
 
 
 def _committed(kind, what, kernel_name, default_size):
@@ -856,7 +875,7 @@ def _committed(kind, what, kernel_name, default_size):
         return None, None
     table = json.load(open(path))
     if table.get("hip_sha16", {}).get(kind) != _hip_sha16(kind):
-        return None, rel + " (stale: %s changed since the counters were collected)" % _KIND_SOURCE[kind]
+        return None, rel + " (stale: %s or a header it includes changed since the counters were collected)" % _KIND_SOURCE[kind]
     return table.get(key, {}).get(kernel_name), rel
 
 
@@ -868,7 +887,7 @@ def _valu_roof(kind, kernel_name):
     if not os.path.exists(path):
         return None, None
     t = json.load(open(path))
-    if t.get("csrc_sha16", {}).get(_KIND_SOURCE[kind]) != _hip_sha16(kind):
+    if t.get("tu_sha16", {}).get(kind) != _hip_sha16(kind):
         return None, None
     rows = [v for v in t["kernels"].values() if v["stage"] == kernel_name or (kernel_name.startswith("bsw_lane_c") and v["stage"] == "bsw_lane_compact")
             or (kernel_name.startswith("bsw_lane_w") and v["stage"] == "bsw_lane_wide")]
@@ -1050,6 +1069,9 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
             line["e2e_ms"] = line["e2e"].get("e2e_ms")
         if hasattr(work, "realistic"):
             line["realistic"] = work.realistic(stream)
+        if hasattr(work, "longest_job"):
+            line["longest_job"] = work.longest_job(stream)
+            line["longest_job_ms"] = line["longest_job"]["ms_alone"]
         line["cpu_baseline"] = work.cpu_baseline(args.cpu_units)
         line["cpu_baseline"]["cgroup_cpu_quota_cores"] = _cpu_quota()      # `cores` = threads used; this is what they could run on
     return line

@@ -412,10 +412,13 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
         auto load_block = [&](int kb) -> v4u { return *(const v4u *)(trace + (int64_t)max(kb, 0) * (16 * ROW) + lane * 16); };
         unsigned codes = 0;
         int cnt = 0;
+        GBX_GUARD(gd_tb, (long long)n_bands + 8);              // a step leaves a band or two: the walk is at most n_bands long
         auto walk_group = [&](const unsigned comp, const int grp) __attribute__((always_inline)) {   // bands 4 grp .. 4 grp + 3
             while ((ck | ce) >= 0 && (bi >> 2) == grp) {
                 const unsigned byte = (unsigned)__builtin_amdgcn_readlane((int)comp, off >> 1) >> ((bi & 3) << 3);
                 const unsigned from = (byte >> ((off & 1) << 1)) & 3u;      // 0 diagonal, 1 up, 2 left (:455-470)
+                // (3 is no move: the band loop never writes it; a walk that met one would stand still for ever)
+                if (from == 3u || GBX_GUARD_TRIP(gd_tb, GBX_GK_ABEA, 1, r)) { ck = -1; break; }
                 codes |= from << (cnt << 1);
                 cnt += 1;
                 last_ck = ck;
@@ -596,6 +599,7 @@ int abea_launch(int64_t n_reads, const int64_t *d_seq_off, const int32_t *d_seq_
         hipLaunchKernelGGL(abea_kernel, dim3(grid), dim3(64), 0, s, A);
     }
     GBX_HIP(hipGetLastError());
+    GBX_GUARD_CHECK("abea");
     return GBX_OK;
 }
 

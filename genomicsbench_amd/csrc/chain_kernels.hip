@@ -400,8 +400,9 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                         st = __builtin_amdgcn_readlane(stv, k);
                     } else {
                         // advance st (:56): first st with ri <= x[st] + max_dist_x, scanning the cached block
+                        GBX_GUARD(gd_st, n / 64 + 4);                              // (st moves up a block of 64 per pass)
                         for (;;) {
-                            if (st >= i) break;
+                            if (st >= i || GBX_GUARD_TRIP(gd_st, GBX_GK_CHAIN, 1, job)) break;
                             if (st >= sb + 64 || st < sb) { sb = st; xs = settle(x[min(sb + lane, n - 1)]); }
                             const int idx = sb + lane;
                             const bool far = idx >= st && idx < i && ri > xs + mdx;
@@ -813,6 +814,7 @@ int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                            d_score, d_parent, d_target, d_peak, W);
     }
     GBX_HIP(hipGetLastError());
+    GBX_GUARD_CHECK("chain");
     return GBX_OK;
 }
 

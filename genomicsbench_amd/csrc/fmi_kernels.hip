@@ -143,6 +143,8 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
     // first record the previous position kept - is still in registers: (k, l, s, n), which the forward sweep no longer needs
     IV nxt = 0;
     int idx2 = 0, n1 = 0;
+    GBX_GUARD(gd_trips, 0);                  // extensions the quad's current read may still take (set when the read is fetched)
+    GBX_GUARD(gd_disp, 1 << 22);             // passes of the dispatch loop of one trip
 
     auto raw_of = [&]() -> uint2 * { return A.raw + (size_t)rid_local * (size_t)(RAW_CAP * 5); };
     auto base_at = [&](int i) -> int {
@@ -259,6 +261,9 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                         len = 0;
                     }
                     if (len <= 0) { t = T_READ_DONE; break; }
+#ifdef GBX_LOOP_GUARD
+                    gd_trips = 64ll * (len + 2) * (len + 2);           // the three rounds of a read take a few extensions per base
+#endif
                     if (LDSQ) {
                         // eight bases per dword, the quad's lanes take turns; nothing is read behind the read (the last
                         // group base by base)
@@ -312,12 +317,14 @@ __global__ void __launch_bounds__(64, sizeof(IV) == 4 ? GBX_FMI_WAVES32 : GBX_FM
                     break;
                     }
                 }
+                if (GBX_GUARD_TRIP(gd_disp, GBX_GK_FMI, 2, A.read_base + rid_local)) { if (t != T_EXT) t = T_IDLE; }
             } while (__ballot(t != T_EXT && t != T_IDLE) != 0);
             if (__ballot(t == T_EXT) == 0) break;
         }
 
         // ---- one backwardExt per read (FMI_search.cpp): rows sp = k and ep = k + s of the checkpoint table; lane b of the
         // quad looks up base b: one 16-byte load per row and lane, one 64-byte line per row and quad
+        if (t == T_EXT && GBX_GUARD_TRIP(gd_trips, GBX_GK_FMI, 1, A.read_base + rid_local)) t = T_IDLE;      // (the read is abandoned: the call fails)
         const bool act = t == T_EXT;
         IV ek = 0, el = 0, es = 0;
         int ea = 0;
@@ -628,6 +635,7 @@ int fmi_launch(const gbx_fmi_index *idx, const void *d_index, const gbx_fmi_para
         }
     }
     GBX_HIP(hipGetLastError());
+    GBX_GUARD_CHECK("fmi");
     return GBX_OK;
 }
 

@@ -40,6 +40,45 @@ struct Stage {
     RoctxRange range_;
 };
 
+// ---- loop guards (-DGBX_LOOP_GUARD: a diagnostic build of libgbx.so, scripts/build_guard.sh; round 5) --------------------------------
+// A device loop whose trip count depends on data (traceback extensions, work-list walks, spin-waits between wavefronts) hangs the
+// whole process if the data is ever not what the algorithm guarantees.  In the guard build every such loop counts down from a bound
+// derived from its input sizes; a loop that hits it records (kernel, loop, unit) in a device word and leaves, and the launch function
+// returns GBX_ERR_HIP with the record in the error text instead of the process dying in a "GPU Hang".  The product build carries only
+// the bounds that are free (a comparison the loop makes anyway).
+//   GBX_GUARD(var, bound)                   declares the counter (nothing in the product build)
+//   GBX_GUARD_TRIP(var, kernel, loop, unit) true when the bound is exhausted (constant false in the product build)
+//   GBX_GUARD_CHECK(what, stream)           in a launch function, after its launches: synchronises and turns a record into an error
+enum { GBX_GK_BSW = 1, GBX_GK_CHAIN = 2, GBX_GK_PHMM = 3, GBX_GK_POA = 4, GBX_GK_ABEA = 5, GBX_GK_FMI = 6 };
+#ifdef GBX_LOOP_GUARD
+namespace { __device__ unsigned long long gbx_guard_word; }      // one per translation unit
+__device__ inline bool gbx_guard_report(int kernel, int loop, long long unit)
+{
+    atomicCAS(&gbx_guard_word, 0ull, 1ull << 63 | (unsigned long long)kernel << 56 | (unsigned long long)loop << 48 | ((unsigned long long)unit & 0xffffffffffffull));
+    return true;
+}
+#define GBX_GUARD(var, bound) long long var = (long long)(bound)
+#define GBX_GUARD_TRIP(var, kernel, loop, unit) (--(var) < 0 && gbx::gbx_guard_report((kernel), (loop), (long long)(unit)))
+static inline int gbx_guard_check(const char *what)
+{
+    unsigned long long v = 0;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(gbx_guard_word), sizeof(v));
+    if (e != hipSuccess) return hip_fail(e, what);
+    if (!v) return GBX_OK;
+    const unsigned long long zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gbx_guard_word), &zero, sizeof(zero));
+    set_error("%s: loop guard hit: kernel %d, loop %d, unit %lld (a data-dependent device loop ran past the bound its inputs allow)", what,
+              (int)(v >> 56 & 0x7f), (int)(v >> 48 & 0xff), (long long)(v & 0xffffffffffffull));
+    return GBX_ERR_HIP;
+}
+#define GBX_GUARD_CHECK(what) do { const int grc_ = gbx::gbx_guard_check(what); if (grc_) return grc_; } while (0)
+#else
+#define GBX_GUARD(var, bound)
+#define GBX_GUARD_TRIP(var, kernel, loop, unit) false
+#define GBX_GUARD_CHECK(what) do { } while (0)
+#endif
+
 // Side streams for independent kernels of one call (the per-class kernels have long single-wave tails that
 // overlap well).  fork(): the side streams wait for everything queued on `main`; join(): `main` waits for
 // them.  One set per device, created on first use and shared by every caller on that device: the launch

@@ -131,10 +131,13 @@ PG_HD void poa_topo_sort(PoaGraph &g)
     const int n = g.n_nodes;
     for (int i = 0; i < n; ++i) { g.mark[i] = 0; g.check[i] = 1; }
     int sp = 0, nr = 0;
+    long long visits = 0;
+    const long long visit_cap = (long long)n * (2 * (g.deg + POA_ALN_STRIDE) + 4) + 64;
     for (int i = 0; i < n; ++i) {
         if (g.mark[i] != 0) continue;
         g.stack[sp++] = i;
         while (sp) {
+            if (++visits > visit_cap) { g.err |= POA_ERR_STACK; return; }      // (a node is pushed once per list that names it)
             const int id = g.stack[sp - 1];
             const int mk = g.mark[id], ic = g.in_cnt[id], ac = g.aln_cnt[id];
             const bool chk = g.check[id] != 0;
@@ -380,10 +383,12 @@ PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, c
             for (;;) {
                 PG_PUSH(-1, j - 1);
                 --j;
+                if (j <= 0) break;                           // column 0 ends every horizontal run (E = Q = -infinity there); never below it
                 if (PG_AT(M.E, i, j) + S.e != PG_AT(M.E, i, j + 1) && PG_AT(M.Q, i, j) + S.c != PG_AT(M.Q, i, j + 1)) break;
             }
         } else if (ext_up) {
-            for (;;) {
+            for (int guard = 0;; ++guard) {
+                if (guard > g.n_nodes) { g.err |= POA_ERR_STACK; break; }     // (rows strictly decrease on a sound matrix)
                 bool stop = false;
                 prev_i = 0;
                 const int nd = g.r2n[i - 1];

@@ -398,7 +398,7 @@ typedef __attribute__((address_space(3))) v8s lds_v8s;
 typedef __attribute__((address_space(3))) v4u lds_v4u;
 typedef __attribute__((address_space(3))) v2u lds_v2u;
 
-template <int POA_RING_ROWS>                                // 0: no ring
+template <int POA_RING_ROWS, bool DESC_DONE = false>        // POA_RING_ROWS 0: no ring; DESC_DONE: the row descriptors are in place (poa_serial_call)
 __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
                                  int &max_i, int &max_j, char *lds_ring = nullptr)
 {
@@ -428,7 +428,7 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
     int32_t *d_pred = g.score, *d_info = g.pred;
     const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;
     int32_t *d_pred3 = g.stack;                                // RING: the 4th predecessor's row (the sort's order buffer is free during the DP)
-    {
+    if (!DESC_DONE) {
         PoaGraph &gm = const_cast<PoaGraph &>(g);
         for (int r = lane; r < n; r += 64) {
             poa_rowdesc_one(gm, r);
@@ -750,7 +750,10 @@ __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, co
     const PoaScore S = A.S;
     const int Wp = M.Wp;
     const Mat2 *Tc = A.Tc[0];
-    const PkMat T0 = pk_mat(Tc[0]), T1 = pk_mat(Tc[1]), T2 = pk_mat(Tc[2]), T3 = pk_mat(Tc[3]);
+    PkMat T0 = pk_mat(Tc[0]), T1 = pk_mat(Tc[1]), T2 = pk_mat(Tc[2]), T3 = pk_mat(Tc[3]);
+    // the scan's uniform factors in VECTOR registers: as scalars they were spilled and reloaded one v_readlane per use (eight per
+    // row, each an issue slot of a wavefront that has the SIMD to itself); the team's kernel has the vector registers to spare
+    asm volatile("" : "+v"(T0.ac), "+v"(T0.bd), "+v"(T1.ac), "+v"(T1.bd), "+v"(T2.ac), "+v"(T2.bd), "+v"(T3.ac), "+v"(T3.bd));
     const PkMat P16 = pk_mat(mp_pow(Tc[0], (lane & 15) + 1));
     const PkMat P32 = pk_mat(mp_pow(Tc[0], (lane & 31) + 1));
     const PkMat PC = pk_mat(mp_pow(Tc[0], lane));
@@ -875,7 +878,11 @@ __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, co
             const int X = i - BOUND;
             int need = X - ((X - 1 - own) & (NW - 1));
             need = max(need, max(max(need_of(ic >= 1 ? sp0 : 0), need_of(ic >= 2 ? sp1 : 0)), max(need_of(ic >= 3 ? p2 : 0), need_of(ic >= 4 ? p3 : 0))));
-            while (__ballot(*(volatile lds_i32 *)prog_mine < need) != 0) __builtin_amdgcn_s_sleep(1);
+            GBX_GUARD(gd_wait, 1 << 24);                           // polls: seconds, against microseconds of legitimate waiting
+            while (__ballot(*(volatile lds_i32 *)prog_mine < need) != 0) {
+                if (GBX_GUARD_TRIP(gd_wait, GBX_GK_POA, 4, i)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
         PoaPredIn in0, in1;
         fetch_pred(ic >= 1 ? sp0 : 0, i, in0);
@@ -908,9 +915,10 @@ __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, co
                 else {
                     prow = g.n2r[PG_IN_SRC(g, node, k)] + 1; wait_vm(); asm volatile("" : "+v"(prow));
                     prow = __builtin_amdgcn_readfirstlane(prow);
+                    GBX_GUARD(gd_wait5, 1 << 24);
                     for (;;) {                                     // (a fifth predecessor: rare; its row may be one of the last few)
                         const int pv = *(volatile lds_i32 *)prog_mine;
-                        if (done(pv, prow)) break;
+                        if (done(pv, prow) || GBX_GUARD_TRIP(gd_wait5, GBX_GK_POA, 5, i)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
@@ -1197,10 +1205,13 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
             for (;;) {
                 PG_PUSH(-1, j - 1);
                 --j;
+                if (j <= 0) break;                          // (column 0 ends every horizontal run: E(i,0) = Q(i,0) = -infinity; the test below says so too on sound data)
                 if (E_at(i, j) + S.e != E_at(i, j + 1) && Q_at(i, j) + S.c != Q_at(i, j + 1)) break;
             }
         } else if (ext_up) {
+            GBX_GUARD(gd_up, g.n_nodes + 2);
             for (;;) {
+                if (GBX_GUARD_TRIP(gd_up, GBX_GK_POA, 2, i)) { g.err |= POA_ERR_STACK; break; }
                 bool stop = false;
                 prev_i = 0;
                 const int nd = g.r2n[i - 1];
@@ -1397,6 +1408,7 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
     // short: one overflow check per visit with a single exit, 32-bit ballots (lanes 0..11 hold the list),
     // v_mbcnt for a lane's push slot.
     bool overflow = false;
+    GBX_GUARD(gd_walk, (long long)n * (2 * (g.deg + POA_ALN_STRIDE) + 4) + 64);      // visits of one sort: a node is pushed once per list that names it
     // the walk from root i (its state byte st_i: not done), emitting into obuf / ord
     auto walk = [&](int i, int st_i) {
         if (lane == 0) st8[i] = (unsigned char)(st_i | POA_ST_ROOT);
@@ -1411,6 +1423,7 @@ __device__ __attribute__((always_inline)) inline void poa_topo_sort_lds(PoaGraph
 #ifdef GBX_POA_PHASE_STATS
             ++nvis_;
 #endif
+            if (GBX_GUARD_TRIP(gd_walk, GBX_GK_POA, 3, i)) { g.err |= POA_ERR_STACK; sp = 0; break; }
             if (sp > T.stk_cap - 16) { overflow = true; break; }     // a visit pushes at most 4 + 8 (+ cold, checked there)
             const int id = top_known ? top : (int)stk[sp - 1];
             const int stv = top_known ? top_st : (int)st8[id];
@@ -2085,6 +2098,270 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
 }
 
 
+// ---- the serial phases as ONE out-of-line function (round 5) -----------------------------------------------------------------------
+// poa_kernel and poa_team_kernel above are single functions: every phase is inlined, and the PoaGraph (25 pointers), the output
+// pointers and the sort's LDS arrays are live from a window's first sequence to its consensus - through the DP's row loop too, which
+// needs a dozen of them.  258-332 scalar registers spill; the allocator keeps some of the live-through values in registers and
+// reloads loop constants instead (the scan's matrices, one v_readlane per use): 34 reloads in the row loop.
+// Here the kernel's body is the DP and nothing else.  Traceback, add_alignment with the sort, the row descriptors of the next
+// alignment and the consensus are poa_serial_call: NOT inlined, it binds the graph by itself - from the launch's arguments, which it
+// reads out of the kernel-argument segment (scalar loads through the pointer the kernel passes; the workgroup id comes with the call), and the window's five words of
+// state, which travel as arguments and return value.  One call per sequence; inside it the allocator starts from nothing, and in the
+// kernel body nothing of the graph is live across the row loop.  (A first attempt at out-of-line phases, round 3, passed `PoaGraph &`:
+// the struct went to scratch memory and every access became FLAT.  Nothing is passed by reference here.)
+struct PoaKernArgs { PoaArgs A; SlotLayout L; };
+static_assert(sizeof(PoaKernArgs) % 4 == 0, "copied word by word out of the kernel-argument segment");
+struct PoaWinState { int n_nodes, n_codes, err, n_sorted, flags_ok; };
+constexpr int POA_SF_FIRST = 1, POA_SF_RAN_DP = 2, POA_SF_LAST = 4, POA_SF_LONGSEQ = 8, POA_SF_EMPTY = 16;
+
+__device__ inline int poa_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline int64_t poa_uni64(int64_t v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffff)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// WAVES: wavefronts per SIMD of the calling kernel (an instance per caller: the compiler hands the caller's register budget down
+// to a function all of whose callers agree on it).  LONG: the caller's slots have five planes, sequences over 512 bases may come.
+// DESC: also builds the row descriptors of the next alignment (the one-wavefront kernel; the team builds them with all its lanes).
+template <int WAVES, bool LONG, bool INC, bool DESC>
+__device__ __attribute__((noinline)) PoaWinState poa_serial_call(PoaWinState st, int64_t w, int64_t s, int mi, int mj, int flags, unsigned long long kernargs)
+{
+    // arguments arrive in vector registers: everything below must know that they are the same in every lane
+    st.n_nodes = poa_uni(st.n_nodes); st.n_codes = poa_uni(st.n_codes); st.err = poa_uni(st.err);
+    st.n_sorted = poa_uni(st.n_sorted); st.flags_ok = poa_uni(st.flags_ok);
+    w = poa_uni64(w); s = poa_uni64(s); mi = poa_uni(mi); mj = poa_uni(mj); flags = poa_uni(flags);
+    // (a struct cannot be copy-constructed out of the constant address space: its words are loaded and put together again; the
+    // loads are scalar - s_load - and only those of fields that are used survive)
+    typedef const __attribute__((address_space(4))) int kernarg_word_t;
+    // (the kernel hands its kernel-argument pointer down: asked for inside a callee, __builtin_amdgcn_kernarg_segment_ptr() faults on
+    // this toolchain - build_tmp/kernarg_probe.hip)
+    kernarg_word_t *const kw = (kernarg_word_t *)(unsigned long long)poa_uni64((int64_t)kernargs);
+    PoaKernArgs KK;
+    {
+        int words[sizeof(PoaKernArgs) / 4];
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(PoaKernArgs) / 4; ++k) words[k] = kw[k];
+        __builtin_memcpy(&KK, words, sizeof(PoaKernArgs));
+    }
+    const PoaArgs &A = KK.A;
+    const SlotLayout &L = KK.L;
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    PoaGraph g;
+    poa_bind_graph(g, slot, L, A);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    PoaTopoLds T;
+    poa_bind_lds(T, lds_raw, A);
+    g.n_nodes = st.n_nodes; g.n_codes = st.n_codes; g.err = st.err; g.n_path = 0; g.path_lo = g.path_hi = -1;
+    T.n_sorted = st.n_sorted; T.flags_ok = st.flags_ok;
+    const int lane = threadIdx.x & 63;
+    if (flags & POA_SF_FIRST) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; }
+    if (!(flags & POA_SF_EMPTY)) {
+        const uint8_t *seq = A.arena + A.seq_off[s];
+        const int len = A.seq_len[s];
+        poa_cell_t *mat = (poa_cell_t *)(slot + L.mat);
+        const bool ran_dp = (flags & POA_SF_RAN_DP) != 0;
+        if (ran_dp) {
+            const bool piped = !LONG || !(flags & POA_SF_LONGSEQ);
+            const int wp = piped ? POA_PIPE_STRIDE : poa_row_stride(len);
+            const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
+            PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
+#ifdef GBX_POA_PHASE_STATS
+            const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+            if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+            else if (LONG) { poa_dp<8>(g, M, A, seq, len, mi, mj); poa_traceback(g, M, A.S, seq, mi, mj); }
+#ifdef GBX_POA_PHASE_STATS
+            if (lane == 0) { atomicAdd(A.cells + 2, __builtin_readcyclecounter() - t0_); atomicAdd(A.cells + 13, (unsigned long long)g.n_path); }
+#endif
+        }
+#ifdef GBX_POA_PHASE_STATS
+        const unsigned long long t1_ = __builtin_readcyclecounter();
+#endif
+        if (T.use && ran_dp) {
+            // the DP's row ring has used the sort's LDS: state bytes back from the slot, previous ranks = n2r
+            const uint8_t *save = (const uint8_t *)(slot + L.st8save);
+            for (int i = lane; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (g.err == 0) poa_add_alignment_wave<INC>(g, seq, len, T);
+        if (T.use && !(flags & POA_SF_LAST)) {
+            uint8_t *save = (uint8_t *)(slot + L.st8save);
+            for (int i = lane; i < g.n_nodes; i += 64) save[i] = T.st8[i];
+        }
+        if (DESC && !(flags & POA_SF_LAST) && g.err == 0) {
+            // the row descriptors of the graph as it now is: what the next alignment's DP and traceback read (the path arrays and the
+            // sort's order buffer, which three of them share, are free again)
+            int32_t *d_pred3 = g.stack;
+            for (int r = lane; r < g.n_nodes; r += 64) {
+                poa_rowdesc_one(g, r);
+                const int node = g.r2n[r];
+                d_pred3[r] = g.in_cnt[node] > 3 ? g.n2r[PG_IN_SRC(g, node, 3)] + 1 : 0;
+            }
+        }
+#ifdef GBX_POA_PHASE_STATS
+        if (lane == 0) atomicAdd(A.cells + 3, __builtin_readcyclecounter() - t1_);
+#endif
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (flags & POA_SF_LAST) {
+#ifdef GBX_POA_PHASE_STATS
+        const unsigned long long t2_ = __builtin_readcyclecounter();
+#endif
+        int clen = 0;
+        if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+        if (lane == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+#ifdef GBX_POA_PHASE_STATS
+        if (lane == 0) atomicAdd(A.cells + 4, __builtin_readcyclecounter() - t2_);
+#endif
+    }
+    PoaWinState out = {g.n_nodes, g.n_codes, g.err, T.n_sorted, T.flags_ok};
+    return out;
+}
+
+// the few graph arrays the DP itself reads (row descriptors; the in-edge lists for a fifth predecessor), bound for the DP alone
+__device__ __attribute__((always_inline)) inline void poa_bind_dp_graph(PoaGraph &g, char *slot, const SlotLayout &L, const PoaArgs &A, bool with_lists)
+{
+    g.ncap = A.ncap; g.deg = A.deg;
+    g.r2n = (int32_t *)(slot + L.r2n); g.n2r = (int32_t *)(slot + L.n2r);
+    g.in_src = (int32_t *)(slot + L.in_src); g.in_src_x = (int32_t *)(slot + L.in_src_x);
+    g.stack = (int32_t *)(slot + L.stack); g.score = (int32_t *)(slot + L.score); g.pred = (int32_t *)(slot + L.pred);
+    g.path_node = (int32_t *)(slot + L.path_node); g.path_pos = (int32_t *)(slot + L.path_pos);
+    if (with_lists) {                                          // (the team builds the descriptors itself: it needs what poa_rowdesc_one reads)
+        g.in_cnt = (uint8_t *)(slot + L.in_cnt); g.out_cnt = (uint8_t *)(slot + L.out_cnt);
+        g.code = (uint8_t *)(slot + L.code); g.decoder = (uint8_t *)(slot + L.decoder);
+    }
+}
+
+// the window kernel (one wavefront per window) with the serial phases out of line
+template <bool LONG, int WAVES = 3, int RROWS = POA_RING_DEFAULT>
+__global__ void __launch_bounds__(64, WAVES) poa_kernel2(PoaKernArgs K)
+{
+    const PoaArgs &A = K.A;
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    if (LONG && lane == 0) atomicAdd(A.cells + POA_LONG_STARTED, 1ull);
+    unsigned long long cells = 0;
+#ifdef GBX_POA_PHASE_STATS
+    unsigned long long t_dp = 0, n_rows = 0;
+#endif
+    const unsigned nwork = (unsigned)A.cells[A.cnt_idx];
+    for (;;) {
+        unsigned long long wq = 0;
+        if (lane == 0) wq = atomicAdd(A.cells + A.cur_idx, 1ull);
+        const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane((int)wq);
+        if (q32 >= nwork) break;
+        const int64_t w = (int64_t)A.wlist[q32];
+        PoaWinState st = {0, 0, 0, 0, 0};
+        const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+        if (s0 == s1) st = poa_serial_call<WAVES, LONG, true, true>(st, w, s0, -1, -1, POA_SF_FIRST | POA_SF_LAST | POA_SF_EMPTY, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+        for (int64_t s = s0; s < s1; ++s) {
+            const int len = A.seq_len[s];
+            int mi = -1, mj = -1, flags = (s == s0 ? POA_SF_FIRST : 0) | (s + 1 == s1 ? POA_SF_LAST : 0);
+            if (st.n_nodes != 0 && len != 0 && st.err == 0) {
+                flags |= POA_SF_RAN_DP;
+                cells += (unsigned long long)st.n_nodes * (unsigned long long)len;
+                if (!LONG || len <= POA_PIPE_MAXLEN) {
+                    const uint8_t *seq = A.arena + A.seq_off[s];
+                    poa_cell_t *mat = (poa_cell_t *)(slot + K.L.mat);
+                    const int64_t plane = (int64_t)(st.n_nodes + 1) * POA_PIPE_STRIDE;
+                    PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, POA_PIPE_STRIDE};
+                    PoaGraph gd;
+                    poa_bind_dp_graph(gd, slot, K.L, A, false);
+                    gd.n_nodes = st.n_nodes;
+#ifdef GBX_POA_PHASE_STATS
+                    const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+                    __builtin_amdgcn_s_setprio(0);
+                    poa_dp_pipelined<RROWS, true>(gd, M, A, seq, len, mi, mj, lds_raw);
+                    __builtin_amdgcn_s_setprio(3);
+#ifdef GBX_POA_PHASE_STATS
+                    t_dp += __builtin_readcyclecounter() - t0_; n_rows += (unsigned long long)st.n_nodes;
+#endif
+                } else flags |= POA_SF_LONGSEQ;
+            }
+            st = poa_serial_call<WAVES, LONG, true, true>(st, w, s, mi, mj, flags, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+            st.n_nodes = poa_uni(st.n_nodes); st.n_codes = poa_uni(st.n_codes); st.err = poa_uni(st.err);
+            st.n_sorted = poa_uni(st.n_sorted); st.flags_ok = poa_uni(st.flags_ok);
+        }
+    }
+    if (lane == 0) atomicAdd(A.cells, cells);
+#ifdef GBX_POA_PHASE_STATS
+    if (lane == 0) { atomicAdd(A.cells + 1, t_dp); atomicAdd(A.cells + 12, n_rows); }
+#endif
+}
+
+// the team kernel with the serial phases out of line
+template <bool LONG, int WAVES>
+__global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team2_kernel(PoaKernArgs K, int sync_off)
+{
+    constexpr int NW = POA_TEAM_NW;
+    const PoaArgs &A = K.A;
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_team *const sy = (lds_team *)((lds_u8 *)lds_raw + sync_off);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    if (LONG && threadIdx.x == 0) atomicAdd(A.cells + POA_LONG_STARTED, 1ull);
+
+    unsigned long long cells = 0;
+    const unsigned nwork = (unsigned)A.cells[A.cnt_idx];
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const unsigned long long wq = atomicAdd(A.cells + A.cur_idx, 1ull);
+            *(volatile lds_i32 *)&sy->widx = (int)(wq < 0x7fffffffull ? wq : 0x7fffffffull);
+        }
+        __syncthreads();
+        const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->widx);
+        if (q32 >= nwork) break;
+        const int64_t w = (int64_t)A.wlist[q32];
+        PoaWinState st = {0, 0, 0, 0, 0};
+        int n_nodes = 0, err = 0;
+        const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+        if (s0 == s1 && wave == 0) st = poa_serial_call<WAVES, LONG, true, false>(st, w, s0, -1, -1, POA_SF_FIRST | POA_SF_LAST | POA_SF_EMPTY, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+        for (int64_t s = s0; s < s1; ++s) {
+            const int len = A.seq_len[s];
+            int mi = -1, mj = -1, flags = (s == s0 ? POA_SF_FIRST : 0) | (s + 1 == s1 ? POA_SF_LAST : 0);
+            if (n_nodes != 0 && len != 0 && err == 0) {
+                flags |= POA_SF_RAN_DP;
+                const bool piped = !LONG || len <= POA_PIPE_MAXLEN;
+                if (wave == 0) cells += (unsigned long long)n_nodes * (unsigned long long)len;
+                if (piped) {
+                    const uint8_t *seq = A.arena + A.seq_off[s];
+                    poa_cell_t *mat = (poa_cell_t *)(slot + K.L.mat);
+                    const int64_t plane = (int64_t)(n_nodes + 1) * POA_PIPE_STRIDE;
+                    PoaMatrices M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, POA_PIPE_STRIDE};
+                    PoaGraph gd;
+                    poa_bind_dp_graph(gd, slot, K.L, A, true);
+#ifdef GBX_POA_PHASE_STATS
+                    const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+                    __builtin_amdgcn_s_setprio(0);
+                    poa_dp_team<NW, POA_TEAM_RR, POA_TEAM_K>(gd, M, A, seq, len, n_nodes, lds_raw, sy, wave, mi, mj);
+                    __builtin_amdgcn_s_setprio(3);
+#ifdef GBX_POA_PHASE_STATS
+                    if (threadIdx.x == 0) { atomicAdd(A.cells + 1, __builtin_readcyclecounter() - t0_); atomicAdd(A.cells + 12, (unsigned long long)n_nodes); }
+#endif
+                } else flags |= POA_SF_LONGSEQ;                  // column blocks: DP and traceback inside the call
+            }
+            if (wave == 0) {
+                st = poa_serial_call<WAVES, LONG, true, false>(st, w, s, mi, mj, flags, (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr());
+                if (lane == 0) { *(volatile lds_i32 *)&sy->n_nodes = st.n_nodes; *(volatile lds_i32 *)&sy->err = st.err; }
+            }
+            __syncthreads();
+            n_nodes = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->n_nodes);
+            err = __builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->err);
+            if (wave == 0) { st.n_nodes = n_nodes; st.err = err; st.n_codes = poa_uni(st.n_codes); st.n_sorted = poa_uni(st.n_sorted); st.flags_ok = poa_uni(st.flags_ok); }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(A.cells, cells);
+}
+
+
 // ---- the lock-step form (round 4): every window resident, one launch per phase and sequence index ----------------
 // poa_kernel keeps a window in one wavefront from its first sequence to its consensus: the DP (throughput work: packed
 // arithmetic and row traffic), the traceback (one dependent row fetch per step) and add_alignment / the sort (chains of
@@ -2369,6 +2646,8 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
     // the team kernel (a window per workgroup of four wavefronts): for the windows of the long launch, and for a main list with
     // fewer windows than the chip keeps team workgroups resident (a job as long as its slowest window: see poa_team_kernel)
     const bool team_on = !(getenv("GBX_POA_TEAM") && atoi(getenv("GBX_POA_TEAM")) == 0);
+    const int serial_form = getenv("GBX_POA_SERIAL_FORM") ? atoi(getenv("GBX_POA_SERIAL_FORM")) : 1;      // 2: poa_kernel2 (serial phases out of line)
+    const int team_form = getenv("GBX_POA_TEAM_FORM") ? atoi(getenv("GBX_POA_TEAM_FORM")) : 1;      // 2: the serial phases out of line (poa_serial_call)
     const size_t team_ring = std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_TEAM_RING_BYTES);
     const int team_sync_off = (int)((team_ring + 15) & ~(size_t)15);
     const size_t team_lds = (size_t)team_sync_off + sizeof(PoaTeamSync);
@@ -2382,6 +2661,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         B.work = wb + ws.lslots; B.slot_bytes = LL.total; B.wlist = d_llist; B.cnt_idx = POA_CNT_LONG; B.cur_idx = POA_CUR_LONG;
         hipStream_t sl = ss ? ss->side[0] : s;
         Stage st("poa_window_long", sl);
+        if (team_form == 2) {
+            PoaKernArgs KB; KB.A = B; KB.L = LL;
+            hipLaunchKernelGGL((poa_team2_kernel<true, GBX_POA_TEAM_LONG_WAVES>), dim3(plan->long_slots), dim3(64 * POA_TEAM_NW), team_lds, sl, KB, team_sync_off);
+        } else
         hipLaunchKernelGGL((poa_team_kernel<true, GBX_POA_TEAM_LONG_WAVES>), dim3(plan->long_slots), dim3(64 * POA_TEAM_NW), team_lds, sl, B, LL, team_sync_off);
     } else if (has_long) {
         const SlotLayout LL = make_layout(ncap, deg, lmax, true);
@@ -2391,6 +2674,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         Stage st("poa_window_long", sl);
         // (compiled for one wavefront per SIMD: the handful of long windows of a job run a wavefront per CU at most, and with
         // all 512 VGPRs the instance - column-block DP, ring, both sorts - has no spills; at 168 it spilled 222)
+        if (serial_form == 2) {
+            PoaKernArgs KB; KB.A = B; KB.L = LL;
+            hipLaunchKernelGGL((poa_kernel2<true, GBX_POA_LONG_WAVES>), dim3(plan->long_slots), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), sl, KB);
+        } else
         hipLaunchKernelGGL((poa_kernel<true, GBX_POA_LONG_WAVES>), dim3(plan->long_slots), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), sl, B, LL);
     }
     const int64_t n_main = n_windows - plan->n_long_windows;
@@ -2428,6 +2715,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
                                (unsigned)std::min<int64_t>(plan->long_slots, cus));
         }
         Stage st("poa_window_team", s);
+        if (team_form == 2) {
+            PoaKernArgs KA; KA.A = A; KA.L = L;
+            hipLaunchKernelGGL((poa_team2_kernel<false, GBX_POA_TEAM_WAVES>), dim3(grid), dim3(64 * POA_TEAM_NW), team_lds, s, KA, team_sync_off);
+        } else
         hipLaunchKernelGGL((poa_team_kernel<false, GBX_POA_TEAM_WAVES>), dim3(grid), dim3(64 * POA_TEAM_NW), team_lds, s, A, L, team_sync_off);
     } else if (has_main) {
         const SlotLayout L = make_layout(ncap, deg, lmax, false);
@@ -2449,11 +2740,16 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
             hipLaunchKernelGGL((poa_kernel<false, 4, 4>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)4 * POA_RING_SLOT), s, A, L);
         else if (oe && atoi(oe) == 2)
             hipLaunchKernelGGL((poa_kernel<false, 2, 9>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)9 * POA_RING_SLOT), s, A, L);
-        else
+        else if (serial_form == 2) {
+            PoaKernArgs KA; KA.A = A; KA.L = L;
+            hipLaunchKernelGGL((poa_kernel2<false>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, KA);
+        } else
             hipLaunchKernelGGL((poa_kernel<false>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)POA_RING_BYTES), s, A, L);
     }
     if (ss && (rc = ss->join(s))) return rc;
     GBX_HIP(hipGetLastError());
+    side_lock = std::unique_lock<std::mutex>();
+    GBX_GUARD_CHECK("poa");
     return GBX_OK;
 }
 

@@ -141,12 +141,15 @@ while time.time() < t_end:
             os.environ["GBX_POA_LOCKSTEP"] = "1"
             os.environ["GBX_POA_TB_SERIAL"] = str(int(rng.integers(0, 2)))
             os.environ["GBX_POA_DP_OCC"] = str(int(rng.choice([5, 6])))
-        what = "windows=%d lockstep=%s tb_serial=%s dp_occ=%s" % (nw, lock, os.environ.get("GBX_POA_TB_SERIAL"), os.environ.get("GBX_POA_DP_OCC"))
+        elif rng.random() < 0.4:                                 # (default: the team kernel; here one wavefront per window, or a mix)
+            os.environ[str(rng.choice(["GBX_POA_TEAM", "GBX_POA_TEAM_MAX"]))] = "0"
+        what = "windows=%d lockstep=%s tb_serial=%s dp_occ=%s team=%s team_max=%s" % (nw, lock, os.environ.get("GBX_POA_TB_SERIAL"), os.environ.get("GBX_POA_DP_OCC"),
+                                                                                     os.environ.get("GBX_POA_TEAM"), os.environ.get("GBX_POA_TEAM_MAX"))
         run = announce("poa seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what))
         try:
             ok = not run or consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
         finally:
-            for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC"):
+            for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC", "GBX_POA_TEAM", "GBX_POA_TEAM_MAX"):
                 os.environ.pop(v, None)
     what += " devices=%d min_units=%s" % (ndev, os.environ.get("GBX_SHARD_MIN_UNITS"))
     count[k] += 1

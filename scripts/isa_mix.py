@@ -72,8 +72,10 @@ def main():
             out[dem] = {"stage": stage_name(dem), "valu_static": n, **{k: counts.get(k, 0) for k in CYC},
                         "mean_cycles_per_valu": round(cyc, 3), "roof_lane_ops_per_s": 64.0 * simds * clk / cyc, "source": f}
     hashes = {f: sha16(os.path.join(CSRC, f)) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))}
+    sys.path.insert(0, ROOT)
+    from genomicsbench_amd.srchash import KIND_SOURCE, tu_sha16
     json.dump({"note": __doc__.split("\n\nusage")[0], "rates_cycles_per_wave64_instruction": CYC, "simds": simds, "clock_hz": clk,
-               "csrc_sha16": hashes, "kernels": out}, open(os.path.join(ROOT, "profiles", "valu_mix.json"), "w"), indent=1)
+               "csrc_sha16": hashes, "tu_sha16": {k: tu_sha16(k) for k in KIND_SOURCE}, "kernels": out}, open(os.path.join(ROOT, "profiles", "valu_mix.json"), "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["valu_static"])[:50]:
         print("%-46s %-18s valu %5d  full %4d half %4d quarter %3d  %.2f cyc  roof %.2e" % (k[:46], v["stage"][:18], v["valu_static"], v["full"], v["half"], v["quarter"], v["mean_cycles_per_valu"], v["roof_lane_ops_per_s"]))
 

@@ -20,6 +20,8 @@ import sys
 import hashlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from genomicsbench_amd.srchash import tu_sha16  # noqa: E402
 CSRC = os.path.join(ROOT, "genomicsbench_amd", "csrc")
 KIND_SOURCE = {"bsw": "bsw_kernels.hip", "chain": "chain_kernels.hip", "phmm": "phmm_kernels.hip", "poa": "poa_kernels.hip", "abea": "abea_kernels.hip",
                "fmi": "fmi_kernels.hip"}
@@ -83,7 +85,7 @@ def main():
         table = json.load(open(path))
         # the stamp is the one recorded when the counters were collected (scripts/pmc_summary.py); a file without one (older
         # collections) is only accepted while the source still hashes to what the committed table says
-        cur = sha16(os.path.join(CSRC, KIND_SOURCE[k]))
+        cur = tu_sha16(k)                                   # every file of the kind's translation unit (genomicsbench_amd/srchash.py)
         rec = table.pop("_hip_sha16", None)
         if rec is None and stamps.get(k) != cur:
             print("skipping %s: no collection-time stamp and the source has changed" % path)

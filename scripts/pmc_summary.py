@@ -20,9 +20,10 @@ for kn, d in agg.items():
     print("%-36s launches %d" % (kn, L), {k: (round(v, 3) if v < 100 else int(v)) for k, v in d.items()})
 # the hash of the kernel source these counters were collected on, recorded HERE (at collection time, on the box that ran
 # them): scripts/make_profile_tables.py copies it, so that re-running that script later cannot re-stamp old counters
-import hashlib, os
+import os
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root)
+from genomicsbench_amd.srchash import KIND_SOURCE, tu_sha16
 _kind = os.path.basename(sys.argv[1].rstrip("/")).replace("pmc_", "")
-_src = os.path.join(_root, "genomicsbench_amd", "csrc", _kind + "_kernels.hip")
-if os.path.exists(_src): out["_hip_sha16"] = hashlib.sha256(open(_src, "rb").read()).hexdigest()[:16]
+if _kind in KIND_SOURCE: out["_hip_sha16"] = tu_sha16(_kind)          # every file of the kind's translation unit
 if len(sys.argv) > 2: json.dump(out, open(sys.argv[2], "w"), indent=1)

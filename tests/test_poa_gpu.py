@@ -149,6 +149,31 @@ def test_windows_with_long_sequences_take_the_second_launch():
         assert consensus_host(p, w2) == O.poa_oracle(p, w2, 2)
 
 
+# ---- the team kernel (round 5, poa_kernels.hip: a window per workgroup of four wavefronts, the DP's rows as a dataflow over a
+# shared LDS ring).  Jobs of up to four windows per CU take it by themselves, i.e. every small job of this file; here the three
+# ways a job can be split over the kernels are forced and compared: team everywhere (default), no team at all
+# (GBX_POA_TEAM=0: one wavefront per window, the kernel of 'large'), and team for the long windows only (GBX_POA_TEAM_MAX=0).
+# GBX_POA_SERIAL_FORM / GBX_POA_TEAM_FORM = 2: the same kernels with traceback, add_alignment, the sort and the consensus in one
+# out-of-line function (poa_serial_call) - measured no faster (profiles/r05m_poa_serial_out_of_line_ab.txt), kept selectable.
+@pytest.mark.parametrize("env", [{}, {"GBX_POA_TEAM": "0"}, {"GBX_POA_TEAM_MAX": "0"}, {"GBX_POA_TEAM_MAX": "5"},
+                                 {"GBX_POA_TEAM_FORM": "2", "GBX_POA_SERIAL_FORM": "2"}, {"GBX_POA_TEAM": "0", "GBX_POA_SERIAL_FORM": "2"},
+                                 {"GBX_POA_TEAM_MAX": "5", "GBX_POA_TEAM_FORM": "2", "GBX_POA_SERIAL_FORM": "2"}])
+def test_team_kernel_equals_the_window_kernel(monkeypatch, env):
+    p = make_params()
+    rng = np.random.default_rng(5)
+    def window(L, n):
+        base = "".join(rng.choice(list("ACGT"), L))
+        return ["".join(c if rng.random() > 0.07 else "ACGT"[rng.integers(4)] for c in base)[int(rng.integers(0, 9)):] for _ in range(n)]
+    sets = [gen_poa(40, 4001), random_windows(17, 24, 300, 7), random_windows(18, 30, 520, 9),
+            PoaWindowSet.from_lists([window(L, 5 + i % 4) for i, L in enumerate([300, 530, 512, 760, 90, 513, 1040, 400])]),
+            PoaWindowSet.from_lists([["ACGTACGTAC"] * 3, ["A", "C", "A"], ["ACGT"], [], ["GATTACA", "GATTACA", "GATTTACA", "GATTACA"]])]
+    want = [O.poa_oracle(p, ws, 8) for ws in sets]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for ws, w in zip(sets, want):
+        diff(consensus_host(p, ws), w)
+
+
 # ---- the lock-step form (poa_kernels.hip: a slot per window, one launch per phase and sequence index).  Jobs with more
 # windows than the chip holds wavefronts take it by themselves ('large': tests/test_fullsize_gpu.py); GBX_POA_LOCKSTEP=1
 # forces it on the small jobs here.
