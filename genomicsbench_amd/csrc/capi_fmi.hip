@@ -79,8 +79,9 @@ int gbx_fmi_extensions(const void *d_work, int64_t *ext, void *stream)
 // was freed and reused for another index of the same length is a different index.  Entries are reference-counted while a
 // call uses them (gbx_fmi_host_release leaves those alone) and at most four idle ones are kept per device.
 namespace {
-struct FmiCached { int dev; int64_t len, sentinel, count[5]; uint64_t fp; void *d_index; size_t bytes; int users; uint64_t last_use; };
+struct FmiCached { int dev; int64_t len, sentinel, count[5]; uint64_t fp; void *d_index; size_t bytes; int users; uint64_t last_use; bool building; };
 std::mutex g_fmi_mu;
+std::condition_variable g_fmi_cv;          // an entry under construction (building) has been finished or given up
 std::vector<FmiCached> g_fmi_cache;
 uint64_t g_fmi_clock = 0;
 
@@ -89,7 +90,9 @@ uint64_t fmi_fingerprint(const gbx_fmi_index *idx)
     const int64_t ncp = (idx->ref_seq_len >> 6) + 1;
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t k = 0; k < n; ++k) { h ^= b[k]; h *= 1099511628211ull; } };
-    const int64_t samples = ncp < 256 ? ncp : 256;
+    // one checkpoint in every 4096 (at least 256): a table edited in place between two calls is caught unless the edit misses
+    // every sampled line - mutating an index that has been handed to the library is not supported (gbx_fmi_host_release forgets it)
+    const int64_t samples = ncp < 256 ? ncp : std::max<int64_t>(256, ncp >> 12);
     for (int64_t k = 0; k < samples; ++k) mix(&idx->cp_occ[(size_t)(k * (ncp - 1) / (samples > 1 ? samples - 1 : 1))], sizeof(gbx_fmi_cp_occ));
     return h;
 }
@@ -137,40 +140,68 @@ static int fmi_host_one(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64
     void *d_index = nullptr;
     {
         const uint64_t fp = fmi_fingerprint(idx);
-        std::lock_guard<std::mutex> lk(g_fmi_mu);
-        for (FmiCached &c : g_fmi_cache)
-            if (c.dev == dev && c.len == idx->ref_seq_len && c.sentinel == idx->sentinel_index && c.fp == fp &&
-                !memcmp(c.count, idx->count, sizeof(c.count))) {
-                d_index = c.d_index; ++c.users; c.last_use = ++g_fmi_clock;
-            }
-        if (!d_index) {
-            // at most four idle entries per device: the least recently used goes first
+        auto same = [&](const FmiCached &c) {
+            return c.dev == dev && c.len == idx->ref_seq_len && c.sentinel == idx->sentinel_index && c.fp == fp && !memcmp(c.count, idx->count, sizeof(c.count));
+        };
+        bool build = false;
+        {
+            std::unique_lock<std::mutex> lk(g_fmi_mu);
             for (;;) {
-                int idle = 0, victim = -1;
-                for (size_t k = 0; k < g_fmi_cache.size(); ++k)
-                    if (g_fmi_cache[k].dev == dev && g_fmi_cache[k].users == 0) {
-                        ++idle;
-                        if (victim < 0 || g_fmi_cache[k].last_use < g_fmi_cache[(size_t)victim].last_use) victim = (int)k;
-                    }
-                if (idle < 4) break;
-                (void)hipFree(g_fmi_cache[(size_t)victim].d_index);
-                g_fmi_cache.erase(g_fmi_cache.begin() + victim);
+                FmiCached *hit = nullptr;
+                for (FmiCached &c : g_fmi_cache) if (same(c)) hit = &c;
+                if (hit && hit->building) { g_fmi_cv.wait(lk); continue; }        // another caller is uploading this very index: wait for it
+                if (hit) { d_index = hit->d_index; ++hit->users; hit->last_use = ++g_fmi_clock; }
+                break;
             }
+            if (!d_index) {
+                // at most four idle entries per device: the least recently used goes first
+                for (;;) {
+                    int idle = 0, victim = -1;
+                    for (size_t k = 0; k < g_fmi_cache.size(); ++k)
+                        if (g_fmi_cache[k].dev == dev && g_fmi_cache[k].users == 0 && !g_fmi_cache[k].building) {
+                            ++idle;
+                            if (victim < 0 || g_fmi_cache[k].last_use < g_fmi_cache[(size_t)victim].last_use) victim = (int)k;
+                        }
+                    if (idle < 4) break;
+                    (void)hipFree(g_fmi_cache[(size_t)victim].d_index);
+                    g_fmi_cache.erase(g_fmi_cache.begin() + victim);
+                }
+                // a place-holder under the lock; the upload and the re-layout (up to a gigabyte over PCIe) run outside it, so that
+                // the shards of a multi-device call build their copies side by side and gbx_fmi_host_release never waits for one
+                FmiCached c{dev, idx->ref_seq_len, idx->sentinel_index, {0, 0, 0, 0, 0}, fp, nullptr, 0, 1, ++g_fmi_clock, true};
+                memcpy(c.count, idx->count, sizeof(c.count));
+                g_fmi_cache.push_back(c);
+                build = true;
+            }
+        }
+        if (build) {
             const size_t bytes = fmi_index_bytes(idx->ref_seq_len);
             void *d_src = nullptr;
-            GBX_HIP(hipMalloc(&d_index, bytes));
-            hipError_t e = hipMalloc(&d_src, bytes);
+            hipError_t e = hipMalloc(&d_index, bytes);
+            if (e != hipSuccess) d_index = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&d_src, bytes);
             if (e == hipSuccess) e = hipMemcpyAsync(d_src, idx->cp_occ, bytes, hipMemcpyHostToDevice, s);
-            if (e != hipSuccess) { (void)hipFree(d_index); if (d_src) (void)hipFree(d_src); return hip_fail(e, "fmi index upload"); }
-            gbx_fmi_index di = *idx;
-            di.cp_occ = (const gbx_fmi_cp_occ *)d_src;
-            rc = fmi_index_build(&di, d_index, bytes, s);
-            hipError_t e2 = hipStreamSynchronize(s);
-            (void)hipFree(d_src);
-            if (rc || e2 != hipSuccess) { (void)hipFree(d_index); return rc ? rc : hip_fail(e2, "fmi index build"); }
-            FmiCached c{dev, idx->ref_seq_len, idx->sentinel_index, {0, 0, 0, 0, 0}, fp, d_index, bytes, 1, ++g_fmi_clock};
-            memcpy(c.count, idx->count, sizeof(c.count));
-            g_fmi_cache.push_back(c);
+            int brc = e == hipSuccess ? GBX_OK : hip_fail(e, "fmi index upload");
+            if (!brc) {
+                gbx_fmi_index di = *idx;
+                di.cp_occ = (const gbx_fmi_cp_occ *)d_src;
+                brc = fmi_index_build(&di, d_index, bytes, s);
+                const hipError_t e2 = hipStreamSynchronize(s);
+                if (!brc && e2 != hipSuccess) brc = hip_fail(e2, "fmi index build");
+            }
+            if (d_src) (void)hipFree(d_src);
+            if (brc && d_index) { (void)hipFree(d_index); d_index = nullptr; }
+            {
+                std::lock_guard<std::mutex> lk(g_fmi_mu);
+                for (size_t k = 0; k < g_fmi_cache.size(); ++k)
+                    if (g_fmi_cache[k].building && same(g_fmi_cache[k])) {
+                        if (brc) g_fmi_cache.erase(g_fmi_cache.begin() + (long)k);
+                        else { g_fmi_cache[k].d_index = d_index; g_fmi_cache[k].bytes = bytes; g_fmi_cache[k].building = false; }
+                        break;
+                    }
+            }
+            g_fmi_cv.notify_all();
+            if (brc) return brc;
         }
         use.d_index = d_index;
     }
@@ -262,7 +293,10 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
         return rc ? rc : one();
     }
     const std::vector<int64_t> cuts = split_by_cost(n_reads, parts, [&](int64_t r) { return (double)read_len[r] + 1.0; });
-    std::vector<std::vector<gbx_fmi_smem>> bufs((size_t)parts);
+    // (uninitialised: a vector's resize() would value-initialise 40 bytes per record slot on the shard's thread)
+    struct RawBuf { gbx_fmi_smem *p = nullptr; ~RawBuf() { free(p); } gbx_fmi_smem *data() { return p; }
+                    bool resize(size_t n) { free(p); p = (gbx_fmi_smem *)malloc((n ? n : 1) * sizeof(gbx_fmi_smem)); return p != nullptr; } };
+    std::vector<RawBuf> bufs((size_t)parts);
     std::vector<std::vector<int64_t>> offs((size_t)parts);
     std::vector<int64_t> counts((size_t)parts, 0);
     int rc = run_on_devices(parts, map, "gbx_fmi_smem_host", [&](int k) -> int {
@@ -273,10 +307,12 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
         std::vector<int64_t> ro((size_t)m);
         for (int64_t r = 0; r < m; ++r) ro[(size_t)r] = read_off[lo + r] - a0;
         offs[(size_t)k].resize((size_t)m + 1);
-        int64_t cap = (int64_t)((double)out_cap * (double)m / (double)n_reads * 1.25) + 4096;
+        // twice the shard's share of out_cap (SMEMs per read are uneven: repeats concentrate; a shard that still does not fit runs
+        // again with the exact size, which doubles that device's time - the margin is there to make it rare)
+        int64_t cap = (int64_t)((double)out_cap * (double)m / (double)n_reads * 2.0) + 4096;
         if (cap > out_cap) cap = out_cap;
         for (int attempt = 0;; ++attempt) {
-            bufs[(size_t)k].resize((size_t)cap);
+            if (!bufs[(size_t)k].resize((size_t)cap)) { set_error("gbx_fmi_smem_host: out of host memory"); return GBX_ERR_NOMEM; }
             int64_t got = 0;
             const int rc1 = fmi_host_one(idx, p, m, enc + a0, a1 - a0, ro.data(), read_len + lo, bufs[(size_t)k].data(), cap, offs[(size_t)k].data(), &got, lo);
             counts[(size_t)k] = got;

@@ -9,6 +9,7 @@
 // threads.  --print (the reference needs a PRINT_OUTPUT rebuild): the SMEMs in the format of fmi.cpp:312-343.
 // --parse-only stops after the ingest and prints counts and a checksum (no GPU needed).
 #include "driver_common.h"
+#include <algorithm>
 
 // The index tables FMI_search::load_index fills (reference_seq_len, count[5], sentinel_index, cp_occ[]), from either
 //   * bwa-mem2's own file <ref_file>.bwt.2bit.64 - the reference opens the index by prefix exactly like this (fmi.cpp:79-80;
@@ -42,6 +43,24 @@ static bool read_index(const char *ref_file, gbx_fmi_index &idx, std::vector<gbx
         const long at = ftell(f);
         fseek(f, 0, SEEK_END);
         const int64_t rest = (int64_t)ftell(f) - at - 8, n = idx.ref_seq_len;
+        if (rest + 8 == 5 * n) {
+            // one suffix-array sample per row and NO trailing sentinel_index (builds without SA compression that derive it on load):
+            // it is the row whose suffix starts at 0.  The file holds the samples' upper bytes (n), then their lower words (4 n).
+            std::vector<int8_t> ms((size_t)n);
+            std::vector<uint32_t> ls((size_t)1 << 20);
+            fseek(f, at, SEEK_SET);
+            bool found = fread(ms.data(), 1, (size_t)n, f) == (size_t)n, hit = false;
+            for (int64_t i = 0; found && i < n && !hit; i += (int64_t)ls.size()) {
+                const size_t m = (size_t)std::min<int64_t>((int64_t)ls.size(), n - i);
+                if (fread(ls.data(), 4, m, f) != m) { found = false; break; }
+                for (size_t k = 0; k < m; ++k) if (ls[k] == 0 && ms[(size_t)i + k] == 0) { idx.sentinel_index = i + (int64_t)k; hit = true; break; }
+            }
+            if (!found || !hit) { fprintf(stderr, "%s: no suffix-array sample is 0: cannot derive sentinel_index\n", path.c_str()); fclose(f); return false; }
+            for (int c = 0; c < 5; ++c) idx.count[c] += 1;
+            fprintf(stderr, "index: bwa-mem2 file %s (uncompressed suffix-array samples, sentinel_index %lld derived from them)\n", path.c_str(), (long long)idx.sentinel_index);
+            fclose(f);
+            return true;
+        }
         if (rest < 0 || rest % 5 || (rest / 5 != n && rest / 5 != (n >> 3) + 1)) {
             fprintf(stderr, "%s: %lld bytes of suffix-array samples fit neither published layout of a .bwt.2bit.64 file\n", path.c_str(), (long long)rest);
             fclose(f);

@@ -14,6 +14,8 @@
 // a reference driver whose OpenMP threads each hand over a small slice (bsw: 512 pairs) still uses every GPU.
 #pragma once
 #include <atomic>
+#include <exception>
+#include <new>
 #include <string>
 
 namespace gbx {
@@ -93,31 +95,47 @@ template <class CostFn> static std::vector<int64_t> split_by_cost(int64_t n, int
 }
 
 // fn(k) for k in [0, parts) on parts threads, thread k with device map[k] selected; returns the status of the lowest
-// failing shard and leaves its error text (with the shard named) as the calling thread's.
+// failing shard and leaves its error text (with the shard named, and how many others failed) as the calling thread's.
+// A C++ exception inside a shard (bad_alloc from its buffers) becomes GBX_ERR_NOMEM for that shard; a thread that cannot
+// be started makes its shard run on the calling thread after the others.
 template <class F> static int run_on_devices(int parts, const int *map, const char *who, F fn)
 {
     std::vector<int> rcs((size_t)parts, GBX_OK);
     std::vector<std::string> errs((size_t)parts);
     auto body = [&](int k) {
-        hipError_t e = hipSetDevice(map[k]);
-        int rc = e == hipSuccess ? fn(k) : hip_fail(e, "hipSetDevice");
+        int rc;
+        try {
+            const hipError_t e = hipSetDevice(map[k]);
+            rc = e == hipSuccess ? fn(k) : hip_fail(e, "hipSetDevice");
+        } catch (const std::bad_alloc &) {
+            set_error("%s: out of host memory", who);
+            rc = GBX_ERR_NOMEM;
+        } catch (const std::exception &ex) {
+            set_error("%s: %s", who, ex.what());
+            rc = GBX_ERR_NOMEM;
+        }
         rcs[(size_t)k] = rc;
         if (rc) errs[(size_t)k] = gbx_last_error();
     };
     int cur = 0;
     GBX_HIP(hipGetDevice(&cur));
     std::vector<std::thread> th;
-    for (int k = 1; k < parts; ++k) th.emplace_back(body, k);
+    std::vector<int> inline_shards;
+    for (int k = 1; k < parts; ++k) {
+        try { th.emplace_back(body, k); }
+        catch (const std::exception &) { inline_shards.push_back(k); }
+    }
     body(0);
+    for (int k : inline_shards) body(k);
     for (auto &t : th) t.join();
     (void)hipSetDevice(cur);
+    int first = -1, failed = 0;
     for (int k = 0; k < parts; ++k)
-        if (rcs[(size_t)k]) {
-            set_error("%s [shard %d of %d, device %d]", errs[(size_t)k].c_str(), k, parts, map[k]);
-            (void)who;
-            return rcs[(size_t)k];
-        }
-    return GBX_OK;
+        if (rcs[(size_t)k]) { if (first < 0) first = k; ++failed; }
+    if (first < 0) return GBX_OK;
+    if (failed > 1) set_error("%s [shard %d of %d, device %d; %d other shard(s) failed too]", errs[(size_t)first].c_str(), first, parts, map[first], failed - 1);
+    else set_error("%s [shard %d of %d, device %d]", errs[(size_t)first].c_str(), first, parts, map[first]);
+    return rcs[(size_t)first];
 }
 
 }  // namespace gbx

@@ -262,6 +262,24 @@ def test_fmi_index_file_roundtrip_and_parallel_ingest(fmi_data):
             assert got["reads"] == rs.n_reads and got["max_readlength"] == L and got["fnv1a"] == want, (name, t)
 
 
+def test_fmi_driver_derives_the_sentinel_of_a_trailerless_index(fmi_data, tmp_path):
+    """A .bwt.2bit.64 with one suffix-array sample per row and no trailing sentinel_index (what a build without SA compression
+    that derives the sentinel on load would write): the driver finds the row whose sample is 0."""
+    from genomicsbench_amd import fmi as FM
+    d, idx, _ = fmi_data
+    n = idx.ref_seq_len
+    sa = np.arange(1, n + 1, dtype=np.int64)                        # (only which sample is 0 matters to the reader)
+    sa[idx.sentinel_index] = 0
+    path = FM.save_bwa_mem2_index(idx, str(tmp_path / "plain.fa"), sa=sa, sa_compx=0)
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 8)
+    r = run([os.path.join(BIN, "fmi"), "--index-info", path])
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    own = json.loads(run([os.path.join(BIN, "fmi"), "--index-info", str(d / "genome.gbxfmi")]).stdout)
+    assert got == own and "derived" in r.stderr
+
+
 def test_fmi_driver_reads_a_bwa_mem2_index_by_prefix(fmi_data, tmp_path):
     """The reference opens the index by prefix (fmi.cpp:79-80: FMI_search(argv[1]), load_index() reads
     <prefix>.bwt.2bit.64).  save_bwa_mem2_index writes that layout as published (both sizes of the suffix-array sample
