@@ -1024,8 +1024,14 @@ __device__ unsigned long long g_tb_fast, g_tb_slow, g_tb_fill;
 // are rebuilt from its H by two tilted prefix-max scans, E(i,j) = max_{k<j} H(i,k) + g + (j-1-k) e (same
 // for Q with q, c) - the same integers the DP had, since H is final - one row load and ~60 instructions,
 // cached per row.  Otherwise identical to poa_traceback (poa_graph.h), which serves the stored-E/Q path.
+// LD (the team kernel): the row descriptors - first four predecessor rows, letter and in-degree, node - are read from a copy in LDS
+// (ldesc: six arrays of n 16-bit entries; the team's row ring is free once the DP is done).  A step of the general path begins with
+// its row's descriptor and the rows of its further predecessors (two dependent loads each, through the in-edge list): on a lone
+// wavefront every one of those was a round trip to memory.
+typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
+template <bool LD = false>
 __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len,
-                                   int max_i, int max_j)
+                                   int max_i, int max_j, lds_cu16 *ldesc = nullptr, int ldn = 0)
 {
     g.n_path = 0;
     if (max_i == -1 && max_j == -1) return;
@@ -1033,6 +1039,11 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     const int lane = threadIdx.x & 63;
     const int Wp = M.Wp;
     const int32_t *rd_pred = g.score, *rd_info = g.pred;
+    auto desc_p0 = [&](int r) -> int { return LD ? (int)ldesc[r] : rd_pred[r]; };
+    auto d_info_of = [&](int r) -> int { return LD ? (int)ldesc[4 * ldn + r] : rd_info[r]; };      // (letter | in-degree << 8: the sink bit is not needed here)
+    auto d_node_of = [&](int r) -> int { return LD ? (int)ldesc[5 * ldn + r] : g.r2n[r]; };
+    // DP row of in-edge source p >= 1 of the node of rank r
+    auto pred_row = [&](int r, int node, int p) -> int { return LD && p < 4 ? (int)ldesc[p * ldn + r] : g.n2r[PG_IN_SRC(g, node, p)] + 1; };
     const int j0 = lane * CPL + 1;
     (void)len;
     int eq_row = -1;
@@ -1123,7 +1134,7 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         const int row = max(oi - 1 - (lane >> 3), 0), col = max(oj - 1 - (lane & 7), 0);
         bH = PG_AT(M.H, row, col);
         const int dr = max(row - 1, 0);
-        bP0 = rd_pred[dr]; bInfo = rd_info[dr]; bNode = g.r2n[dr];
+        bP0 = desc_p0(dr); bInfo = d_info_of(dr); bNode = d_node_of(dr);
         bS = seq[col];
     };
     while (!(i == 0 && j == 0)) {
@@ -1158,21 +1169,37 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         bool hn_known = false, dn_first = false;          // next step: H known / descriptor = the prefetched one
         if (i != 0) {
             if (d_known) { p0 = d_p0; info = d_info; node = d_node; }
-            else { p0 = rd_pred[i - 1]; info = rd_info[i - 1]; node = g.r2n[i - 1]; }
+            else { p0 = desc_p0(i - 1); info = d_info_of(i - 1); node = d_node_of(i - 1); }
             ic = (info >> 8) & 0xff;
             const int pr = p0 > 0 ? p0 - 1 : 0;            // descriptor of the first predecessor's row, in flight with its cell
-            n_p0 = rd_pred[pr]; n_info = rd_info[pr]; n_node = g.r2n[pr];
+            n_p0 = desc_p0(pr); n_info = d_info_of(pr); n_node = d_node_of(pr);
             if (j != 0) {
                 const int mc = (info & 0xff) == seq[j - 1] ? S.m : S.n;
-                for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
-                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                int pfirst = 0;
+#ifndef GBX_POA_TB_BATCH
+#define GBX_POA_TB_BATCH 0            // measured (profiles/r05o_poa_team_tb_ab.txt): 56.8 against 55.3 ms for a lone window - most general steps end at the first predecessor; off
+#endif
+                if (LD && GBX_POA_TB_BATCH) {
+                    // the diagonal cells of the first four predecessors in ONE round trip: their rows come out of LDS, so the loads
+                    // do not depend on each other (through memory each row took two dependent loads first: the loop below)
+                    const int icc = ic ? ic : 1;
+                    int pis[4], hds[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { pis[p] = p && p < icc ? pred_row(i - 1, node, p) : p0; hds[p] = PG_AT(M.H, pis[p], j - 1); }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (!found && p < icc && Hij == hds[p] + mc) { prev_i = pis[p]; prev_j = j - 1; found = true; Hnext = hds[p]; hn_known = true; dn_first = p == 0 && p0 > 0; }
+                    pfirst = 4;
+                }
+                for (int p = pfirst; p < (ic ? ic : 1) && !found; ++p) {
+                    const int pi = p ? pred_row(i - 1, node, p) : p0;
                     const int hd = PG_AT(M.H, pi, j - 1);
                     if (Hij == hd + mc) { prev_i = pi; prev_j = j - 1; found = true; Hnext = hd; hn_known = true; dn_first = p == 0 && p0 > 0; }
                 }
             }
             if (!found) {
                 for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
-                    const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
+                    const int pi = p ? pred_row(i - 1, node, p) : p0;
                     const int hv = PG_AT(M.H, pi, j), fv = fo_at(pi, j, hv, 0), ov = fo_at(pi, j, hv, 1);
                     const bool c1 = Hij == fv + S.e;
                     const bool c2 = !c1 && Hij == hv + S.g;
@@ -1214,12 +1241,12 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
                 if (GBX_GUARD_TRIP(gd_up, GBX_GK_POA, 2, i)) { g.err |= POA_ERR_STACK; break; }
                 bool stop = false;
                 prev_i = 0;
-                const int nd = g.r2n[i - 1];
-                const int icu = (rd_info[i - 1] >> 8) & 0xff;
+                const int nd = d_node_of(i - 1);
+                const int icu = (d_info_of(i - 1) >> 8) & 0xff;
                 const int hij = PG_AT(M.H, i, j);
                 const int fij = fo_at(i, j, hij, 0), oij = fo_at(i, j, hij, 1);
                 for (int p = 0; p < icu; ++p) {
-                    const int pi = p ? g.n2r[PG_IN_SRC(g, nd, p)] + 1 : rd_pred[i - 1];
+                    const int pi = p ? pred_row(i - 1, nd, p) : desc_p0(i - 1);
                     const int hv = PG_AT(M.H, pi, j);
                     const bool s1 = fij == hv + S.g;
                     const bool s2 = !s1 && fij == fo_at(pi, j, hv, 0) + S.e;
@@ -2049,10 +2076,26 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
                 __builtin_amdgcn_s_setprio(0);
                 if (piped) poa_dp_team<NW, POA_TEAM_RR, POA_TEAM_K>(g, M, A, seq, len, n_nodes, lds_raw, sy, wave, mi, mj);
                 else if (wave == 0) poa_dp<8>(g, M, A, seq, len, mi, mj);
+                // the row descriptors into the ring's LDS for the traceback (the path it writes shares memory with two of them)
+#ifndef GBX_POA_TB_NOLDS
+#define GBX_POA_TB_NOLDS 0            // tuning aid: 1 = the team's traceback reads its descriptors from memory, as the one-wavefront kernel's
+#endif
+                const bool ld = piped && !GBX_POA_TB_NOLDS && n_nodes * 12 <= POA_TEAM_RING_BYTES;
+                if (ld) {
+                    typedef __attribute__((address_space(3))) unsigned short lds_u16;
+                    lds_u16 *const ldw = (lds_u16 *)(lds_u8 *)lds_raw;
+                    for (int r = threadIdx.x; r < n_nodes; r += 64 * NW) {
+                        ldw[r] = (unsigned short)g.score[r]; ldw[n_nodes + r] = (unsigned short)g.path_node[r];
+                        ldw[2 * n_nodes + r] = (unsigned short)g.path_pos[r]; ldw[3 * n_nodes + r] = (unsigned short)g.stack[r];
+                        ldw[4 * n_nodes + r] = (unsigned short)g.pred[r]; ldw[5 * n_nodes + r] = (unsigned short)g.r2n[r];
+                    }
+                    __syncthreads();
+                }
                 PH_ACC(t_dp)
                 if (wave == 0) {
                     __builtin_amdgcn_s_setprio(3);
-                    if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
+                    if (ld) poa_traceback_wave<true>(g, M, A.S, seq, len, mi, mj, (lds_cu16 *)(lds_u8 *)lds_raw, n_nodes);
+                    else if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                     else poa_traceback(g, M, A.S, seq, mi, mj);
                     PH_ACC(t_tb)
 #ifdef GBX_POA_PHASE_STATS
