@@ -722,7 +722,7 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
 // wavefront ran; units of 256.
 __device__ unsigned long long g_bsw_lane_stats[16][4];
 #endif
-template <bool SYM, bool COMPACT>
+template <bool SYM, bool COMPACT, bool CODE4 = false>
 __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, BswWork W, int rlo, int rhi, int cols, int slot)
 {
     extern __shared__ uint32_t lcell[];
@@ -743,11 +743,23 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
     // compact: cell of column j = halfword at (j >> 1) * 256 + lane * 4 + (j & 1) * 2; query code of column j = byte at
     //          qb + (j >> 1) * 128 + (j & 1)
     const int cb = lane * 4;
-    const int qb = (cols >> 1) * 256 + (lane & 31) * 4 + (lane >> 5) * 2;       // cols is even
+    // CODE4 (round 5, the two longest compact classes): the query codes of a column pair FOUR bits each, a byte per pair and lane - 2.5
+    // instead of 3 bytes of LDS per column and lane: 7 instead of 6 wavefronts of the 100..135 class per CU, 6 instead of 5 of the
+    // class above - for three more instructions per column pair that expand the byte into the v_perm_b32 selector.  Measured
+    // (profiles/r05p_bsw_query_codes_ab.txt): the step's loop alone 1 094 -> 1 243 G cells/s at those occupancies; in the job the
+    // 100..135 launch 16 % shorter in isolation, the 80..99 and 48..79 launches 7 % and 2 % LONGER (they have the wavefronts already,
+    // and 64-byte rows let lanes of a quad that stand two pairs apart meet in an LDS bank): so only where it pays.  A conflict-free
+    // form (the codes of four pairs as one dword per lane, lined up by v_alignbit_b32) was slower than either: the job as a whole
+    // runs at 80 % of its VALU issue bound, and that form's extra instructions are paid by every class.
+    constexpr int QROW = CODE4 ? 64 : 128;                      // bytes of the code plane per column pair
+    const int qb = (cols >> 1) * 256 + (CODE4 ? lane : (lane & 31) * 4 + (lane >> 5) * 2);       // cols is even; halfwords: bank = lane & 31 for any column
+    auto LQREAD = [&](int a) -> uint32_t { return CODE4 ? (uint32_t)LQ8(a) : (uint32_t)LCELL16(a); };
+    auto QSEL = [](uint32_t q) -> uint32_t { return CODE4 ? (((q >> 4) << 8) | (q & 15u)) : q; };
+    auto QLOW = [](uint32_t q) -> uint32_t { return CODE4 ? (q & 15u) : (q & 0xffu); };
     auto cell_at = [&](int j) { return COMPACT ? (j >> 1) * 256 + cb + (j & 1) * 2 : j * 256 + cb; };
     // the scoring matrix by target base, behind the planes: {bytes against A C G T, byte against N, 6-bit fields (wide format), -}
     // (in the last 128 bytes of the look-ahead rows: nothing is written there, and what a look-ahead load reads is not used)
-    const int tab = COMPACT ? (cols >> 1) * 384 + 512 : (cols + 2) * 256 - 128;
+    const int tab = COMPACT ? (cols >> 1) * (256 + QROW) + 512 : (cols + 2) * 256 - 128;
     if (lane < 5) *(uint4 *)((char *)lcell + tab + lane * 16) = make_uint4(prm.row0[lane], prm.row1[lane], prm.lrow[lane], 0u);
 #define LTAB(base_code) (*(const uint4 *)((const char *)lcell + tab + min((int)(base_code), 4) * 16))
     int rel0 = 0, rel1 = 2, rel2 = 256, rel3 = 258, rel4 = 512, rel5 = 514, rel6 = 768, rel7 = 770;      // cell offsets within a trip of the main loop
@@ -788,7 +800,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                         if (COMPACT) {
                             // (cell j + 1 may lie one past qlen: it exists - look-ahead rows - and is never live)
                             LCELL((j >> 1) * 256 + cb) = ((uint32_t)hv0 << 8) | ((uint32_t)hv1 << 24);
-                            LCELL16(qb + (j >> 1) * 128) = (uint16_t)(c0 | (c1 << 8));
+                            if (CODE4) LQ8(qb + (j >> 1) * QROW) = (uint8_t)(c0 | (c1 << 4));
+                            else LCELL16(qb + (j >> 1) * QROW) = (uint16_t)(c0 | (c1 << 8));
                         } else {
                             LCELL(cell_at(j)) = ((uint32_t)hv0 << 18) | (uint32_t)(c0 * 6);
                             if (j + 1 <= qlen) LCELL(cell_at(j + 1)) = ((uint32_t)hv1 << 18) | (uint32_t)(c1 * 6);
@@ -852,34 +865,34 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
                 // cycles under load and the wavefront has nothing else to do meanwhile).  Two register sets take turns, so
                 // nothing is copied.  Loads past the window read cells that exist (look-ahead rows are part of the allocation)
                 // and are not used.
-                int pa = (j >> 1) * 256 + cb, qa = qb + (j >> 1) * 128;
-                uint32_t w0 = LCELL(pa), q0 = LCELL16(qa), w1 = LCELL(pa + 256), q1 = LCELL16(qa + 128);
+                int pa = (j >> 1) * 256 + cb, qa = qb + (j >> 1) * QROW;
+                uint32_t w0 = LCELL(pa), q0 = LQREAD(qa), w1 = LCELL(pa + 256), q1 = LQREAD(qa + QROW);
                 w0 &= odd_first ? 0xffff0000u : 0xffffffffu;
-                for (; j + 7 < end; j += 8, pa += 1024, qa += 512) {
-                    const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256), x1 = LCELL(pa + 768), y1 = LCELL16(qa + 384);
+                for (; j + 7 < end; j += 8, pa += 1024, qa += 4 * QROW) {
+                    const uint32_t x0 = LCELL(pa + 512), y0 = LQREAD(qa + 2 * QROW), x1 = LCELL(pa + 768), y1 = LQREAD(qa + 3 * QROW);
                     uint32_t kt;                            // the trip's maximum, positions relative to pa (eight constant registers)
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, (uint32_t)vzero, kt, rel0, rel1, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, kt, kt, rel2, rel3, vzero, oe_del, oe_ins, e_del, e_ins);
-                    w0 = LCELL(pa + 1024); q0 = LCELL16(qa + 512); w1 = LCELL(pa + 1280); q1 = LCELL16(qa + 640);
-                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, y0, rw, rwn, f, left, kt, kt, rel4, rel5, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, y1, rw, rwn, f, left, kt, kt, rel6, rel7, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, QSEL(q0), rw, rwn, f, left, (uint32_t)vzero, kt, rel0, rel1, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, QSEL(q1), rw, rwn, f, left, kt, kt, rel2, rel3, vzero, oe_del, oe_ins, e_del, e_ins);
+                    w0 = LCELL(pa + 1024); q0 = LQREAD(qa + 4 * QROW); w1 = LCELL(pa + 1280); q1 = LQREAD(qa + 5 * QROW);
+                    LCELL(pa + 512) = lane_pair_step<SYM>(x0, QSEL(y0), rw, rwn, f, left, kt, kt, rel4, rel5, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 768) = lane_pair_step<SYM>(x1, QSEL(y1), rw, rwn, f, left, kt, kt, rel6, rel7, vzero, oe_del, oe_ins, e_del, e_ins);
                     key = max(key, kt + (uint32_t)pa);
                 }
                 if (j + 3 < end) {
-                    const uint32_t x0 = LCELL(pa + 512), y0 = LCELL16(qa + 256);
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
-                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, q1, rw, rwn, f, left, key, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
+                    const uint32_t x0 = LCELL(pa + 512), y0 = LQREAD(qa + 2 * QROW);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, QSEL(q0), rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa + 256) = lane_pair_step<SYM>(w1, QSEL(q1), rw, rwn, f, left, key, key, pa + 256, pa + 258, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = x0; q0 = y0;
-                    w1 = LCELL(pa + 768); q1 = LCELL16(qa + 384);
-                    j += 4; pa += 512; qa += 256;
+                    w1 = LCELL(pa + 768); q1 = LQREAD(qa + 3 * QROW);
+                    j += 4; pa += 512; qa += 2 * QROW;
                 }
                 if (j + 1 < end) {
-                    LCELL(pa) = lane_pair_step<SYM>(w0, q0, rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
+                    LCELL(pa) = lane_pair_step<SYM>(w0, QSEL(q0), rw, rwn, f, left, key, key, pa, pa + 2, vzero, oe_del, oe_ins, e_del, e_ins);
                     w0 = w1; q0 = q1;
-                    j += 2; pa += 256; qa += 128;
+                    j += 2; pa += 256; qa += QROW;
                 }
                 if (j < end) {                             // even last column: the low half of its dword, alone
-                    LCELL16(pa) = (uint16_t)step((int)((w0 >> 8) & 0xffu), (int)(w0 & 0xffu), q0 & 0xffu, pa);
+                    LCELL16(pa) = (uint16_t)step((int)((w0 >> 8) & 0xffu), (int)(w0 & 0xffu), QLOW(q0), pa);
                 }
                 LCELL16(cell_at(end)) = (uint16_t)(left << 8);                   // eh[end] = {h1, 0}, :213
                 // The next window (:230-233) starts at the first non-zero cell from beg on and ends two past the last one up to
@@ -1268,7 +1281,10 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                 const int cols = (qhi + 3) & ~1;                   // columns 0..qlen, and even
                 // compact: cols / 2 dword rows of cells, cols / 2 halfword rows of query codes, and what the look-ahead of the
                 // query plane reads past its end (the cells' look-ahead lands in the query plane); wide: 2 columns of look-ahead
-                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * 384 + 640;
+                // (four-bit query codes for the two longest compact classes: see bsw_lane_kernel; GBX_BSW_CODE4=0 / 1 forces none / all)
+                const char *c4e = getenv("GBX_BSW_CODE4");
+                const bool code4 = fmt == 0 && (c4e ? atoi(c4e) != 0 : qhi > 99);
+                const size_t lds = fmt ? (size_t)(cols + 2) * 256 : (size_t)(cols / 2) * (code4 ? 320 : 384) + 640;
                 int per_cu = (int)((size_t)160 * 1024 / lds);
                 if (per_cu > 16) per_cu = 16;
                 const int sk = (nl - 1) & 3;
@@ -1277,7 +1293,10 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                 if (blocks > want) blocks = want;
                 const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
                 Stage st(names[fmt][r], sc);
-                if (fmt == 0) {
+                if (fmt == 0 && code4) {
+                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                } else if (fmt == 0) {
                     if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
                     else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
                 } else {

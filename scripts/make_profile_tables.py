@@ -37,7 +37,7 @@ def stage_name(kname):
     m = re.match(r"bsw_rows_kernel<(\d+), (\d+), \w+>", kname)
     if m:
         return "bsw_rows_%sx%s" % (m.group(1), m.group(2))
-    m = re.match(r"bsw_lane_kernel<\w+, (\w+)>(?:@(\d+))?", kname)
+    m = re.match(r"bsw_lane_kernel<\w+, (\w+)(?:, \w+)?>(?:@(\d+))?", kname)
     if m:
         # one symbol, five launches per format: the launch is identified by its grid = resident blocks per CU, which
         # follows from its LDS size (bsw_kernels.hip: bsw_launch; scripts/pmc_summary.py appends it to the name)
@@ -45,7 +45,7 @@ def stage_name(kname):
             return "bsw_lane_compact" if m.group(1) == "true" else "bsw_lane_wide"
         per_cu = int(m.group(2))
         if m.group(1) == "true":
-            return "bsw_lane_c%d" % {16: 47, 10: 79, 8: 99, 6: 135, 5: 159}.get(per_cu, 0)
+            return "bsw_lane_c%d" % {16: 47, 10: 79, 8: 99, 7: 135, 6: 159}.get(per_cu, 0)
         return "bsw_lane_w%d" % {14: 39, 7: 79, 5: 103, 4: 127, 3: 159}.get(per_cu, 0)
     m = re.match(r"phmm_stream_kernel<(\d+)>", kname)
     if m:
