@@ -417,8 +417,12 @@ __global__ void __launch_bounds__(64, 4) abea_kernel(AbeaArgs A)
             while ((ck | ce) >= 0 && (bi >> 2) == grp) {
                 const unsigned byte = (unsigned)__builtin_amdgcn_readlane((int)comp, off >> 1) >> ((bi & 3) << 3);
                 const unsigned from = (byte >> ((off & 1) << 1)) & 3u;      // 0 diagonal, 1 up, 2 left (:455-470)
-                // (3 is no move: the band loop never writes it; a walk that met one would stand still for ever)
+#ifdef GBX_LOOP_GUARD
+                // (3 is no move: the band loop never writes it; a walk that met one would stand still for ever.  Guard build only: in
+                // the product build this one test cost the kernel two spilled vector registers and a fifth of its speed - 48.5 against
+                // 39.6 ms on 'large' - although the walk is a hundredth of a read's time: the band loop's allocation shifted)
                 if (from == 3u || GBX_GUARD_TRIP(gd_tb, GBX_GK_ABEA, 1, r)) { ck = -1; break; }
+#endif
                 codes |= from << (cnt << 1);
                 cnt += 1;
                 last_ck = ck;

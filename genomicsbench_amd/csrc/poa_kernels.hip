@@ -167,15 +167,29 @@ __device__ inline void store_cells(poa_cell_t *p, const int *in)
     }
 }
 
-template <int CPL>
+// (the team's words in LDS: poa_dp_team below, and the column-block DP when a team runs it)
+struct PoaTeamSync {
+    int prog[4];                 // last DP row (1-based) wavefront w has completed
+    int best[4], best_i[4];      // best sink score of wavefront w's rows and its row
+    int n_nodes, err, widx, pad_;    // the team's view of the window: graph size and error bits after the last add_alignment, work item
+};
+typedef __attribute__((address_space(3))) PoaTeamSync lds_team;
+typedef __attribute__((address_space(3))) int lds_i32;
+
+// NW > 1 (round 5, the long windows of a team launch): the rows go to the NW wavefronts of the workgroup in turn, a row starts when its
+// predecessor rows are complete (sy->prog, as in poa_dp_team) and is complete once its stores are acknowledged - this DP already ends
+// every row waiting for them.  n_team = the graph's size (only wavefront 0's PoaGraph knows it).
+template <int CPL, int NW = 1>
 __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
-                       int &max_i, int &max_j)
+                       int &max_i, int &max_j, lds_team *sy = nullptr, int wave = 0, int n_team = 0)
 {
     static_assert(CPL == 8 || CPL == 16, "a lane owns one or two 16-byte vectors of cells");
     const int lane = threadIdx.x & 63;
+    const int tid = NW > 1 ? (int)threadIdx.x : lane;
+    constexpr int NT = 64 * NW;
     const PoaScore S = A.S;
     const int Wp = M.Wp;
-    const int n = g.n_nodes;
+    const int n = NW > 1 ? n_team : g.n_nodes;
     constexpr int BLK = 64 * CPL;
     const Mat2 *Tc = A.Tc[CPL == 8 ? 0 : 1];
     // lane-dependent max-plus matrices: Tc^(lane&15 + 1), Tc^(lane&31 + 1), Tc^lane
@@ -184,7 +198,7 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
     const Mat2 PC = mp_pow(Tc[0], lane);
 
     // row 0 (sisd_alignment_engine `initialize`) and the row descriptors
-    for (int j = lane; j <= len; j += 64) {
+    for (int j = tid; j <= len; j += NT) {
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
         M.E[j + POA_COL0] = (poa_cell_t)e0; M.Q[j + POA_COL0] = (poa_cell_t)q0;
         M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
@@ -193,10 +207,15 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
     int32_t *d_pred = g.score, *d_info = g.pred;       // [rank] first predecessor row | letter, in-degree, sink
     {
         PoaGraph &gm = const_cast<PoaGraph &>(g);
-        for (int r = lane; r < n; r += 64) poa_rowdesc_one(gm, r);
+        for (int r = tid; r < n; r += NT) poa_rowdesc_one(gm, r);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (NW > 1) {
+        if (wave == 0 && lane < NW) sy->prog[lane] = 0;
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     const bool single = len <= BLK;
     int sq[CPL];
@@ -209,17 +228,32 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
     int best = POA_NEG_INF;
     max_i = -1; max_j = -1;
     const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;   // 2nd / 3rd predecessor rows (free until the traceback)
-    int nx_pred = n ? d_pred[0] : 0, nx_info = n ? d_info[0] : 0, nx_p1 = n ? d_pred1[0] : 0, nx_p2 = n ? d_pred2[0] : 0;
-    for (int r = 0; r < n; ++r) {
+    const int r0 = NW > 1 ? wave : 0;
+    int nx_pred = n > r0 ? d_pred[r0] : 0, nx_info = n > r0 ? d_info[r0] : 0, nx_p1 = n > r0 ? d_pred1[r0] : 0, nx_p2 = n > r0 ? d_pred2[r0] : 0;
+    for (int r = r0; r < n; r += NW) {
         const int i = r + 1;
         const int p0 = nx_pred, info = nx_info, p1 = nx_p1, p2 = nx_p2;
-        if (r + 1 < n) { nx_pred = d_pred[r + 1]; nx_info = d_info[r + 1]; nx_p1 = d_pred1[r + 1]; nx_p2 = d_pred2[r + 1]; }   // prefetch
+        if (r + NW < n) { nx_pred = d_pred[r + NW]; nx_info = d_info[r + NW]; nx_p1 = d_pred1[r + NW]; nx_p2 = d_pred2[r + NW]; }   // prefetch
         const int letter = info & 0xff, ic = (info >> 8) & 0xff;
         const bool sink = (info >> 16) & 1;
         const int64_t ro = (int64_t)i * Wp + POA_COL0;                             // index of (i, 0)
         // predecessor rows: the first three from the descriptors, any further ones from the in-edge list
         const int node = ic > 3 ? g.r2n[r] : 0;
         auto pred_row = [&](int k) { return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : g.n2r[PG_IN_SRC(g, node, k)] + 1; };
+        if (NW > 1) {
+            // wait for the predecessor rows: lane l (mod NW) for those wavefront l mod NW owns
+            const int own = lane & (NW - 1);
+            auto need_of = [&](int x) { return ((x - 1) & (NW - 1)) == own ? x : 0; };
+            int need = 0;
+            for (int k = 0; k < ic; ++k) need = max(need, need_of(__builtin_amdgcn_readfirstlane(pred_row(k))));
+            lds_i32 *const pm = (lds_i32 *)&sy->prog[own];
+            GBX_GUARD(gd_wait, 1 << 24);
+            while (__ballot(*(volatile lds_i32 *)pm < need) != 0) {
+                if (GBX_GUARD_TRIP(gd_wait, GBX_GK_POA, 6, i)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");                       // nothing of the rows waited for is read before this point
+        }
         int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
         {
             // column 0 of up to three predecessor rows: independent loads, one round trip
@@ -321,9 +355,27 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
                 hlast = __builtin_amdgcn_readlane(hv, (len - 1 - base) / CPL);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (NW > 1) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the row is in memory for the other wavefronts
+            asm volatile("" ::: "memory");
+            if (lane == 0) *(volatile lds_i32 *)&sy->prog[wave] = i;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (sink && best < hlast) { best = hlast; max_i = i; max_j = len; }       // NW: best sink at the last column
+    }
+    if (NW > 1) {
+        // the team's best sink: ties go to the first row in topological order (the serial loop's strict `<`)
+        if (lane == 0) { sy->best[wave] = best; sy->best_i[wave] = max_i; }
+        __syncthreads();
+        int b = POA_NEG_INF, bi = -1;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int v = *(volatile lds_i32 *)&sy->best[w], vi = *(volatile lds_i32 *)&sy->best_i[w];
+            if (vi != -1 && (bi == -1 || v > b || (v == b && vi < bi))) { b = v; bi = vi; }
+        }
+        max_i = bi; max_j = bi == -1 ? -1 : len;
     }
 }
 
@@ -730,13 +782,6 @@ __device__ __attribute__((always_inline)) void poa_dp_pipelined(const PoaGraph &
 //     (all wavefronts of a workgroup share the CU's vector L1, which is write-through).
 // A waiting wavefront sleeps (s_sleep) and polls one LDS word per owner; the smallest incomplete row never waits for anything, so the
 // team always makes progress.
-struct PoaTeamSync {
-    int prog[4];                 // last DP row (1-based) wavefront w has completed
-    int best[4], best_i[4];      // best sink score of wavefront w's rows and its row
-    int n_nodes, err, widx, pad_;    // the team's view of the window: graph size and error bits after the last add_alignment, work item
-};
-typedef __attribute__((address_space(3))) PoaTeamSync lds_team;
-typedef __attribute__((address_space(3))) int lds_i32;
 
 template <int NW, int RR, int K>
 __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len, int n,
@@ -883,6 +928,7 @@ __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, co
                 if (GBX_GUARD_TRIP(gd_wait, GBX_GK_POA, 4, i)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            asm volatile("" ::: "memory");                       // nothing of the rows waited for is read before this point
         }
         PoaPredIn in0, in1;
         fetch_pred(ic >= 1 ? sp0 : 0, i, in0);
@@ -921,6 +967,7 @@ __device__ __attribute__((always_inline)) void poa_dp_team(const PoaGraph &g, co
                         if (done(pv, prow) || GBX_GUARD_TRIP(gd_wait5, GBX_GK_POA, 5, i)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    asm volatile("" ::: "memory");
                 }
                 PoaPredIn x;
                 fetch_pred(prow, i, x);
@@ -2075,7 +2122,7 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
                 PH_T0
                 __builtin_amdgcn_s_setprio(0);
                 if (piped) poa_dp_team<NW, POA_TEAM_RR, POA_TEAM_K>(g, M, A, seq, len, n_nodes, lds_raw, sy, wave, mi, mj);
-                else if (wave == 0) poa_dp<8>(g, M, A, seq, len, mi, mj);
+                else poa_dp<8, NW>(g, M, A, seq, len, mi, mj, sy, wave, n_nodes);          // column blocks; the rows shared out like the team DP's
                 // the row descriptors into the ring's LDS for the traceback (the path it writes shares memory with two of them)
 #ifndef GBX_POA_TB_NOLDS
 #define GBX_POA_TB_NOLDS 0            // tuning aid: 1 = the team's traceback reads its descriptors from memory, as the one-wavefront kernel's

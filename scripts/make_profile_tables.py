@@ -104,7 +104,7 @@ def main():
                 wide = name.startswith(WIDE_READS)
                 traffic[name] = {"fetch_raw": int(f), "write": int(w), "fetch_factor": 2 if wide else 1, "bytes": int(f * (2 if wide else 1) + w)}
             if "valu_busy" in v:
-                busy[name] = v["valu_busy"]
+                busy[name] = min(1.0, v["valu_busy"])       # (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles overshoots by a few per cent on saturated kernels: never a fraction above 1)
             if "SQ_INSTS_VALU" in v:
                 insts[name] = int(v["SQ_INSTS_VALU"])
     note = ("rocprofv3 --pmc, separate passes per counter group (scripts/pmc.sh), default 'large' sizes, tag %s; units and the gfx950 "
