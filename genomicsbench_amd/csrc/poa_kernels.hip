@@ -70,6 +70,7 @@ struct PoaArgs {
     int ncap, deg, lmax;
     int lds_marks;                    // 1: mark/check/DFS stack live in LDS (dynamic shared memory)
     int lds_stack;                    // entries of the DFS stack in LDS (poa_lds_plan)
+    int lds_ncap;                     // nodes the sort's per-node LDS arrays hold (<= ncap): a window that outgrows it sorts in global memory
     PoaScore S;
     Mat2 Tc[2][4];                    // [CPL 8 | CPL 16][(T^CPL)^(1,2,4,8)]: uniform factors of the row_shr scan steps
 };
@@ -1398,6 +1399,7 @@ struct PoaTopoLds {
     lds_s16 *obuf;           // [POA_OBUF_SHORTS] the newest entries of the order, flushed to global memory 64 at a time
     int n_sorted;            // nodes ranked by the previous sort
     int flags_ok;            // the root flags in st8 describe the previous order (not after a sort that ran in global memory)
+    int cap;                 // nodes st8 / old hold (PoaArgs::lds_ncap)
     int use;                 // 0: the node capacity does not fit LDS, the global-memory sort runs instead (a null test
                              // will not do: LDS offset 0 is a valid address, and the LDS null pointer is not 0)
 };
@@ -1715,6 +1717,9 @@ __device__ __attribute__((always_inline)) void poa_add_alignment_wave(PoaGraph &
 {
     if (len == 0) return;
     const int lane = threadIdx.x & 63;
+    // (round 5) the sort's LDS arrays hold T.cap nodes - what lets twelve (or sixteen) windows share a CU, not the graph's capacity: a
+    // window that may outgrow them with this sequence (every base a new node at worst) sorts in global memory from here on
+    if (T.use && g.n_nodes + len > T.cap) { T.use = 0; T.flags_ok = 0; }
     // letter codes, in order of first appearance in the sequence
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;
@@ -1939,7 +1944,7 @@ __device__ __attribute__((always_inline)) inline void poa_bind_graph(PoaGraph &g
 // serial DFS state on chip (LDS): state byte per node, order under construction, stack
 __device__ __attribute__((always_inline)) inline void poa_bind_lds(PoaTopoLds &T, char *lds_raw, const PoaArgs &A)
 {
-    const int ncp = (A.ncap + 15) & ~15;
+    const int ncp = (A.lds_ncap + 15) & ~15;
     lds_u8 *const lds0 = (lds_u8 *)lds_raw;
     // fixed-size arrays first, at compile-time offsets (the per-node arrays behind them need the node capacity): the
     // bases then fold into the ds instructions' offset fields instead of living in (spilled) scalar registers
@@ -1947,7 +1952,7 @@ __device__ __attribute__((always_inline)) inline void poa_bind_lds(PoaTopoLds &T
     T.rec = (lds_s16 *)(lds0 + POA_LDS_STACK16 * 2);
     T.obuf = T.rec + 64 * POA_REC_SHORTS;
     T.st8 = lds0 + POA_LDS_FIXED;
-    T.use = A.lds_marks;
+    T.use = A.lds_marks; T.cap = A.lds_ncap;
     T.old = (lds_s16 *)(lds0 + POA_LDS_FIXED + ncp);
     T.stk_cap = A.lds_stack;
     T.n_sorted = 0; T.flags_ok = 0;
@@ -1991,7 +1996,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
         if (q32 >= nwork) break;
         const int64_t w = (int64_t)A.wlist[q32];
         poa_graph_reset(g);
-        T.n_sorted = 0; T.flags_ok = 0;
+        T.n_sorted = 0; T.flags_ok = 0; T.use = A.lds_marks;
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
         for (int64_t s = s0; s < s1; ++s) {
             const uint8_t *seq = A.arena + A.seq_off[s];
@@ -2103,7 +2108,7 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
         const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane(*(volatile lds_i32 *)&sy->widx);
         if (q32 >= nwork) break;
         const int64_t w = (int64_t)A.wlist[q32];
-        if (wave == 0) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; }
+        if (wave == 0) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; T.use = A.lds_marks; }
         int n_nodes = 0, err = 0;                                  // the team's view of the graph (wavefront 0 owns the PoaGraph registers)
         const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
         for (int64_t s = s0; s < s1; ++s) {
@@ -2244,8 +2249,9 @@ __device__ __attribute__((noinline)) PoaWinState poa_serial_call(PoaWinState st,
     poa_bind_lds(T, lds_raw, A);
     g.n_nodes = st.n_nodes; g.n_codes = st.n_codes; g.err = st.err; g.n_path = 0; g.path_lo = g.path_hi = -1;
     T.n_sorted = st.n_sorted; T.flags_ok = st.flags_ok;
+    if (st.n_sorted < 0) { T.use = 0; T.n_sorted = 0; }       // (the window has outgrown the sort's LDS arrays: see poa_add_alignment_wave)
     const int lane = threadIdx.x & 63;
-    if (flags & POA_SF_FIRST) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; }
+    if (flags & POA_SF_FIRST) { poa_graph_reset(g); T.n_sorted = 0; T.flags_ok = 0; T.use = A.lds_marks; }
     if (!(flags & POA_SF_EMPTY)) {
         const uint8_t *seq = A.arena + A.seq_off[s];
         const int len = A.seq_len[s];
@@ -2307,7 +2313,7 @@ __device__ __attribute__((noinline)) PoaWinState poa_serial_call(PoaWinState st,
         if (lane == 0) atomicAdd(A.cells + 4, __builtin_readcyclecounter() - t2_);
 #endif
     }
-    PoaWinState out = {g.n_nodes, g.n_codes, g.err, T.n_sorted, T.flags_ok};
+    PoaWinState out = {g.n_nodes, g.n_codes, g.err, A.lds_marks && !T.use ? -1 : T.n_sorted, T.flags_ok};
     return out;
 }
 
@@ -2532,6 +2538,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLay
         uint8_t *const save = (uint8_t *)(slot + L.st8save);
         if (s_idx != 0) {
             T.n_sorted = hdr->n_sorted; T.flags_ok = hdr->flags_ok;
+            if (T.n_sorted < 0) { T.use = 0; T.n_sorted = 0; }       // (the window has outgrown the sort's LDS arrays)
             if (T.use) {
                 // the sort's state as the previous launch left it: state bytes from the slot, previous ranks = n2r
                 for (int i = lane; i < g.n_nodes; i += 64) { T.st8[i] = save[i]; T.old[i] = i < T.n_sorted ? (short)g.n2r[i] : (short)-1; }
@@ -2550,7 +2557,7 @@ __global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLay
             if (T.use) for (int i = lane; i < g.n_nodes; i += 64) save[i] = T.st8[i];
             if (lane == 0) {
                 hdr->n_nodes = g.n_nodes; hdr->n_codes = g.n_codes; hdr->n_path = 0; hdr->err = g.err; hdr->path_lo = -1; hdr->path_hi = -1;
-                hdr->n_sorted = T.n_sorted; hdr->flags_ok = T.flags_ok; hdr->dp_ran = 0;
+                hdr->n_sorted = A.lds_marks && !T.use ? -1 : T.n_sorted; hdr->flags_ok = T.flags_ok; hdr->dp_ran = 0;
             }
         }
     }
@@ -2564,29 +2571,33 @@ __global__ void __launch_bounds__(64, WAVES) poa_phase_kernel(PoaArgs A, SlotLay
 // sized so that as many windows as the registers allow (12 per CU at 168 VGPRs) fit the CU's 160 KB: the stack
 // takes what is left of a window's share, between 128 and POA_LDS_STACK16 entries (a deeper walk falls back to the
 // global-memory sort).  Returns the bytes, or 0 when the node capacity does not fit LDS at all.
-static size_t poa_lds_plan(int ncap, int *stack_entries)
+static size_t poa_lds_plan(int ncap, int *stack_entries, int *lds_ncap)
 {
-    const size_t fixed = (size_t)3 * ((ncap + 15) & ~15) + POA_LDS_FIXED;
     if (ncap >= 32768) return 0;
     int max_waves = 12;
     if (const char *e = getenv("GBX_POA_MAX_WAVES")) { const int v = atoi(e); if (v >= 8 && v <= 16) max_waves = v; }   // tuning aid
-    for (int waves = max_waves; waves >= 8; --waves) {
-        // measured (node capacity 3364): twelve windows of 12304 B run together (336 ms); at 13024 B the twelfth is
-        // resident only some of the time (362-386 ms), so the budget is 12 x 12544 B, not the nominal 160 KB
-        const size_t share = ((size_t)12 * 12544 / (size_t)waves) & ~(size_t)31;
-        if (share < fixed) continue;
-        size_t st = POA_LDS_STACK16;                      // the stack's region is fixed; fewer entries only as a tuning aid
-        if (const char *e = getenv("GBX_POA_LDS_STACK")) { const size_t v = (size_t)atoi(e); if (v >= 32 && v <= st) st = v; }   // tuning aid
-        *stack_entries = (int)st;
-        return fixed;
-    }
-    return 0;
+    // measured (node capacity 3364): twelve windows of 12304 B run together (336 ms); at 13024 B the twelfth is
+    // resident only some of the time (362-386 ms), so the budget is 12 x 12544 B, not the nominal 160 KB.
+    // Round 5: the per-node arrays hold what fits a window's share, not the graph's capacity: a window that outgrows them sorts in
+    // global memory from then on (before, a job whose capacity did not fit lost windows per CU - or the LDS sort altogether - for all
+    // its windows).
+    const size_t share = ((size_t)12 * 12544 / (size_t)max_waves) & ~(size_t)31;
+    int fit = (int)((share - POA_LDS_FIXED) / 3) & ~15;
+    const int ncp = (ncap + 15) & ~15;
+    if (fit > ncp) fit = ncp;
+    if (const char *e = getenv("GBX_POA_LDS_NCAP")) { const int v = atoi(e) & ~15; if (v >= 64 && v < fit) fit = v; }   // test aid: windows outgrow the arrays early
+    else if (fit < 512) return 0;
+    size_t st = POA_LDS_STACK16;                          // the stack's region is fixed; fewer entries only as a tuning aid
+    if (const char *e = getenv("GBX_POA_LDS_STACK")) { const size_t v = (size_t)atoi(e); if (v >= 32 && v <= st) st = v; }   // tuning aid
+    *stack_entries = (int)st;
+    *lds_ncap = fit;
+    return (size_t)3 * (size_t)fit + POA_LDS_FIXED;
 }
 
 int poa_waves_per_cu(int ncap)
 {
-    int lds_stack = 0;
-    const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
+    int lds_stack = 0, lds_ncap = 0;
+    const size_t lds_need = poa_lds_plan(ncap, &lds_stack, &lds_ncap);
     const bool lds_marks = lds_need != 0;
     int q = 0;
     const char *oe_ = getenv("GBX_POA_OCC");
@@ -2714,10 +2725,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         set_error("poa: scores may leave the int16 range for these capacities (nodes %d, length %d)", ncap, lmax);
         return GBX_ERR_UNSUPPORTED;
     }
-    int lds_stack = 0;
-    const size_t lds_need = poa_lds_plan(ncap, &lds_stack);
+    int lds_stack = 0, lds_ncap = 0;
+    const size_t lds_need = poa_lds_plan(ncap, &lds_stack, &lds_ncap);
     A.lds_marks = lds_need != 0 ? 1 : 0;
-    A.lds_stack = lds_stack;
+    A.lds_stack = lds_stack; A.lds_ncap = lds_ncap;
     int32_t *d_wlist = (int32_t *)(wb + ws.wlist), *d_llist = (int32_t *)(wb + ws.llist);
     A.work = wb; A.slot_bytes = 0; A.wlist = d_wlist; A.cnt_idx = POA_CNT_MAIN; A.cur_idx = POA_CUR_MAIN;
     hipLaunchKernelGGL(poa_classify_kernel, dim3(1), dim3(1024), 0, s, A, d_wlist, d_llist, plan->n_long_windows);
@@ -2826,7 +2837,10 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
         }
         Stage st("poa_window", s);
         const char *oe = getenv("GBX_POA_OCC");             // tuning aid: 2 = the instance compiled for two wavefronts per SIMD (no spills, nine ring rows)
-        if (oe && atoi(oe) == 4)          // with GBX_POA_NODE_FACTOR=4 GBX_POA_MAX_WAVES=16: sixteen windows per CU (128 VGPRs, four ring rows)
+        if (oe && atoi(oe) == 4 && serial_form == 2) {      // sixteen windows per CU with the serial phases out of line (128 VGPRs without the spills)
+            PoaKernArgs KA; KA.A = A; KA.L = L;
+            hipLaunchKernelGGL((poa_kernel2<false, 4, 4>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)4 * POA_RING_SLOT), s, KA);
+        } else if (oe && atoi(oe) == 4)   // with GBX_POA_MAX_WAVES=16: sixteen windows per CU (128 VGPRs, four ring rows; the sort's LDS arrays hold 2 352 nodes)
             hipLaunchKernelGGL((poa_kernel<false, 4, 4>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)4 * POA_RING_SLOT), s, A, L);
         else if (oe && atoi(oe) == 2)
             hipLaunchKernelGGL((poa_kernel<false, 2, 9>), dim3(grid), dim3(64), std::max<size_t>(A.lds_marks ? lds_need : 0, (size_t)9 * POA_RING_SLOT), s, A, L);

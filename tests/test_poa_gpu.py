@@ -174,6 +174,25 @@ def test_team_kernel_equals_the_window_kernel(monkeypatch, env):
         diff(consensus_host(p, ws), w)
 
 
+@pytest.mark.parametrize("env", [{"GBX_POA_LDS_NCAP": "640"}, {"GBX_POA_LDS_NCAP": "640", "GBX_POA_TEAM": "0"},
+                                 {"GBX_POA_LDS_NCAP": "1200", "GBX_POA_TEAM": "0", "GBX_POA_SERIAL_FORM": "2"},
+                                 {"GBX_POA_LDS_NCAP": "640", "GBX_POA_LOCKSTEP": "1"},
+                                 {"GBX_POA_OCC": "4", "GBX_POA_MAX_WAVES": "16", "GBX_POA_TEAM": "0"}])
+def test_windows_that_outgrow_the_sorts_lds_arrays(monkeypatch, env):
+    """The topological sort's per-node LDS arrays hold what fits a window's share of the CU (PoaArgs::lds_ncap), not the graph's
+    capacity: a window that may outgrow them switches to the global-memory sort for the rest of its life, the others keep the LDS
+    sort.  GBX_POA_LDS_NCAP (test aid) makes that happen early and in the middle of windows; the last case is the sixteen-windows-
+    per-CU instance, whose arrays hold 2 352 nodes."""
+    p = make_params()
+    sets = [gen_poa(24, 4001), random_windows(27, 16, 520, 9),
+            PoaWindowSet.from_lists([["ACGTACGTAC"] * 3, ["A", "C", "A"], ["GATTACA", "GATTACA", "GATTTACA", "GATTACA"]])]
+    want = [O.poa_oracle(p, ws, 8) for ws in sets]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for ws, w in zip(sets, want):
+        diff(consensus_host(p, ws), w)
+
+
 # ---- the lock-step form (poa_kernels.hip: a slot per window, one launch per phase and sequence index).  Jobs with more
 # windows than the chip holds wavefronts take it by themselves ('large': tests/test_fullsize_gpu.py); GBX_POA_LOCKSTEP=1
 # forces it on the small jobs here.
