@@ -1089,7 +1089,7 @@ def predict_shards(kind, args, ctx, parts, steps, warmup, whole_ms=None):
     dev = ctx["dev"]
     stream = torch.cuda.current_stream().cuda_stream
     sub = argparse.Namespace(**vars(args))
-    sub.size = 0
+    sub.size = 0 if whole_ms is not None else args.size      # (--size shrinks the job of a stand-alone --predict-shards run: tests)
     probe = WORKLOADS[kind](sub)
     full = probe.generate(0, probe.n)
     verify = args.verify_units or {"bsw": 20000, "chain": 40, "phmm": 20, "poa": 8, "abea": 8, "fmi": 20000}[kind]

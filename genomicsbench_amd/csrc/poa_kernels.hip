@@ -1077,7 +1077,7 @@ __device__ unsigned long long g_tb_fast, g_tb_slow, g_tb_fill;
 // its row's descriptor and the rows of its further predecessors (two dependent loads each, through the in-edge list): on a lone
 // wavefront every one of those was a round trip to memory.
 typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
-template <bool LD = false>
+template <int LD = 0>        // 0: descriptors from memory; 1: six arrays in LDS (team); 2: first predecessor, info and node in LDS (one-wavefront kernel)
 __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int len,
                                    int max_i, int max_j, lds_cu16 *ldesc = nullptr, int ldn = 0)
 {
@@ -1088,10 +1088,10 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     const int Wp = M.Wp;
     const int32_t *rd_pred = g.score, *rd_info = g.pred;
     auto desc_p0 = [&](int r) -> int { return LD ? (int)ldesc[r] : rd_pred[r]; };
-    auto d_info_of = [&](int r) -> int { return LD ? (int)ldesc[4 * ldn + r] : rd_info[r]; };      // (letter | in-degree << 8: the sink bit is not needed here)
-    auto d_node_of = [&](int r) -> int { return LD ? (int)ldesc[5 * ldn + r] : g.r2n[r]; };
+    auto d_info_of = [&](int r) -> int { return LD ? (int)ldesc[(LD == 1 ? 4 : 1) * ldn + r] : rd_info[r]; };      // (letter | in-degree << 8: the sink bit is not needed here)
+    auto d_node_of = [&](int r) -> int { return LD ? (int)ldesc[(LD == 1 ? 5 : 2) * ldn + r] : g.r2n[r]; };
     // DP row of in-edge source p >= 1 of the node of rank r
-    auto pred_row = [&](int r, int node, int p) -> int { return LD && p < 4 ? (int)ldesc[p * ldn + r] : g.n2r[PG_IN_SRC(g, node, p)] + 1; };
+    auto pred_row = [&](int r, int node, int p) -> int { return LD == 1 && p < 4 ? (int)ldesc[p * ldn + r] : g.n2r[PG_IN_SRC(g, node, p)] + 1; };
     const int j0 = lane * CPL + 1;
     (void)len;
     int eq_row = -1;
@@ -1227,7 +1227,7 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
 #ifndef GBX_POA_TB_BATCH
 #define GBX_POA_TB_BATCH 0            // measured (profiles/r05o_poa_team_tb_ab.txt): 56.8 against 55.3 ms for a lone window - most general steps end at the first predecessor; off
 #endif
-                if (LD && GBX_POA_TB_BATCH) {
+                if (LD == 1 && GBX_POA_TB_BATCH) {
                     // the diagonal cells of the first four predecessors in ONE round trip: their rows come out of LDS, so the loads
                     // do not depend on each other (through memory each row took two dependent loads first: the loop below)
                     const int icc = ic ? ic : 1;
@@ -2018,6 +2018,19 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
                 else poa_dp<8>(g, M, A, seq, len, mi, mj);     // longer sequences run as several column blocks
                 PH_ACC(t_dp)
                 __builtin_amdgcn_s_setprio(3);
+#ifndef GBX_POA_TB_LDS3
+#define GBX_POA_TB_LDS3 1           // (round 5, measured: profiles/r05z_poa_tb_lds3_ab.txt, 200.2 against 201.9 ms) the one-wavefront kernel's traceback with p0 / info / node of every row in the ring's LDS
+#endif
+                const bool ld3 = GBX_POA_TB_LDS3 && T.use && (!LONG || len <= POA_PIPE_MAXLEN) && g.n_nodes * 6 <= 3 * T.cap;      // (the sort's per-node arrays: 3 bytes per node, free until add_alignment restores them)
+                if (ld3) {
+                    typedef __attribute__((address_space(3))) unsigned short lds_u16;
+                    lds_u16 *const ldw = (lds_u16 *)((lds_u8 *)lds_raw + POA_LDS_FIXED);
+                    const int n_ = g.n_nodes;
+                    for (int r = threadIdx.x & 63; r < n_; r += 64) { ldw[r] = (unsigned short)g.score[r]; ldw[n_ + r] = (unsigned short)g.pred[r]; ldw[2 * n_ + r] = (unsigned short)g.r2n[r]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    poa_traceback_wave<2>(g, M, A.S, seq, len, mi, mj, (lds_cu16 *)((lds_u8 *)lds_raw + POA_LDS_FIXED), n_);
+                } else
                 if (!LONG || len <= POA_PIPE_MAXLEN) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                 else poa_traceback(g, M, A.S, seq, mi, mj);
                 PH_ACC(t_tb)
@@ -2146,7 +2159,7 @@ __global__ void __launch_bounds__(64 * POA_TEAM_NW, WAVES) poa_team_kernel(PoaAr
                 PH_ACC(t_dp)
                 if (wave == 0) {
                     __builtin_amdgcn_s_setprio(3);
-                    if (ld) poa_traceback_wave<true>(g, M, A.S, seq, len, mi, mj, (lds_cu16 *)(lds_u8 *)lds_raw, n_nodes);
+                    if (ld) poa_traceback_wave<1>(g, M, A.S, seq, len, mi, mj, (lds_cu16 *)(lds_u8 *)lds_raw, n_nodes);
                     else if (piped) poa_traceback_wave(g, M, A.S, seq, len, mi, mj);
                     else poa_traceback(g, M, A.S, seq, mi, mj);
                     PH_ACC(t_tb)

@@ -92,3 +92,21 @@ def test_short_form_of_the_other_kernels_records():
     k = m.compact_entry(rec, keep=("shard_units", "scatter_ms"))
     assert k["shard_units"] == [5, 5] and k["scatter_ms"] == 1.5 and k["config4_strong"]["shard_units"] == [1, 2] and k["config4_strong"]["strong_scaling"]
     assert len(json.dumps(c)) < len(json.dumps(rec))
+
+
+def test_config4_predicted_survives_the_short_form_and_predict_shards_is_a_one_gpu_flag():
+    """`kernels.poa.config4_predicted` (the eight shards of BASELINE config 4's cut, each alone on one GPU) keeps its per-shard times and
+    the prediction in the short form of the line; `--predict-shards` with more than one rank is refused before anything touches a GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rec = {"metric": "poa_large_gcups", "value": 450.0, "ms_per_step": 200.0,
+           "config4_predicted": {"what": "x" * 200, "parts": 8, "shard_units": [750] * 8, "shard_ms": [64.0 + k / 10 for k in range(8)],
+                                 "whole_job_ms_1gpu": 200.0, "predicted_ms_per_step": 64.7, "predicted_speedup": 3.0912345,
+                                 "verified": "front 8 units of every shard vs oracle: identical"}}
+    c = m.compact_entry(rec)["config4_predicted"]
+    assert len(c["shard_ms"]) == 8 and c["predicted_speedup"] == 3.0912 and c["predicted_ms_per_step"] == 64.7 and "what" not in c
+    assert "identical" in c["verified"]
+    ap_src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "--predict-shards is a one-GPU measurement" in ap_src

@@ -157,3 +157,20 @@ def test_fmi_split_compute_concat(parts):
     assert np.array_equal(goff, woff)
     for f in ("rid", "m", "n", "k", "l", "s"):
         assert np.array_equal(got[f], wo[f]), f
+
+
+@pytest.mark.parametrize("kind,size", [("poa", 96), ("chain", 60)])
+def test_bench_predict_shards_on_one_gpu(kind, size):
+    """`bench.py --kernel K --predict-shards P` (BASELINE config 4 measured on one GPU: the P shards of the N-GPU cut, each run alone
+    and checked against the oracle; the slowest one is the predicted N-GPU step) on a small job."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--kernel", kind, "--predict-shards", "3", "--size", str(size), "--steps", "1", "--warmup", "1",
+                        "--verify-units", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    p = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["config4_predicted"]
+    assert p["parts"] == 3 and sum(p["shard_units"]) == size and len(p["shard_ms"]) == 3
+    assert abs(p["predicted_ms_per_step"] - max(p["shard_ms"])) < 1e-2 and p["predicted_speedup"] > 0 and "identical" in p["verified"] and "DIFFER" not in p["verified"]
