@@ -273,3 +273,37 @@ def test_host_index_cache_is_keyed_by_content_not_by_address():
         ix, rs = build_index(g), gen_fmi_reads(g, 100, 6300 + seed)
         assert_same(smem_host(ix, rs, P), O.fmi_oracle(ix, rs, P, nthreads=4))
     N.check(N.lib().gbx_fmi_host_release())
+
+
+def test_threads_that_meet_an_index_for_the_first_time_together():
+    """Round 5: the device copy of an index is uploaded and re-laid OUTSIDE the cache's lock behind a place-holder entry; callers that
+    ask for the very index under construction wait for it, callers with another index build theirs beside it, and a release in between
+    leaves the entries in use alone.  Six threads, two indexes, twice (the second time after a release)."""
+    import threading
+    from genomicsbench_amd import _native as N
+    ga, gb = gen_fmi_genome(300_000, 7101), gen_fmi_genome(260_000, 7102)
+    ia, ib = build_index(ga), build_index(gb)
+    P = default_params(19)
+    sets = [(ia, gen_fmi_reads(ga, 400, 7200 + k)) if k % 2 == 0 else (ib, gen_fmi_reads(gb, 400, 7200 + k)) for k in range(6)]
+    want = [O.fmi_oracle(ix, rs, P, nthreads=4) for ix, rs in sets]
+    for rnd in range(2):
+        N.check(N.lib().gbx_fmi_host_release())
+        got, err = [None] * len(sets), []
+
+        def work(k):
+            try:
+                got[k] = smem_host(sets[k][0], sets[k][1], P)
+                if k == 3:
+                    N.check(N.lib().gbx_fmi_host_release())                        # beside calls that hold their entries
+            except Exception as e:                                                 # noqa: BLE001
+                err.append((k, repr(e)))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(sets))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not err, err
+        for k in range(len(sets)):
+            assert_same(got[k], want[k])
+    N.check(N.lib().gbx_fmi_host_release())
