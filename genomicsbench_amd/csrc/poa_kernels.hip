@@ -2243,7 +2243,7 @@ __device__ __attribute__((noinline)) PoaWinState poa_serial_call(PoaWinState st,
     // loads are scalar - s_load - and only those of fields that are used survive)
     typedef const __attribute__((address_space(4))) int kernarg_word_t;
     // (the kernel hands its kernel-argument pointer down: asked for inside a callee, __builtin_amdgcn_kernarg_segment_ptr() faults on
-    // this toolchain - build_tmp/kernarg_probe.hip)
+    // this toolchain - scripts/kernarg_probe.hip)
     kernarg_word_t *const kw = (kernarg_word_t *)(unsigned long long)poa_uni64((int64_t)kernargs);
     PoaKernArgs KK;
     {
