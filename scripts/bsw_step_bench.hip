@@ -5,7 +5,7 @@
 // cells that live in LDS as in the kernel (3 bytes per column and pair), four column steps per loop trip with the loads ahead, at the
 // LDS occupancy the long-query classes have (27 KB per 64 pairs).  The packed step is given its BEST case: both pairs of a lane share
 // one window (no per-half masks, which the real kernel would need: windows are per pair) and one target base per row.
-// Prints cells per second and the static instruction count of each loop body (from the ISA: scripts/bsw_step_bench.sh).
+// Prints cells per second (best of eight interleaved launches); the static instruction counts quoted in profiles/r05o_* come from the ISA (hipcc -S).
 //   hipcc -O3 --offload-arch=gfx950 -I genomicsbench_amd/csrc scripts/bsw_step_bench.hip -Lgenomicsbench_amd -lgbx -Wl,-rpath,$PWD/genomicsbench_amd -o build_tmp/bsw_step_bench
 #include "bsw_kernels.hip"
 #include <cstdio>
