@@ -1105,29 +1105,49 @@ size_t bsw_workspace_bytes(int64_t n)
 }
 
 // Expands the packed image of a byte arena (two base codes per byte, host_pipeline.h: pack4) over [lo, hi) of the
-// arena, lo even: 8 packed bytes -> 16 codes per thread.
+// arena, lo even: 4 x 8 packed bytes -> 4 x 16 codes per thread, a block's four rounds each one contiguous 4 KB (in a
+// pipelined host call this kernel runs beside the previous chunk's lane kernels and gets a wavefront slot or two per
+// SIMD: few wavefronts with four loads in flight each, not many with one - 0.5-1.0 ms -> see profiles/r05af_*).
+constexpr int UNPACK_ROUNDS = 4;
 __global__ void __launch_bounds__(256) bsw_unpack4_kernel(const uint8_t *__restrict__ packed, uint8_t *__restrict__ out, int64_t lo, int64_t hi)
 {
-    const int64_t o = lo + ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
-    if (o >= hi) return;
-    if (((uintptr_t)(packed + (o >> 1)) & 7) == 0 && ((uintptr_t)(out + o) & 15) == 0 && o + 16 <= hi) {
-        const uint2 v = *(const uint2 *)(packed + (o >> 1));
-        uint4 r;
+    const int64_t base = lo + (int64_t)blockIdx.x * (256 * 16 * UNPACK_ROUNDS) + threadIdx.x * 16;
+    const bool aligned = (((uintptr_t)(packed + (base >> 1)) & 7) == 0) && (((uintptr_t)(out + base) & 15) == 0);
+    if (aligned && base + (int64_t)(UNPACK_ROUNDS - 1) * 4096 + 16 <= hi) {
+        uint2 v[UNPACK_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < UNPACK_ROUNDS; ++r) v[r] = *(const uint2 *)(packed + ((base + r * 4096) >> 1));
         // byte b = lo | hi << 4  ->  two bytes (lo, hi); four packed bytes give two dwords
         auto spread = [](unsigned h) -> unsigned { return (h & 0xfu) | ((h & 0xf0u) << 4) | ((h & 0xf00u) << 8) | ((h & 0xf000u) << 12); };
-        r.x = spread(v.x & 0xffffu); r.y = spread(v.x >> 16); r.z = spread(v.y & 0xffffu); r.w = spread(v.y >> 16);
-        *(uint4 *)(out + o) = r;
+#pragma unroll
+        for (int r = 0; r < UNPACK_ROUNDS; ++r) {
+            uint4 q;
+            q.x = spread(v[r].x & 0xffffu); q.y = spread(v[r].x >> 16); q.z = spread(v[r].y & 0xffffu); q.w = spread(v[r].y >> 16);
+            *(uint4 *)(out + base + r * 4096) = q;
+        }
         return;
     }
-    for (int64_t k = o; k < o + 16 && k < hi; ++k) out[k] = (uint8_t)((packed[k >> 1] >> ((k & 1) * 4)) & 0xf);
+    for (int r = 0; r < UNPACK_ROUNDS; ++r) {
+        const int64_t o = base + r * 4096;
+        if (o >= hi) return;
+        if (aligned && o + 16 <= hi) {
+            const uint2 v = *(const uint2 *)(packed + (o >> 1));
+            auto spread = [](unsigned h) -> unsigned { return (h & 0xfu) | ((h & 0xf0u) << 4) | ((h & 0xf00u) << 8) | ((h & 0xf000u) << 12); };
+            uint4 q;
+            q.x = spread(v.x & 0xffffu); q.y = spread(v.x >> 16); q.z = spread(v.y & 0xffffu); q.w = spread(v.y >> 16);
+            *(uint4 *)(out + o) = q;
+        } else {
+            for (int64_t k = o; k < o + 16 && k < hi; ++k) out[k] = (uint8_t)((packed[k >> 1] >> ((k & 1) * 4)) & 0xf);
+        }
+    }
 }
 
 int bsw_unpack4(const uint8_t *d_packed, uint8_t *d_out, int64_t lo, int64_t hi, hipStream_t s)
 {
     if (hi <= lo) return GBX_OK;
-    const int64_t threads = (hi - lo + 15) / 16;
+    const int64_t per_block = 256 * 16 * UNPACK_ROUNDS;
     Stage st("bsw_unpack4", s);
-    hipLaunchKernelGGL(bsw_unpack4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_packed, d_out, lo, hi);
+    hipLaunchKernelGGL(bsw_unpack4_kernel, dim3((unsigned)((hi - lo + per_block - 1) / per_block)), dim3(256), 0, s, d_packed, d_out, lo, hi);
     GBX_HIP(hipGetLastError());
     return GBX_OK;
 }
@@ -1160,11 +1180,32 @@ int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,
     return GBX_OK;
 }
 
+// lane path: large jobs only (a wavefront holds 64 pairs: the chip wants a few thousand wavefronts), GBX_BSW_LANE=0/1 overrides
+static bool lane_wanted(int64_t n)
+{
+    const char *lane_env = getenv("GBX_BSW_LANE");              /* read per call: the tests vary it */
+    const int64_t lane_min = getenv("GBX_BSW_LANE_MIN") ? atoll(getenv("GBX_BSW_LANE_MIN")) : 262144;
+    return lane_env ? atoi(lane_env) != 0 : n >= lane_min;
+}
+
+int bsw_lane_rule(const gbx_bsw_params *p, int64_t n, BswLaneRule *r)
+{
+    BswDev dev;
+    const int rc = make_dev_params(p, &dev);
+    if (rc) return rc;
+    r->on = dev.lane_on && lane_wanted(n) ? 1 : 0;
+    r->max_mat = dev.max_mat > 0 ? dev.max_mat : 0;
+    r->qmax = LANE_QMAX;
+    r->limit = LANE_SCORE_LIMIT;
+    return GBX_OK;
+}
+
 int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const uint8_t *d_ref, const uint8_t *d_qer,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
-               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s, hipEvent_t *join_events)
+               gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s, hipEvent_t *join_events,
+               const BswChunkPrep *prep)
 {
     if (n == 0) return GBX_OK;
     if (n > 0x7fffffffLL - 1024) { set_error("bsw: more than 2^31 pairs in one call"); return GBX_ERR_UNSUPPORTED; }
@@ -1179,14 +1220,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     int32_t *wl = wi + WS_HDR + 4 * n;
     BswWork W = {wi, wi + HDR, wi + 2 * HDR, wi + 3 * HDR, wi + WS_HDR, wi + WS_HDR + n, wl, wi + WS_HDR + 3 * n, wi + WS_HDR + 2 * n,
                  wl + LANE_BINS + 64};
-    GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s));
-    // lane path: large jobs only (a wavefront holds 64 pairs: the chip wants a few thousand wavefronts), GBX_BSW_LANE=0/1 overrides
-    {
-        const char *lane_env = getenv("GBX_BSW_LANE");              /* read per call: the tests vary it */
-        const int64_t lane_min = getenv("GBX_BSW_LANE_MIN") ? atoll(getenv("GBX_BSW_LANE_MIN")) : 262144;
-        const bool want = lane_env ? atoi(lane_env) != 0 : n >= lane_min;
-        dev.lane_on = dev.lane_on && want ? 1 : 0;
-    }
+    dev.lane_on = dev.lane_on && lane_wanted(n) ? 1 : 0;
     // the classes are independent and every kernel ends in a tail of a few long pairs: they go to four
     // streams so that a tail overlaps the next class (GBX_BSW_SERIAL=1 keeps them on the caller's stream)
     static const bool serial = getenv("GBX_BSW_SERIAL") != nullptr;
@@ -1196,15 +1230,36 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         if ((rc = side_streams(&ss))) return rc;
         side_lock = std::unique_lock<std::mutex>(ss->mu);
     }
+    // A chunk of a pipelined host call: its preparing passes go to the two urgent streams and wait for the uploads only.
+    // On the caller's stream they would queue behind the previous chunk's kernels there, and with them every kernel of
+    // this chunk: the chunks then ran one after the other, each with its own tails (2.5 ms a chunk of 'large' against
+    // 1.9 ms for a third of the job; GBX_BSW_PREP=0 keeps that order).
+    static const bool prep_off = getenv("GBX_BSW_PREP") && atoi(getenv("GBX_BSW_PREP")) == 0;
+    const bool ahead = prep && prep->uploaded && join_events && !serial && !prep_off;
+    hipStream_t s_cls = ahead ? ss->pre[0] : s;
+    if (ahead) {
+        GBX_HIP(hipStreamWaitEvent(ss->pre[0], prep->uploaded, 0));
+        GBX_HIP(hipStreamWaitEvent(ss->pre[1], prep->uploaded, 0));
+    }
+    if (prep && prep->ref_packed &&
+        ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, prep->lo_r, prep->hi_r, s_cls)) ||
+         (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, prep->lo_q, prep->hi_q, s_cls))))
+        return rc;
+    GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s_cls));
     // The lane sort (0.3 ms on 'large': two passes of scattered atomics) runs on a side stream of its own, beside
     // classify and the row-kernel classes on the caller's stream, which do not need it; the lane launches wait for it.
     const bool sort_aside = dev.lane_on && !serial;
     if (dev.lane_on) {
-        GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
         hipStream_t so = s;
-        if (sort_aside) {
-            if ((rc = ss->fork(s))) return rc;
-            so = ss->side[SideStreams::N - 1];
+        if (ahead) {
+            so = ss->pre[1];
+            GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), so));
+        } else {
+            GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
+            if (sort_aside) {
+                if ((rc = ss->fork(s))) return rc;
+                so = ss->side[SideStreams::N - 1];
+            }
         }
         Stage st("bsw_lane_sort", so);
         const int sblocks = (int)((n + 255) / 256);
@@ -1215,10 +1270,15 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     }
     const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
     {
-        Stage st("bsw_classify", s);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(HDR), 0, s, W);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s, dev, P, n, W, 1);
+        Stage st("bsw_classify", s_cls);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 0);
+        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(HDR), 0, s_cls, W);
+        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 1);
+    }
+    if (ahead) {                                                 // the kernel streams wait for classify (and, below, for the sort)
+        GBX_HIP(hipEventRecord(ss->ev_pre, s_cls));
+        GBX_HIP(hipStreamWaitEvent(s, ss->ev_pre, 0));
+        for (int k = 0; k < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_pre, 0));
     }
 
     int dev_id = 0, cus = 256;
@@ -1234,11 +1294,13 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     // round-robin over the longest-first list starts every group on the longest pairs together
     const bool sym = dev.oe_ins == dev.oe_del;
     const RowShape *shapes = class_shapes();
-    if (!serial && !sort_aside && (rc = ss->fork(s))) return rc;
+    if (!serial && !sort_aside && !ahead && (rc = ss->fork(s))) return rc;
     // The row-kernel classes first.  With the lane path on they hold next to nothing (what the lane kernels cannot take):
     // twenty near-empty launches, all on the caller's stream, in the shadow of the lane sort.
+    // (none at all when the host entry has counted the chunk's pairs and the lane kernels take every one)
+    const bool no_rows = dev.lane_on && prep && prep->rows_pairs == 0 && !(getenv("GBX_BSW_SKIP_ROWS") && atoi(getenv("GBX_BSW_SKIP_ROWS")) == 0);
     int launched = 0;
-    for (int c = 0; c < NCLS - 1; ++c) {
+    for (int c = 0; c < NCLS - 1 && !no_rows; ++c) {
         if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
         // Four kernel streams when the inputs are resident.  The host pipeline (join_events) uses three: the
         // runtime maps streams onto four hardware queues, and with all four busy with class kernels its copy
@@ -1264,7 +1326,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     }
     if (sort_aside) {                                          // the lane launches need the sorted lists (the sort's own stream has them in order)
         GBX_HIP(hipStreamWaitEvent(s, ss->ev_aux, 0));
-        for (int k = 0; k + 1 < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_aux, 0));
+        for (int k = 0; k + (ahead ? 0 : 1) < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_aux, 0));
     }
     if (dev.lane_on) {
         // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts
@@ -1312,7 +1374,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     // the host pipeline queues chunk after chunk like that, so that the single-wavefront tails of one chunk
     // overlap the next chunk's kernels, and its downloader waits for the events.
     if (!serial && !join_events && (rc = ss->join(s))) return rc;
-    {
+    if (!no_rows) {
         const size_t lds_bytes = (size_t)(GBX_BSW_MAX_QLEN + 1) * 2 * sizeof(int);
         // per device (a process may drive several GPUs through gbx_set_device), set at most once each
         static std::atomic<uint64_t> attr_set[2];

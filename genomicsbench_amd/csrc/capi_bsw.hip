@@ -63,19 +63,25 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     const bool trace = getenv("GBX_HOST_TRACE") != nullptr;     /* timeline of this call on stderr */
     const double t_begin = wall_s();
     // one pass over the pairs: validation, and per pipeline chunk the furthest arena byte its pairs need
-    const int64_t chunk = bsw_host_chunk(n);
-    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const std::vector<int64_t> cut = bsw_host_cuts(n);          // chunk c = pairs [cut[c], cut[c + 1])
+    const int64_t n_chunks = (int64_t)cut.size() - 1;
+    int64_t chunk = 0;                                          // the largest chunk
+    for (int64_t c = 0; c < n_chunks; ++c) chunk = cut[(size_t)c + 1] - cut[(size_t)c] > chunk ? cut[(size_t)c + 1] - cut[(size_t)c] : chunk;
     std::vector<int64_t> need_r((size_t)n_chunks), need_q((size_t)n_chunks);
     // slices of 64 Ki pairs, a few threads when there are many; the lowest failing pair is reported
     const int64_t SL = 65536, n_slices = (n + SL - 1) / SL;
     std::vector<int64_t> slice_r((size_t)n_slices), slice_q((size_t)n_slices), slice_bad((size_t)n_slices, -1);
+    std::vector<int64_t> slice_rows((size_t)n_slices, 0);   // pairs the lane kernels will not take (BswChunkPrep::rows_pairs)
+    BswLaneRule rule = {0, 0, 0, 0};
+    if (bsw_lane_rule(p, chunk, &rule) != GBX_OK) rule.on = 0;      // (bad parameters: the launch reports them)
     std::vector<int> slice_plain((size_t)n_slices, 0);      // longest query if every pair has 1 <= qlen <= 256, tlen >= 1 and a small h0 (bsw_launch_direct), else 0
     auto check_slice = [&](int64_t sl) {
         const int64_t a = sl * SL, b = a + SL < n ? a + SL : n;
-        int64_t mr = 0, mq = 0;
+        int64_t mr = 0, mq = 0, rows = 0;
         bool plain = true;
         int maxq = 1;
         for (int64_t k = a; k < b; ++k) {
+            rows += !bsw_lane_takes(rule, len2[k], len1[k], h0[k]) && len1[k] != 0 && len2[k] != 0;
             plain = plain && len2[k] >= 1 && len2[k] <= 256 && len1[k] >= 1 && h0[k] < 1000000;
             maxq = len2[k] > maxq ? len2[k] : maxq;
             const int64_t er = idr[k] + len1[k], eq = idq[k] + len2[k];
@@ -86,7 +92,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
             }
             mr = er > mr ? er : mr; mq = eq > mq ? eq : mq;
         }
-        slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0;
+        slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0; slice_rows[(size_t)sl] = rows;
     };
     {
         const int vt = n_slices >= 16 ? 8 : n_slices >= 8 ? 4 : 1;      // 0.9 ms with 4 threads at 2 M pairs, on the call's critical path
@@ -106,15 +112,22 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)(base + k));
         return GBX_ERR_ARG;
     }
+    std::vector<int64_t> rows_pairs((size_t)n_chunks, -1);
     for (int64_t c = 0; c < n_chunks; ++c) {
-        int64_t mr = 0, mq = 0;
+        int64_t mr = 0, mq = 0, rows = 0;
         // chunks are multiples of 64 pairs, slices of 65536: a slice may straddle two chunks, which only makes
         // the earlier chunk wait for a few more bytes
-        for (int64_t sl = c * chunk / SL; sl < n_slices && sl * SL < (c + 1) * chunk; ++sl) {
+        for (int64_t sl = cut[(size_t)c] / SL; sl < n_slices && sl * SL < cut[(size_t)c + 1]; ++sl) {
             mr = slice_r[(size_t)sl] > mr ? slice_r[(size_t)sl] : mr;
             mq = slice_q[(size_t)sl] > mq ? slice_q[(size_t)sl] : mq;
+            rows += slice_rows[(size_t)sl];
         }
         need_r[(size_t)c] = mr; need_q[(size_t)c] = mq;
+        // (an upper bound: a slice that straddles two chunks counts for both; a short last chunk may run without the lane path)
+        BswLaneRule last = rule;
+        const int64_t m = cut[(size_t)c + 1] - cut[(size_t)c];
+        if (m != chunk && bsw_lane_rule(p, m, &last) != GBX_OK) last.on = 0;
+        rows_pairs[(size_t)c] = rule.on && last.on ? rows : -1;
     }
     int rc = require_device();
     if (rc) return rc;
@@ -126,7 +139,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     // perfectly for the usual monotone one.  The chunks are queued back to back without a barrier between them
     // (own workspace each; the launch records the events a chunk's download waits for), and their results come
     // back while later chunks run.  Chunks are multiples of 64 pairs.
-    const size_t wb1 = (bsw_workspace_bytes(chunk < n ? chunk : n) + 255) & ~(size_t)255;
+    const size_t wb1 = (bsw_workspace_bytes(chunk) + 255) & ~(size_t)255;
     HostLane lane;
     if ((rc = lane.acquire())) return rc;
     Lane *L = lane.l;
@@ -147,8 +160,8 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     if (pack_bases && ((rc = dref_p.alloc((size_t)ref_bytes / 2 + 16)) || (rc = dqer_p.alloc((size_t)qer_bytes / 2 + 16)))) return rc;
     std::vector<int64_t> lo_r((size_t)n_chunks), hi_r((size_t)n_chunks), lo_q((size_t)n_chunks), hi_q((size_t)n_chunks);
     int64_t up_r = 0, up_q = 0;
-    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
-        const int64_t b = a + chunk < n ? a + chunk : n, m = b - a;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t a = cut[(size_t)c], m = cut[(size_t)c + 1] - a;
         int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
         int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
         if (pack_bases) {
@@ -189,19 +202,22 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         if (!rc) { pipe.fetch(0, out, dout.p, n * sizeof(gbx_bsw_result)); rc = pipe.chunk_launched(0, 0); }
         return pipe.finish(rc);
     }
-    for (int64_t a = 0, c = 0; a < n; a += chunk, ++c) {
-        const int64_t m = (a + chunk < n ? a + chunk : n) - a;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t a = cut[(size_t)c], m = cut[(size_t)c + 1] - a;
         if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
         mark("uploads queued, chunk", c);
-        if (pack_bases &&
-            ((rc = bsw_unpack4(dref_p.as<uint8_t>(), dref.as<uint8_t>(), lo_r[(size_t)c], hi_r[(size_t)c], L->compute)) ||
-             (rc = bsw_unpack4(dqer_p.as<uint8_t>(), dqer.as<uint8_t>(), lo_q[(size_t)c], hi_q[(size_t)c], L->compute))))
-            return pipe.finish(rc);
-        // pipelined calls: no barrier between the chunks, the launch records one event per kernel stream
+        // pipelined calls: no barrier between the chunks, the launch records one event per kernel stream, and what
+        // prepares a chunk (unpacking, classify, the lane sort) waits for its uploads only (BswChunkPrep)
         hipEvent_t *je = n_chunks > 1 ? pipe.join_events(c) : nullptr;
+        BswChunkPrep prep = {je ? pipe.stage_event() : nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, rows_pairs[(size_t)c]};
+        if (pack_bases) {
+            prep.ref_packed = dref_p.as<uint8_t>(); prep.ref_bytes = dref.as<uint8_t>();
+            prep.qer_packed = dqer_p.as<uint8_t>(); prep.qer_bytes = dqer.as<uint8_t>();
+            prep.lo_r = lo_r[(size_t)c]; prep.hi_r = hi_r[(size_t)c]; prep.lo_q = lo_q[(size_t)c]; prep.hi_q = hi_q[(size_t)c];
+        }
         rc = bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,
                         dl1.as<int32_t>() + a, dl2.as<int32_t>() + a, dh0.as<int32_t>() + a,
-                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute, je);
+                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute, je, &prep);
         if (!rc) {
             pipe.fetch(c, out + a, dout.as<gbx_bsw_result>() + a, m * sizeof(gbx_bsw_result));
             rc = pipe.chunk_launched(c, je ? Lane::JOIN_EVENTS : 0);

@@ -134,6 +134,12 @@ int side_streams(SideStreams **out)
         GBX_HIP(hipStreamCreateWithPriority(&ss->side[k], hipStreamNonBlocking, prio[k]));
         GBX_HIP(hipEventCreateWithFlags(&ss->ev_join[k], hipEventDisableTiming));
     }
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        for (int k = 0; k < 2; ++k) GBX_HIP(hipStreamCreateWithPriority(&ss->pre[k], hipStreamNonBlocking, greatest));
+        GBX_HIP(hipEventCreateWithFlags(&ss->ev_pre, hipEventDisableTiming));
+    }
     made.emplace_back(dev, ss);
     *out = ss;
     return GBX_OK;

@@ -87,7 +87,9 @@ static inline int gbx_guard_check(const char *what)
 struct SideStreams {
     static constexpr int N = 3;
     hipStream_t side[N];
+    hipStream_t pre[2];                          // urgent streams for the passes that prepare a launch (bsw's pipelined chunks)
     hipEvent_t ev_fork, ev_join[N], ev_aux;      // ev_aux: a point on one side stream the others wait for (bsw: the lane sort)
+    hipEvent_t ev_pre;                           // the other preparing pass (bsw: classify)
     std::mutex mu;
     int fork(hipStream_t main);
     int join(hipStream_t main);
@@ -95,13 +97,31 @@ struct SideStreams {
 int side_streams(SideStreams **out);
 
 // ---- bsw (bsw_kernels.hip)
+// A chunk of a pipelined host call (join_events set): what has to happen between its uploads and its kernels.  With it the
+// launch puts these passes (unpacking, classify, the lane sort) on the urgent streams, waiting for `uploaded` only, and the
+// chunk's kernels wait for them - not, as everything on the caller's stream would, for the previous chunk's kernels.
+struct BswChunkPrep {
+    hipEvent_t uploaded;                          // recorded on the copy stream behind the chunk's uploads
+    const uint8_t *ref_packed, *qer_packed;       // 4-bit arenas to unpack (nullptr: the bytes were uploaded as they are)
+    uint8_t *ref_bytes, *qer_bytes;
+    int64_t lo_r, hi_r, lo_q, hi_q;
+    int64_t rows_pairs;                           // pairs of the chunk that bsw_lane_takes() turns down, or an upper bound; -1: not counted
+};
+// Which pairs a launch of n pairs puts on the lane kernels (bsw_kernels.hip: lane_ok), for a host pass that counts the
+// others: a launch that knows there are none leaves out the row-kernel classes, twenty-one near-empty launches.
+struct BswLaneRule { int on, max_mat, qmax, limit; };
+int bsw_lane_rule(const gbx_bsw_params *p, int64_t n, BswLaneRule *r);
+static inline bool bsw_lane_takes(const BswLaneRule &r, int qlen, int tlen, int h0)
+{
+    return r.on && qlen >= 1 && qlen <= r.qmax && tlen >= 1 && h0 >= 0 && h0 + qlen * r.max_mat < r.limit;
+}
 size_t bsw_workspace_bytes(int64_t n);
 int bsw_launch(const gbx_bsw_params *p, int64_t n,
                const uint8_t *d_ref, const uint8_t *d_qer,
                const int64_t *d_idr, const int64_t *d_idq,
                const int32_t *d_len1, const int32_t *d_len2, const int32_t *d_h0,
                gbx_bsw_result *d_out, void *d_work, size_t work_bytes, hipStream_t s,
-               hipEvent_t *join_events = nullptr);
+               hipEvent_t *join_events = nullptr, const struct BswChunkPrep *prep = nullptr);
 
 int bsw_unpack4(const uint8_t *d_packed, uint8_t *d_out, int64_t lo, int64_t hi, hipStream_t s);
 int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,

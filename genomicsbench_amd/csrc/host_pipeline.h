@@ -89,8 +89,10 @@ struct Lane {
     // share a queue run in order: with compute + transfer + two of the kernels' side streams every one has a
     // queue of its own (measured with more: uploads stalled behind class kernels, or two kernel streams lost
     // their overlap).  Calls that do not overlap transfer and compute use `compute` for everything.
-    hipStream_t compute = nullptr, copy = nullptr;
-    hipEvent_t ev_stage = nullptr, ev_half[2] = {nullptr, nullptr};
+    // (Round 5: urgent streams get hardware queues of their own class, so the uploads have two - their DMAs fill each other's
+    // gaps - and the downloads one more instead of queueing between the uploads; without priorities all three are `copy`.)
+    hipStream_t compute = nullptr, copy = nullptr, copy2 = nullptr, down = nullptr;
+    hipEvent_t ev_stage = nullptr, ev_stage2 = nullptr, ev_half[2] = {nullptr, nullptr};
     static constexpr int JOIN_EVENTS = 1 + SideStreams::N;
     std::vector<hipEvent_t> ev_chunk;      // JOIN_EVENTS per pipeline chunk of a call, grown on demand
     char *wslab[MAX_WORKERS][2] = {};
@@ -161,11 +163,18 @@ struct HostLane {
         if (e == hipSuccess) {
             int least = 0, greatest = 0;
             const bool hi = !(getenv("GBX_COPY_PRIO") && atoi(getenv("GBX_COPY_PRIO")) == 0);
-            if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+            if (hi && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least) {
                 e = hipStreamCreateWithPriority(&n->copy, hipStreamNonBlocking, greatest);
-            else { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&n->copy, hipStreamNonBlocking); }
+                const int ups = getenv("GBX_COPY_STREAMS") ? atoi(getenv("GBX_COPY_STREAMS")) : 2;
+                if (e == hipSuccess && ups >= 2) e = hipStreamCreateWithPriority(&n->copy2, hipStreamNonBlocking, greatest);
+                if (e == hipSuccess && !(getenv("GBX_DOWN_STREAM") && atoi(getenv("GBX_DOWN_STREAM")) == 0))
+                    e = hipStreamCreateWithPriority(&n->down, hipStreamNonBlocking, greatest);
+            } else { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&n->copy, hipStreamNonBlocking); }
+            if (!n->copy2) n->copy2 = n->copy;
+            if (!n->down) n->down = n->copy;
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage2, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[0], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[1], hipEventDisableTiming);
         if (e != hipSuccess) { delete n; return hip_fail(e, "host lane"); }
@@ -313,6 +322,7 @@ struct HostPipe {
     std::deque<std::vector<char>> gathered;    // compact copies of strided pieces of calls too small to stage (alive until the pipe goes)
     std::vector<int> chunk_nev;            // join events recorded for chunk c
     hipStream_t xfer;                      // L->copy, or L->compute for calls that do not overlap
+    hipStream_t xfer2, xdown;              // the second upload stream and the download stream (the same rule)
     std::atomic<size_t> next{0};
     std::atomic<int> hip_err{0};
     bool abort_ = false;
@@ -335,7 +345,7 @@ struct HostPipe {
     size_t pack_off = 0;
     HostPipe(Lane *l, size_t total_bytes, bool overlap)
         : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
-          xfer(overlap ? l->copy : l->compute),
+          xfer(overlap ? l->copy : l->compute), xfer2(overlap ? l->copy2 : l->compute), xdown(overlap ? l->down : l->compute),
           packed(!staged && l->staged_ready && total_bytes <= Lane::PIECE / 2 && !getenv("GBX_HOST_PAGEABLE")) {}
     // an early return between start() and the last chunk_launched() must not leave the downloader waiting for a chunk
     // that will never be launched: such a pipe is cancelled, not finished
@@ -410,6 +420,7 @@ struct HostPipe {
         if (hipSetDevice(L->dev) != hipSuccess) { fail_hip(hipErrorInvalidDevice); return; }
         bool busy[2] = {false, false};
         int slot = 0;
+        const hipStream_t xw = (w & 1) ? xfer2 : xfer;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= pieces.size() || hip_err.load()) break;
@@ -424,9 +435,9 @@ struct HostPipe {
                     const char *q = p.src;
                     for (size_t k = 0, n = p.len / 4; k < n; ++k, q += p.stride) memcpy(o + k, q, 4);
                 } else memcpy(L->wslab[w][slot], p.src, p.len);
-                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.pack ? (p.len + 1) / 2 : p.len, hipMemcpyHostToDevice, xfer);
+                e = hipMemcpyAsync(p.dst, L->wslab[w][slot], p.pack ? (p.len + 1) / 2 : p.len, hipMemcpyHostToDevice, xw);
             }
-            if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], xfer);
+            if (e == hipSuccess) e = hipEventRecord(L->wev[w][slot], xw);
             if (e != hipSuccess) { fail_hip(e); return; }
             busy[slot] = true;
             slot ^= 1;
@@ -510,8 +521,8 @@ struct HostPipe {
             const char *s = (const char *)f.src;
             for (size_t left = f.len; left;) {
                 const size_t len = left < HALF ? left : HALF;
-                if ((e = hipMemcpyAsync(L->dslab + half * HALF, s, len, hipMemcpyDeviceToHost, xfer)) != hipSuccess) return e;
-                if ((e = hipEventRecord(L->ev_half[half], xfer)) != hipSuccess) return e;
+                if ((e = hipMemcpyAsync(L->dslab + half * HALF, s, len, hipMemcpyDeviceToHost, xdown)) != hipSuccess) return e;
+                if ((e = hipEventRecord(L->ev_half[half], xdown)) != hipSuccess) return e;
                 if (pend_len) {
                     if ((e = hipEventSynchronize(L->ev_half[half ^ 1])) != hipSuccess) return e;
                     deliver(half ^ 1);
@@ -578,11 +589,17 @@ struct HostPipe {
             if (abort_) return hip_fail((hipError_t)hip_err.load(), "host pipeline upload");
         }
         if (xfer != L->compute) {
+            if (xfer2 != xfer) {                 // the first upload stream waits for the second: one event then stands for both
+                GBX_HIP(hipEventRecord(L->ev_stage2, xfer2));
+                GBX_HIP(hipStreamWaitEvent(xfer, L->ev_stage2, 0));
+            }
             GBX_HIP(hipEventRecord(L->ev_stage, xfer));
             GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
         }
         return GBX_OK;
     }
+    // the event wait_stage() recorded behind the chunk's uploads (nullptr when they went on the compute stream itself)
+    hipEvent_t stage_event() const { return xfer != L->compute ? L->ev_stage : nullptr; }
     // a result array of chunk c (call before chunk_launched(c))
     void fetch(int64_t c, void *host_dst, const void *dev_src, size_t bytes)
     {
@@ -639,21 +656,43 @@ struct HostPipe {
         }
         // nothing of this call may still be in flight when the caller's device buffers are freed
         (void)hipStreamSynchronize(L->copy); (void)hipStreamSynchronize(L->compute);
+        if (L->copy2 != L->copy) (void)hipStreamSynchronize(L->copy2);
+        if (L->down != L->copy) (void)hipStreamSynchronize(L->down);
         if (rc) (void)hipDeviceSynchronize();        // kernels on the shared side streams too
         return rc;
     }
 };
 
-// pairs per pipeline chunk of gbx_bsw_extend_host: a multiple of 64.  Every chunk is a full set of class kernels,
-// and a launch needs several hundred thousand pairs to keep 256 CUs busy through the single-wavefront tails
-// (measured: +0.7 ms per extra chunk at 2 M pairs), so: at most 3 chunks, none below 512 Ki pairs.
-static int64_t bsw_host_chunk(int64_t n)
+// The pipeline chunks of gbx_bsw_extend_host: cuts[c] .. cuts[c + 1] are chunk c's pairs, every cut but the last a multiple
+// of 64.  Every chunk is a full set of class kernels, and a launch needs several hundred thousand pairs to keep 256 CUs
+// busy through the single-wavefront tails (measured: +0.7 ms per extra chunk at 2 M pairs), so: at most 3 equal chunks,
+// none below 512 Ki pairs.  GBX_BSW_HOST_CHUNK=<pairs> (the tests vary it) cuts into equal chunks of that size,
+// GBX_BSW_HOST_CUTS="0.2,0.6" at those fractions of the pairs (a small first chunk, so that the kernels start early, was
+// measured no faster than thirds: 10.5 against 10.3 ms, profiles/r05ae_cuts.txt).
+static std::vector<int64_t> bsw_host_cuts(int64_t n)
 {
-    const char *env = getenv("GBX_BSW_HOST_CHUNK");      /* read per call: the tests vary it */
-    if (env && atoll(env) > 0) return (atoll(env) + 63) & ~63LL;
-    int64_t c = (n + 2) / 3;
-    if (c < 524288) c = 524288;
-    return (c + 63) & ~63LL;
+    std::vector<int64_t> cuts(1, 0);
+    auto r64 = [](int64_t v) { return (v + 63) & ~63LL; };
+    const char *env = getenv("GBX_BSW_HOST_CHUNK");      /* read per call */
+    const char *frac = getenv("GBX_BSW_HOST_CUTS");
+    if (env && atoll(env) > 0) {
+        const int64_t c = r64(atoll(env));
+        for (int64_t a = c; a < n; a += c) cuts.push_back(a);
+    } else if (frac && *frac) {
+        for (const char *q = frac; *q;) {
+            const int64_t a = r64((int64_t)(atof(q) * (double)n));
+            if (a > cuts.back() && a < n) cuts.push_back(a);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    } else {
+        int64_t c = (n + 2) / 3;
+        if (c < 524288) c = 524288;
+        c = r64(c);
+        for (int64_t a = c; a < n; a += c) cuts.push_back(a);
+    }
+    cuts.push_back(n);
+    return cuts;
 }
 
 }  // namespace gbx

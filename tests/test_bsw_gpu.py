@@ -267,6 +267,26 @@ def test_lane_non_default_scoring(kw, lane):
     assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
 
 
+@pytest.mark.parametrize("env", [{}, {"GBX_BSW_PREP": "0"}, {"GBX_BSW_SKIP_ROWS": "0"}, {"GBX_COPY_STREAMS": "1", "GBX_DOWN_STREAM": "0"}])
+def test_lane_pipelined_chunks_with_and_without_row_kernel_pairs(lane, monkeypatch, env):
+    """The pipelined host call prepares a chunk (unpacking, classify, the lane sort) on streams of their own and leaves out
+    the row-kernel classes of a chunk whose pairs all go to the lane kernels: chunks with none, with a few (long queries,
+    in the third chunk only) and a ragged last one give the oracle's results, with each of the shortcuts switched off too."""
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    monkeypatch.setenv("GBX_BSW_HOST_CHUNK", "2048")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p = make_params()
+    b = gen_bsw(9000, 41)
+    want = O.bsw_oracle(p, b, 8)
+    assert_same(extend_host(p, b), want, b)
+    a = adversarial_bsw(40, 3, max_q=900, max_t=1200)          # row-kernel pairs, spliced in at 4100..4139
+    ref = np.concatenate([b.ref, a.ref]); qer = np.concatenate([b.qer, a.qer])
+    ins = lambda x, y: np.concatenate([x[:4100], y, x[4100:]])
+    m = BswBatch(ref, qer, ins(b.idr, a.idr + b.ref.size), ins(b.idq, a.idq + b.qer.size), ins(b.len1, a.len1), ins(b.len2, a.len2), ins(b.h0, a.h0))
+    assert_same(extend_host(p, m), O.bsw_oracle(p, m, 8), m)
+
+
 def test_lane_generated_reads_and_ragged_last_chunk(lane):
     b = gen_bsw(30_011, 77)                        # not a multiple of 64 in any length class
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
