@@ -55,6 +55,7 @@ struct BswPairs {
     const int64_t *idr, *idq;
     const int32_t *len1, *len2, *h0;
     gbx_bsw_result *out;
+    int packed = 0;        // 1: ref / qer are the packed images (two codes per byte), for launches of bsw_lane_kernel<.., PACKED> only
 };
 
 // workspace layout (ints): counts[HDR] | cursors[HDR] | base[HDR] (exclusive prefix of counts) | misc[HDR] | order[n] | wband[n]
@@ -722,7 +723,9 @@ __device__ __forceinline__ uint32_t lane_pair_step(uint32_t w, uint32_t qq, uint
 // wavefront ran; units of 256.
 __device__ unsigned long long g_bsw_lane_stats[16][4];
 #endif
-template <bool SYM, bool COMPACT, bool CODE4 = false>
+// PACKED: P.ref / P.qer are the packed images of the arenas (two base codes per byte, host_pipeline.h: pack4; code k of an
+// arena is nibble k & 1 of byte k >> 1) - the pipelined host call's chunks whose pairs all run here are never expanded.
+template <bool SYM, bool COMPACT, bool CODE4 = false, bool PACKED = false>
 __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, BswWork W, int rlo, int rhi, int cols, int slot)
 {
     extern __shared__ uint32_t lcell[];
@@ -774,20 +777,40 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         const bool have = idx >= 0;                     // only the last chunk of a launch is ragged: its spare lanes repeat entry 0
         const int pair = order[have ? idx : 0];
         const int qlen = P.len2[pair], tlen = P.len1[pair], h0 = P.h0[pair];
-        const uint8_t *q = P.qer + P.idq[pair];
-        const uint8_t *t = P.ref + P.idr[pair];
+        const int64_t qo = P.idq[pair], to = P.idr[pair];
+        const uint8_t *q = P.qer + (PACKED ? 0 : qo);
+        const uint8_t *t = P.ref + (PACKED ? 0 : to);
+        // sixteen query codes from column j on, as bytes; packed: nine bytes hold them, whichever half of the first one they start in
+        auto qpiece = [&](int j) -> uint4 {
+            uint4 r;
+            if (!PACKED) { __builtin_memcpy(&r, q + j, 16); return r; }
+            const int64_t o = qo + j;
+            const uint8_t *b = q + (o >> 1);
+            uint64_t v;
+            __builtin_memcpy(&v, b, 8);
+            if (o & 1) v = (v >> 4) | ((uint64_t)b[8] << 60);
+            auto spread = [](unsigned h) -> unsigned { return (h & 0xfu) | ((h & 0xf0u) << 4) | ((h & 0xf00u) << 8) | ((h & 0xf000u) << 12); };
+            const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+            r.x = spread(lo & 0xffffu); r.y = spread(lo >> 16); r.z = spread(hi & 0xffffu); r.w = spread(hi >> 16);
+            return r;
+        };
+        // the target's base of row i (the arenas, packed or not, are readable 16 codes past their last base)
+        auto tbase = [&](int i) -> int {
+            if (!PACKED) return t[i];
+            const int64_t o = to + i;
+            return (t[o >> 1] >> ((int)(o & 1) * 4)) & 15;
+        };
         // first row, :155-157, and the query codes (x 6: the bit offset of the score field in the matrix row word).  The query
         // comes in 16-byte pieces, the next one requested before the current one is unpacked (round 4: a byte load per column,
         // each waited for on the spot, was ~130 serial memory round trips per chunk of pairs - a tenth of a long-query
         // chunk's time, at 1.5 wavefronts per SIMD with little to hide it behind); the arenas are readable 16 bytes past
         // their last base.  Compact format: a column pair is one dword of cells and one halfword of codes.
         {
-            uint4 wq;
-            __builtin_memcpy(&wq, q, 16);
+            uint4 wq = qpiece(0);
             int hrun = h0 - oe_ins + e_ins;                 // h0 - oe_ins - (j - 1) e_ins at j = 0
             for (int j0 = 0; j0 <= qlen; j0 += 16) {
                 const uint4 cur = wq;
-                if (j0 + 16 <= qlen) __builtin_memcpy(&wq, q + j0 + 16, 16);
+                if (j0 + 16 <= qlen) wq = qpiece(j0 + 16);
                 const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
                 for (int c = 0; c < 16; c += 2) {
@@ -815,8 +838,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
         int beg = 0, end = qlen;
         // the matrix row of the target base two rows ahead of its use: row i's in registers, row i+1's on its way from the
         // table, the base of row i+2 on its way from memory (the arenas are readable 16 bytes past their last base)
-        uint4 mrow = LTAB(t[0]), mnext = LTAB(t[1]);
-        int tb2 = t[2];
+        uint4 mrow = LTAB(tbase(0)), mnext = LTAB(tbase(1));
+        int tb2 = tbase(2);
         const uint8_t *tp = t + 3;
         int hrow = h0 - prm.o_del - e_del;                 // h0 - (o_del + e_del * (i + 1))
         int imw = -w, ipw = w + 1;                         // i - w, i + w + 1
@@ -824,7 +847,8 @@ __global__ void __launch_bounds__(64) bsw_lane_kernel(BswDev prm, BswPairs P, Bs
             const uint32_t rw = COMPACT ? mrow.x : mrow.z, rwn = mrow.y;
             mrow = mnext;
             mnext = LTAB(tb2);
-            tb2 = *tp++;
+            if (PACKED) tb2 = tbase(i + 3);
+            else tb2 = *tp++;
             beg = max(beg, imw);                           // :179-181
             end = min(min(end, ipw), qlen);
             ++imw; ++ipw;
@@ -1241,7 +1265,15 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         GBX_HIP(hipStreamWaitEvent(ss->pre[0], prep->uploaded, 0));
         GBX_HIP(hipStreamWaitEvent(ss->pre[1], prep->uploaded, 0));
     }
-    if (prep && prep->ref_packed &&
+    // A chunk whose pairs all go to the lane kernels (the host entry has counted: rows_pairs == 0) leaves out the row-kernel
+    // classes, twenty-one near-empty launches that each wait for LDS behind the lane kernels, and its bases stay packed: the
+    // lane kernels read the nibbles (PACKED).  Beside the previous chunk's lane kernels the unpacking took 0.5-1.0 ms
+    // instead of 0.05, and the chunk's kernels wait for it (profiles/r05af_host_timeline.txt).
+    const bool no_rows = dev.lane_on && prep && prep->rows_pairs == 0 && !(getenv("GBX_BSW_SKIP_ROWS") && atoi(getenv("GBX_BSW_SKIP_ROWS")) == 0);
+    const bool packed_lanes = no_rows && prep->ref_packed && !(getenv("GBX_BSW_PACKED_LANES") && atoi(getenv("GBX_BSW_PACKED_LANES")) == 0);
+    if (packed_lanes) {
+        P.ref = prep->ref_packed; P.qer = prep->qer_packed; P.packed = 1;
+    } else if (prep && prep->ref_packed &&
         ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, prep->lo_r, prep->hi_r, s_cls)) ||
          (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, prep->lo_q, prep->hi_q, s_cls))))
         return rc;
@@ -1297,8 +1329,7 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     if (!serial && !sort_aside && !ahead && (rc = ss->fork(s))) return rc;
     // The row-kernel classes first.  With the lane path on they hold next to nothing (what the lane kernels cannot take):
     // twenty near-empty launches, all on the caller's stream, in the shadow of the lane sort.
-    // (none at all when the host entry has counted the chunk's pairs and the lane kernels take every one)
-    const bool no_rows = dev.lane_on && prep && prep->rows_pairs == 0 && !(getenv("GBX_BSW_SKIP_ROWS") && atoi(getenv("GBX_BSW_SKIP_ROWS")) == 0);
+    // (none at all when the host entry has counted the chunk's pairs and the lane kernels take every one: no_rows)
     int launched = 0;
     for (int c = 0; c < NCLS - 1 && !no_rows; ++c) {
         if (CLASS_REMAP[mode][c] != c) continue;          // this class's pairs run on a wider class's kernel
@@ -1355,15 +1386,17 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
                 if (blocks > want) blocks = want;
                 const int rlo = fmt * (LANE_QMAX + 1) + qlo, rhi = fmt * (LANE_QMAX + 1) + qhi, slot = fmt * LANE_NRANGE + r;
                 Stage st(names[fmt][r], sc);
-                if (fmt == 0 && code4) {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot); };
+                if (P.packed) {
+                    if (fmt == 0 && code4) { if (sym) go(bsw_lane_kernel<true, true, true, true>); else go(bsw_lane_kernel<false, true, true, true>); }
+                    else if (fmt == 0) { if (sym) go(bsw_lane_kernel<true, true, false, true>); else go(bsw_lane_kernel<false, true, false, true>); }
+                    else { if (sym) go(bsw_lane_kernel<true, false, false, true>); else go(bsw_lane_kernel<false, false, false, true>); }
+                } else if (fmt == 0 && code4) {
+                    if (sym) go(bsw_lane_kernel<true, true, true>); else go(bsw_lane_kernel<false, true, true>);
                 } else if (fmt == 0) {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, true>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    if (sym) go(bsw_lane_kernel<true, true>); else go(bsw_lane_kernel<false, true>);
                 } else {
-                    if (sym) hipLaunchKernelGGL((bsw_lane_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
-                    else hipLaunchKernelGGL((bsw_lane_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, sc, dev, P, W, rlo, rhi, cols, slot);
+                    if (sym) go(bsw_lane_kernel<true, false>); else go(bsw_lane_kernel<false, false>);
                 }
             }
         }

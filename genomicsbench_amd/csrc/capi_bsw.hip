@@ -68,8 +68,8 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     int64_t chunk = 0;                                          // the largest chunk
     for (int64_t c = 0; c < n_chunks; ++c) chunk = cut[(size_t)c + 1] - cut[(size_t)c] > chunk ? cut[(size_t)c + 1] - cut[(size_t)c] : chunk;
     std::vector<int64_t> need_r((size_t)n_chunks), need_q((size_t)n_chunks);
-    // slices of 64 Ki pairs, a few threads when there are many; the lowest failing pair is reported
-    const int64_t SL = 65536, n_slices = (n + SL - 1) / SL;
+    // slices of 32 Ki pairs, a few threads when there are many; the lowest failing pair is reported
+    const int64_t SL = 32768, n_slices = (n + SL - 1) / SL;
     std::vector<int64_t> slice_r((size_t)n_slices), slice_q((size_t)n_slices), slice_bad((size_t)n_slices, -1);
     std::vector<int64_t> slice_rows((size_t)n_slices, 0);   // pairs the lane kernels will not take (BswChunkPrep::rows_pairs)
     BswLaneRule rule = {0, 0, 0, 0};
@@ -94,28 +94,36 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         }
         slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0; slice_rows[(size_t)sl] = rows;
     };
-    {
-        const int vt = n_slices >= 16 ? 8 : n_slices >= 8 ? 4 : 1;      // 0.9 ms with 4 threads at 2 M pairs, on the call's critical path
-        std::vector<std::thread> th;
-        for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = t; sl < n_slices; sl += vt) check_slice(sl); });
-        for (int64_t sl = 0; sl < n_slices; sl += vt) check_slice(sl);
+    // slices [s0, s1): checked by a few threads; the lowest failing pair is reported
+    auto validate = [&](int64_t s0, int64_t s1) -> int {
+        const int64_t cnt = s1 - s0;
+        const int vt = cnt >= 24 ? 12 : cnt >= 8 ? (int)(cnt / 2) : 1;      // 2.5 ns a pair and thread: 0.9 ms with 4 threads at 2 M pairs
+        std::vector<Helper> th;
+        for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = s0 + t; sl < s1; sl += vt) check_slice(sl); });
+        for (int64_t sl = s0; sl < s1; sl += vt) check_slice(sl);
         for (auto &x : th) x.join();
-    }
-    for (int64_t sl = 0; sl < n_slices; ++sl) {
-        const int64_t k = slice_bad[(size_t)sl];
-        if (k < 0) continue;
-        if (len1[k] >= 0 && len2[k] >= 0 && idr[k] >= 0 && idq[k] >= 0 && idr[k] + len1[k] <= ref_bytes &&
-            idq[k] + len2[k] <= qer_bytes) {
-            set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)(base + k));
-            return GBX_ERR_UNSUPPORTED;
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            const int64_t k = slice_bad[(size_t)sl];
+            if (k < 0) continue;
+            if (len1[k] >= 0 && len2[k] >= 0 && idr[k] >= 0 && idq[k] >= 0 && idr[k] + len1[k] <= ref_bytes &&
+                idq[k] + len2[k] <= qer_bytes) {
+                set_error("gbx_bsw_extend_host: pair %lld exceeds GBX_BSW_MAX_QLEN/TLEN", (long long)(base + k));
+                return GBX_ERR_UNSUPPORTED;
+            }
+            set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)(base + k));
+            return GBX_ERR_ARG;
         }
-        set_error("gbx_bsw_extend_host: pair %lld lies outside the arenas", (long long)(base + k));
-        return GBX_ERR_ARG;
-    }
+        return GBX_OK;
+    };
+    // A pipelined call checks the first chunk's pairs, starts its upload, and checks the rest while it is on its way (the
+    // whole pass is 0.75 ms at 2 M pairs, and nothing else of the call can start before the first chunk is on the device).
+    const int64_t s_first = n_chunks > 1 && (cut[1] + SL - 1) / SL < n_slices ? (cut[1] + SL - 1) / SL : n_slices;
+    int rc = validate(0, s_first);
+    if (rc) return rc;
     std::vector<int64_t> rows_pairs((size_t)n_chunks, -1);
-    for (int64_t c = 0; c < n_chunks; ++c) {
+    auto chunk_needs = [&](int64_t c) {
         int64_t mr = 0, mq = 0, rows = 0;
-        // chunks are multiples of 64 pairs, slices of 65536: a slice may straddle two chunks, which only makes
+        // chunks are multiples of 64 pairs, slices of 32768: a slice may straddle two chunks, which only makes
         // the earlier chunk wait for a few more bytes
         for (int64_t sl = cut[(size_t)c] / SL; sl < n_slices && sl * SL < cut[(size_t)c + 1]; ++sl) {
             mr = slice_r[(size_t)sl] > mr ? slice_r[(size_t)sl] : mr;
@@ -128,11 +136,11 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         const int64_t m = cut[(size_t)c + 1] - cut[(size_t)c];
         if (m != chunk && bsw_lane_rule(p, m, &last) != GBX_OK) last.on = 0;
         rows_pairs[(size_t)c] = rule.on && last.on ? rows : -1;
-    }
-    int rc = require_device();
-    if (rc) return rc;
+    };
+    chunk_needs(0);
+    if ((rc = require_device())) return rc;
     auto mark = [&](const char *what, int64_t k) { if (trace) fprintf(stderr, "[gbx host] %8.3f ms %s %lld\n", (wall_s() - t_begin) * 1e3, what, (long long)k); };
-    mark("validated", n);
+    mark("validated", s_first * SL < n ? s_first * SL : n);
     // Upload, compute and download are pipelined over chunks of pairs (host_pipeline.h).  Chunk k's bases and
     // index slices go up while earlier chunks run; the arenas are uploaded front to back up to the furthest
     // byte any pair seen so far needs (a running maximum), which is right for every offset layout and streams
@@ -160,7 +168,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     if (pack_bases && ((rc = dref_p.alloc((size_t)ref_bytes / 2 + 16)) || (rc = dqer_p.alloc((size_t)qer_bytes / 2 + 16)))) return rc;
     std::vector<int64_t> lo_r((size_t)n_chunks), hi_r((size_t)n_chunks), lo_q((size_t)n_chunks), hi_q((size_t)n_chunks);
     int64_t up_r = 0, up_q = 0;
-    for (int64_t c = 0; c < n_chunks; ++c) {
+    auto stage_chunk = [&](int64_t c) {
         const int64_t a = cut[(size_t)c], m = cut[(size_t)c + 1] - a;
         int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
         int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
@@ -181,9 +189,17 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         pipe.stage(c, dl2.as<int32_t>() + a, len2 + a, m * 4);
         pipe.stage(c, dh0.as<int32_t>() + a, h0 + a, m * 4);
         up_r = nr; up_q = nq;
-    }
+    };
+    stage_chunk(0);
+    if (n_chunks > 1) pipe.keep_open();
     pipe.start();
     mark("pipeline started, chunks", n_chunks);
+    if (n_chunks > 1) {
+        if ((rc = validate(s_first, n_slices))) return pipe.finish(rc);
+        for (int64_t c = 1; c < n_chunks; ++c) { chunk_needs(c); stage_chunk(c); }
+        pipe.seal();
+        mark("all chunks staged", n);
+    }
     // small jobs of plain pairs: one kernel launch instead of the binning passes and the class kernels
     bool direct = n <= 16384 && n_chunks == 1 && !(getenv("GBX_BSW_DIRECT") && atoi(getenv("GBX_BSW_DIRECT")) == 0);
     int direct_q = 1;

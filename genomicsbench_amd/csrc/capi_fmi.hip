@@ -331,14 +331,14 @@ int gbx_fmi_smem_host(const gbx_fmi_index *idx, const gbx_fmi_params *p, int64_t
         set_error("gbx_fmi_smem_host: %lld SMEMs do not fit out_cap = %lld", (long long)total, (long long)out_cap);
         return GBX_ERR_ARG;
     }
-    std::vector<std::thread> th;
+    std::vector<Helper> th;
     auto merge = [&](int k) {
         const int64_t lo = cuts[(size_t)k], m = cuts[(size_t)k + 1] - lo, f = first[(size_t)k];
         const gbx_fmi_smem *src = bufs[(size_t)k].data();
         for (int64_t j = 0; j < counts[(size_t)k]; ++j) { gbx_fmi_smem rec = src[j]; rec.rid += (uint32_t)lo; out[f + j] = rec; }
         if (smem_off && m > 0) for (int64_t r = 0; r < m; ++r) smem_off[lo + r] = offs[(size_t)k][(size_t)r] + f;
     };
-    for (int k = 1; k < parts; ++k) th.emplace_back(merge, k);
+    for (int k = 1; k < parts; ++k) th.emplace_back([&, k] { merge(k); });
     merge(0);
     for (auto &t : th) t.join();
     if (smem_off) smem_off[n_reads] = total;

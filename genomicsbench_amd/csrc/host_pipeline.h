@@ -14,7 +14,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <thread>
+#include <type_traits>
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -26,13 +28,88 @@ static double wall_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// fn(t, lo, hi) over [0, n) split into `threads` contiguous ranges (short-lived threads; the caller's thread takes
+// A thread from a cache of idle ones: what std::thread is used for in the host entries (a few helpers for the length of one
+// call or one pass), without creating threads per call - eighteen of them cost a 2 M-pair bsw call 0.5-0.7 ms of its 10.
+// Same use as std::thread: construct from a callable, join().  The operating-system threads are detached and never end;
+// one that has finished its task waits for the next.  A task always starts at once (an idle thread, else a new one), so
+// tasks that wait for each other (upload workers, the downloader) cannot block one another out.
+class Helper {
+    struct Worker {
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has = false, done = false;
+        void loop()
+        {
+            for (;;) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return has; });
+                std::function<void()> f = std::move(job);
+                has = false;
+                lk.unlock();
+                f();
+                f = nullptr;
+                lk.lock();
+                done = true;
+                cv.notify_all();
+            }
+        }
+    };
+    struct Cache { std::mutex mu; std::vector<Worker *> idle; };
+    static Cache &cache() { static Cache *c = new Cache(); return *c; }      // never destroyed: its threads outlive static destruction
+    Worker *w = nullptr;
+
+public:
+    Helper() = default;
+    template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Helper>::value>::type>
+    explicit Helper(F &&f)
+    {
+        Cache &c = cache();
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            if (!c.idle.empty()) { w = c.idle.back(); c.idle.pop_back(); }
+        }
+        if (!w) {
+            Worker *n = new Worker();
+            try { std::thread([n] { n->loop(); }).detach(); }
+            catch (...) { delete n; throw; }
+            w = n;
+        }
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->job = std::forward<F>(f);
+            w->has = true;
+            w->done = false;
+        }
+        w->cv.notify_all();
+    }
+    Helper(Helper &&o) noexcept : w(o.w) { o.w = nullptr; }
+    Helper &operator=(Helper &&o) noexcept { if (this != &o) { join(); w = o.w; o.w = nullptr; } return *this; }
+    Helper(const Helper &) = delete;
+    Helper &operator=(const Helper &) = delete;
+    bool joinable() const { return w != nullptr; }
+    void join()
+    {
+        if (!w) return;
+        {
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->done; });
+        }
+        Cache &c = cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.idle.push_back(w);
+        w = nullptr;
+    }
+    ~Helper() { join(); }
+};
+
+// fn(t, lo, hi) over [0, n) split into `threads` contiguous ranges (helper threads; the caller's thread takes
 // range 0)
 template <class F> static void parallel_ranges(int64_t n, int threads, F fn)
 {
     if (threads > n / 4096) threads = (int)(n / 4096);
     if (threads <= 1) { fn(0, (int64_t)0, n); return; }
-    std::vector<std::thread> th;
+    std::vector<Helper> th;
     for (int t = 1; t < threads; ++t) th.emplace_back([=] { fn(t, n * t / threads, n * (t + 1) / threads); });
     fn(0, (int64_t)0, n / threads);
     for (auto &x : th) x.join();
@@ -119,11 +196,31 @@ static int lane_prepare_staging(Lane *l)
             if (!l->wev[w][k]) GBX_HIP(hipEventCreateWithFlags(&l->wev[w][k], hipEventDisableTiming));
         }
     if (!l->dslab) GBX_HIP(hipHostMalloc((void **)&l->dslab, Lane::DOWN, hipHostMallocDefault));
-    std::vector<std::thread> th;
+    std::vector<Helper> th;
     for (int w = 0; w < Lane::MAX_WORKERS; ++w)
         th.emplace_back([=] { memset(l->wslab[w][0], 0, Lane::PIECE); memset(l->wslab[w][1], 0, Lane::PIECE); });
     memset(l->dslab, 0, Lane::DOWN);
     for (auto &x : th) x.join();
+    // one small DMA from every slab on the stream its worker will use, one to the download slab, an event behind each: what
+    // the runtime sets up at the first use of a stream or of a slab by a DMA engine (measured: 15 ms over the first two
+    // large calls of a process) is paid here, not by a call
+    if (l->copy && l->copy != l->compute) {
+        void *scratch = nullptr;
+        GBX_HIP(hipMalloc(&scratch, (size_t)3 << 20));            // a megabyte per stream: nothing here touches the same bytes twice at once
+        hipError_t e = hipSuccess;
+        for (int w = 0; w < Lane::MAX_WORKERS && e == hipSuccess; ++w)
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                const hipStream_t xw = (w & 1) ? l->copy2 : l->copy;
+                e = hipMemcpyAsync((char *)scratch + ((size_t)(w & 1) << 20), l->wslab[w][k], (size_t)1 << 20, hipMemcpyHostToDevice, xw);
+                if (e == hipSuccess) e = hipEventRecord(l->wev[w][k], xw);
+            }
+        if (e == hipSuccess) e = hipMemsetAsync((char *)scratch + ((size_t)2 << 20), 0, (size_t)1 << 20, l->down);
+        if (e == hipSuccess) e = hipMemcpyAsync(l->dslab, (char *)scratch + ((size_t)2 << 20), (size_t)1 << 20, hipMemcpyDeviceToHost, l->down);
+        if (e == hipSuccess) e = hipEventRecord(l->ev_half[0], l->down);
+        for (hipStream_t x : {l->copy, l->copy2, l->down}) { const hipError_t e2 = hipStreamSynchronize(x); if (e == hipSuccess) e = e2; }
+        (void)hipFree(scratch);
+        if (e != hipSuccess) return hip_fail(e, "host lane warm-up");
+    }
     l->staged_ready = true;
     return GBX_OK;
 }
@@ -245,7 +342,7 @@ struct DevBuf {
 // the calling thread and returns when all are done; only the downloader thread calls it.
 struct CopyPool {
     struct Job { char *dst; const char *src; size_t n; };
-    std::vector<std::thread> th;
+    std::vector<Helper> th;
     std::mutex mu;
     std::condition_variable cv, done_cv;
     const std::vector<Job> *jobs = nullptr;
@@ -329,10 +426,17 @@ struct HostPipe {
     int64_t launched = 0, n_chunks = 0;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<std::thread> threads;
+    std::vector<Helper> threads;
     CopyPool pool;                         // the downloader's copy helpers (staged calls)
     bool started = false;
+    bool open_ = false;                    // staged calls: more pieces may be staged after start() (keep_open() .. seal())
 
+    // stage*() after start() (keep_open() calls only): the workers are reading the list
+    struct StageLock {
+        HostPipe *p;
+        explicit StageLock(HostPipe *q) : p(q->started ? q : nullptr) { if (p) p->mu.lock(); }
+        ~StageLock() { if (p) { p->mu.unlock(); p->cv.notify_all(); } }
+    };
     static size_t stage_min()
     {
         const char *env = getenv("GBX_HOST_STAGE_MIN");      /* bytes; the tests set 0 to stage small inputs too */
@@ -370,6 +474,7 @@ struct HostPipe {
     }
     void stage(int64_t chunk, void *dst, const void *src, size_t bytes)
     {
+        StageLock lk(this);
         char *d = (char *)dst;
         const char *s = (const char *)src;
         const size_t cap = staged ? Lane::PIECE : bytes;
@@ -384,6 +489,7 @@ struct HostPipe {
     // even): byte k of the arena's packed image on the device holds codes 2k and 2k+1
     void stage_pack4(int64_t chunk, void *dst_packed, const void *src, size_t bytes)
     {
+        StageLock lk(this);
         char *d = (char *)dst_packed;
         const char *s = (const char *)src;
         while (bytes) {
@@ -397,6 +503,7 @@ struct HostPipe {
     // gather the field into the pinned slab instead of copying, so no compact host copy is ever made (staged calls only)
     void stage_field4(int64_t chunk, void *dst, const void *first_field, size_t n_records, int stride)
     {
+        StageLock lk(this);
         char *d = (char *)dst;
         const char *s = (const char *)first_field;
         const size_t per = Lane::PIECE / 4;
@@ -422,9 +529,15 @@ struct HostPipe {
         int slot = 0;
         const hipStream_t xw = (w & 1) ? xfer2 : xfer;
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= pieces.size() || hip_err.load()) break;
-            const Piece &p = pieces[i];
+            Piece p;
+            {   // the next piece, or wait for one while the caller may still stage more (the vector can grow: a copy is taken)
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort_ || !open_ || next.load() < pieces.size(); });
+                const size_t i = next.load();
+                if (abort_ || i >= pieces.size() || hip_err.load()) break;
+                next.store(i + 1);
+                p = pieces[i];
+            }
             hipError_t e = hipSuccess;
             if (busy[slot]) e = hipEventSynchronize(L->wev[w][slot]);
             if (e == hipSuccess) {
@@ -552,6 +665,16 @@ struct HostPipe {
             if (e != hipSuccess) { fail_hip(e); return; }
         }
     }
+    // Staged calls that stage their first chunk, start(), and stage the rest while it uploads (bsw: the later chunks' pairs
+    // are validated meanwhile): keep_open() before start(), seal() after the last stage*() - and before wait_stage() of
+    // any chunk staged after start().
+    void keep_open() { open_ = staged; }
+    void seal()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        open_ = false;
+        cv.notify_all();
+    }
     void start()
     {
         started = true;
@@ -634,6 +757,7 @@ struct HostPipe {
     {
         std::lock_guard<std::mutex> lk(mu);
         abort_ = true;
+        open_ = false;
         next = pieces.size();
         cv.notify_all();
     }
@@ -643,6 +767,7 @@ struct HostPipe {
         if (!started) return rc_in;
         started = false;
         if (rc_in) cancel();
+        else seal();
         for (auto &t : threads) t.join();
         threads.clear();
         pool.shutdown();

@@ -81,7 +81,9 @@ static int call_one_chunk(size_t n, uint64_t seed, bool expect_ok)
 
 // shaped like gbx_bsw_extend_host: three chunks, transfers on the copy stream overlapping the kernels, bases packed two
 // per byte on the way up, a second kernel stream per chunk with its own join event
-static int call_three_chunks(size_t per, uint64_t seed)
+// late: only the first chunk is staged before start(), the others while it uploads (keep_open() .. seal(), as the bsw entry
+// does while it checks the later chunks' pairs); abandon_open: the call gives up before seal()
+static int call_three_chunks(size_t per, uint64_t seed, bool late = false, bool abandon_open = false)
 {
     const int C = 3;
     std::vector<uint8_t> base = random_bytes(per * C, seed, 5);
@@ -94,8 +96,16 @@ static int call_three_chunks(size_t per, uint64_t seed)
     if ((rc = dpacked.alloc(per * C / 2 + 8)) || (rc = dout.alloc(per * C * 4))) return rc;
     HostPipe pipe(L, per * C, true);
     if ((rc = pipe.prepare(C))) return rc;
-    for (int c = 0; c < C; ++c) pipe.stage_pack4(c, dpacked.as<uint8_t>() + (size_t)c * per / 2, base.data() + (size_t)c * per, per);
+    for (int c = 0; c < (late ? 1 : C); ++c) pipe.stage_pack4(c, dpacked.as<uint8_t>() + (size_t)c * per / 2, base.data() + (size_t)c * per, per);
+    if (late) pipe.keep_open();
     pipe.start();
+    if (late) {
+        std::this_thread::sleep_for(std::chrono::microseconds(200 + seed % 700));       // the workers run dry and wait
+        pipe.stage_pack4(1, dpacked.as<uint8_t>() + per / 2, base.data() + per, per);
+        if (abandon_open) return pipe.finish(GBX_ERR_ARG);
+        pipe.stage_pack4(2, dpacked.as<uint8_t>() + per, base.data() + 2 * per, per);
+        pipe.seal();
+    }
     for (int c = 0; c < C; ++c) {
         if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
         const uint8_t *pk = dpacked.as<uint8_t>() + (size_t)c * per / 2;
@@ -197,6 +207,8 @@ int main(int argc, char **argv)
                 CHECK(call_one_chunk((size_t)3 << 20, seed, true) == GBX_OK, "staged one-chunk call: %s", g_err);
                 CHECK(call_one_chunk(5000 + 977 * (size_t)t, seed + 7, true) == GBX_OK, "small (unstaged / packed) call: %s", g_err);
                 CHECK(call_three_chunks(((size_t)1 << 20) + 64 * (size_t)t, seed + 13) == GBX_OK, "three-chunk call: %s", g_err);
+                CHECK(call_three_chunks(((size_t)1 << 20) + 64 * (size_t)t, seed + 14, true) == GBX_OK, "three-chunk call staged late: %s", g_err);
+                CHECK(call_three_chunks(((size_t)1 << 20) + 64 * (size_t)t, seed + 15, true, true) == GBX_ERR_ARG, "three-chunk call abandoned before seal()");
                 CHECK(call_field_and_scatter(150000 + 1000 * (size_t)t, seed + 17) == GBX_OK, "field / scatter call: %s", g_err);
                 CHECK(call_field_and_scatter(300, seed + 19) == GBX_OK, "small field call: %s", g_err);
                 call_abandoned((size_t)1 << 20, seed + 23);

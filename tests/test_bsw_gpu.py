@@ -267,11 +267,13 @@ def test_lane_non_default_scoring(kw, lane):
     assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
 
 
-@pytest.mark.parametrize("env", [{}, {"GBX_BSW_PREP": "0"}, {"GBX_BSW_SKIP_ROWS": "0"}, {"GBX_COPY_STREAMS": "1", "GBX_DOWN_STREAM": "0"}])
+@pytest.mark.parametrize("env", [{}, {"GBX_BSW_PREP": "0"}, {"GBX_BSW_SKIP_ROWS": "0"}, {"GBX_BSW_PACKED_LANES": "0"},
+                                 {"GBX_COPY_STREAMS": "1", "GBX_DOWN_STREAM": "0"}])
 def test_lane_pipelined_chunks_with_and_without_row_kernel_pairs(lane, monkeypatch, env):
     """The pipelined host call prepares a chunk (unpacking, classify, the lane sort) on streams of their own and leaves out
-    the row-kernel classes of a chunk whose pairs all go to the lane kernels: chunks with none, with a few (long queries,
-    in the third chunk only) and a ragged last one give the oracle's results, with each of the shortcuts switched off too."""
+    the row-kernel classes of a chunk whose pairs all go to the lane kernels, which then read the packed bases as they were
+    uploaded: chunks with none, with a few (long queries, in the third chunk only) and a ragged last one give the oracle's
+    results, with each of the shortcuts switched off too."""
     monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
     monkeypatch.setenv("GBX_BSW_HOST_CHUNK", "2048")
     for k, v in env.items():
