@@ -1261,56 +1261,73 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
     static const bool prep_off = getenv("GBX_BSW_PREP") && atoi(getenv("GBX_BSW_PREP")) == 0;
     const bool ahead = prep && prep->uploaded && join_events && !serial && !prep_off;
     hipStream_t s_cls = ahead ? ss->pre[0] : s;
-    if (ahead) {
-        GBX_HIP(hipStreamWaitEvent(ss->pre[0], prep->uploaded, 0));
-        GBX_HIP(hipStreamWaitEvent(ss->pre[1], prep->uploaded, 0));
-    }
     // A chunk whose pairs all go to the lane kernels (the host entry has counted: rows_pairs == 0) leaves out the row-kernel
     // classes, twenty-one near-empty launches that each wait for LDS behind the lane kernels, and its bases stay packed: the
     // lane kernels read the nibbles (PACKED).  Beside the previous chunk's lane kernels the unpacking took 0.5-1.0 ms
     // instead of 0.05, and the chunk's kernels wait for it (profiles/r05af_host_timeline.txt).
     const bool no_rows = dev.lane_on && prep && prep->rows_pairs == 0 && !(getenv("GBX_BSW_SKIP_ROWS") && atoi(getenv("GBX_BSW_SKIP_ROWS")) == 0);
     const bool packed_lanes = no_rows && prep->ref_packed && !(getenv("GBX_BSW_PACKED_LANES") && atoi(getenv("GBX_BSW_PACKED_LANES")) == 0);
-    if (packed_lanes) {
-        P.ref = prep->ref_packed; P.qer = prep->qer_packed; P.packed = 1;
-    } else if (prep && prep->ref_packed &&
-        ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, prep->lo_r, prep->hi_r, s_cls)) ||
-         (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, prep->lo_q, prep->hi_q, s_cls))))
-        return rc;
-    GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s_cls));
-    // The lane sort (0.3 ms on 'large': two passes of scattered atomics) runs on a side stream of its own, beside
-    // classify and the row-kernel classes on the caller's stream, which do not need it; the lane launches wait for it.
-    const bool sort_aside = dev.lane_on && !serial;
-    if (dev.lane_on) {
-        hipStream_t so = s;
-        if (ahead) {
-            so = ss->pre[1];
-            GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), so));
-        } else {
-            GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
-            if (sort_aside) {
-                if ((rc = ss->fork(s))) return rc;
-                so = ss->side[SideStreams::N - 1];
-            }
-        }
-        Stage st("bsw_lane_sort", so);
-        const int sblocks = (int)((n + 255) / 256);
-        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_lane_scan_kernel, dim3(1), dim3(1024), 0, so, W);
-        hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 1);
-        if (sort_aside) GBX_HIP(hipEventRecord(ss->ev_aux, so));
+    // Such a chunk's launch can also come in two calls (BswChunkPrep::phase): the preparing passes as soon as the chunk's index
+    // arrays are up - they read nothing else - and the kernels when its bases are.  A phase-1 call that cannot be split
+    // (a chunk with row-kernel pairs, a switch set) queues nothing and returns 1: the caller then makes one whole call.
+    const int phase = prep ? prep->phase : 0;
+    if (phase && !(ahead && packed_lanes && prep->ev_pre && prep->ev_aux)) {
+        if (phase == 1) return 1;
+        set_error("bsw: the kernels of a chunk whose preparing passes were not queued");
+        return GBX_ERR_ARG;
     }
-    const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
-    {
-        Stage st("bsw_classify", s_cls);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 0);
-        hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(HDR), 0, s_cls, W);
-        hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 1);
+    hipEvent_t ev_pre = phase ? prep->ev_pre : ss ? ss->ev_pre : nullptr, ev_aux = phase ? prep->ev_aux : ss ? ss->ev_aux : nullptr;
+    const bool sort_aside = dev.lane_on && !serial;
+    if (packed_lanes) { P.ref = prep->ref_packed; P.qer = prep->qer_packed; P.packed = 1; }
+    if (phase != 2) {
+        if (ahead) {
+            GBX_HIP(hipStreamWaitEvent(ss->pre[0], prep->uploaded, 0));
+            GBX_HIP(hipStreamWaitEvent(ss->pre[1], prep->uploaded, 0));
+        }
+        if (!packed_lanes && prep && prep->ref_packed &&
+            ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, prep->lo_r, prep->hi_r, s_cls)) ||
+             (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, prep->lo_q, prep->hi_q, s_cls))))
+            return rc;
+        GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s_cls));
+        // The lane sort (0.3 ms on 'large': two passes of scattered atomics) runs on a side stream of its own, beside
+        // classify and the row-kernel classes on the caller's stream, which do not need it; the lane launches wait for it.
+        if (dev.lane_on) {
+            hipStream_t so = s;
+            if (ahead) {
+                so = ss->pre[1];
+                GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), so));
+            } else {
+                GBX_HIP(hipMemsetAsync(wl, 0, (size_t)WS_LANE * sizeof(int32_t), s));
+                if (sort_aside) {
+                    if ((rc = ss->fork(s))) return rc;
+                    so = ss->side[SideStreams::N - 1];
+                }
+            }
+            Stage st("bsw_lane_sort", so);
+            const int sblocks = (int)((n + 255) / 256);
+            hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 0);
+            hipLaunchKernelGGL(bsw_lane_scan_kernel, dim3(1), dim3(1024), 0, so, W);
+            hipLaunchKernelGGL(bsw_lane_sort_kernel, dim3(sblocks), dim3(256), 0, so, dev, P, n, W, 1);
+            if (sort_aside) GBX_HIP(hipEventRecord(ev_aux, so));
+        }
+        const int cblocks = (int)((n + CLS_THREADS - 1) / CLS_THREADS);
+        {
+            Stage st("bsw_classify", s_cls);
+            hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 0);
+            hipLaunchKernelGGL(bsw_scan_kernel, dim3(1), dim3(HDR), 0, s_cls, W);
+            hipLaunchKernelGGL(bsw_classify_kernel, dim3(cblocks), dim3(CLS_THREADS), 0, s_cls, dev, P, n, W, 1);
+        }
+        if (ahead) GBX_HIP(hipEventRecord(ev_pre, s_cls));
+        GBX_HIP(hipGetLastError());
+        if (phase == 1) return GBX_OK;
     }
     if (ahead) {                                                 // the kernel streams wait for classify (and, below, for the sort)
-        GBX_HIP(hipEventRecord(ss->ev_pre, s_cls));
-        GBX_HIP(hipStreamWaitEvent(s, ss->ev_pre, 0));
-        for (int k = 0; k < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_pre, 0));
+        GBX_HIP(hipStreamWaitEvent(s, ev_pre, 0));
+        for (int k = 0; k < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ev_pre, 0));
+        if (phase == 2) {                                        // ... and for the bases, which the preparing passes did not
+            GBX_HIP(hipStreamWaitEvent(s, prep->uploaded, 0));
+            for (int k = 0; k < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], prep->uploaded, 0));
+        }
     }
 
     int dev_id = 0, cus = 256;
@@ -1356,8 +1373,8 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
         hipLaunchKernelGGL(k->fn[sym], dim3(grid_for(256 / k->lpp, bpc)), dim3(256), 0, sc, dev, P, W, c);
     }
     if (sort_aside) {                                          // the lane launches need the sorted lists (the sort's own stream has them in order)
-        GBX_HIP(hipStreamWaitEvent(s, ss->ev_aux, 0));
-        for (int k = 0; k + (ahead ? 0 : 1) < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ss->ev_aux, 0));
+        GBX_HIP(hipStreamWaitEvent(s, ev_aux, 0));
+        for (int k = 0; k + (ahead ? 0 : 1) < SideStreams::N; ++k) GBX_HIP(hipStreamWaitEvent(ss->side[k], ev_aux, 0));
     }
     if (dev.lane_on) {
         // longest queries first, one launch per format and LDS class, spread over the streams; grids = resident wavefronts

@@ -168,26 +168,28 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     if (pack_bases && ((rc = dref_p.alloc((size_t)ref_bytes / 2 + 16)) || (rc = dqer_p.alloc((size_t)qer_bytes / 2 + 16)))) return rc;
     std::vector<int64_t> lo_r((size_t)n_chunks), hi_r((size_t)n_chunks), lo_q((size_t)n_chunks), hi_q((size_t)n_chunks);
     int64_t up_r = 0, up_q = 0;
+    // Two upload stages per chunk: its index arrays (stage 2c: all the preparing passes read) and then its bases (2c + 1)
+    pipe.upload_stages(2 * n_chunks);
     auto stage_chunk = [&](int64_t c) {
         const int64_t a = cut[(size_t)c], m = cut[(size_t)c + 1] - a;
+        pipe.stage(2 * c, didr.as<int64_t>() + a, idr + a, m * 8);
+        pipe.stage(2 * c, didq.as<int64_t>() + a, idq + a, m * 8);
+        pipe.stage(2 * c, dl1.as<int32_t>() + a, len1 + a, m * 4);
+        pipe.stage(2 * c, dl2.as<int32_t>() + a, len2 + a, m * 4);
+        pipe.stage(2 * c, dh0.as<int32_t>() + a, h0 + a, m * 4);
         int64_t nr = need_r[(size_t)c] > up_r ? need_r[(size_t)c] : up_r;
         int64_t nq = need_q[(size_t)c] > up_q ? need_q[(size_t)c] : up_q;
         if (pack_bases) {
             // packed ranges start at even offsets: round the ends up to even while the arena allows it
             if ((nr & 1) && nr < ref_bytes) ++nr;
             if ((nq & 1) && nq < qer_bytes) ++nq;
-            pipe.stage_pack4(c, dref_p.as<uint8_t>() + up_r / 2, ref + up_r, (size_t)(nr - up_r));
-            pipe.stage_pack4(c, dqer_p.as<uint8_t>() + up_q / 2, qer + up_q, (size_t)(nq - up_q));
+            pipe.stage_pack4(2 * c + 1, dref_p.as<uint8_t>() + up_r / 2, ref + up_r, (size_t)(nr - up_r));
+            pipe.stage_pack4(2 * c + 1, dqer_p.as<uint8_t>() + up_q / 2, qer + up_q, (size_t)(nq - up_q));
             lo_r[(size_t)c] = up_r; hi_r[(size_t)c] = nr; lo_q[(size_t)c] = up_q; hi_q[(size_t)c] = nq;
         } else {
-            pipe.stage(c, dref.as<uint8_t>() + up_r, ref + up_r, (size_t)(nr - up_r));
-            pipe.stage(c, dqer.as<uint8_t>() + up_q, qer + up_q, (size_t)(nq - up_q));
+            pipe.stage(2 * c + 1, dref.as<uint8_t>() + up_r, ref + up_r, (size_t)(nr - up_r));
+            pipe.stage(2 * c + 1, dqer.as<uint8_t>() + up_q, qer + up_q, (size_t)(nq - up_q));
         }
-        pipe.stage(c, didr.as<int64_t>() + a, idr + a, m * 8);
-        pipe.stage(c, didq.as<int64_t>() + a, idq + a, m * 8);
-        pipe.stage(c, dl1.as<int32_t>() + a, len1 + a, m * 4);
-        pipe.stage(c, dl2.as<int32_t>() + a, len2 + a, m * 4);
-        pipe.stage(c, dh0.as<int32_t>() + a, h0 + a, m * 4);
         up_r = nr; up_q = nq;
     };
     stage_chunk(0);
@@ -208,7 +210,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         direct_q = slice_plain[(size_t)sl] > direct_q ? slice_plain[(size_t)sl] : direct_q;
     }
     if (direct) {
-        if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        if ((rc = pipe.wait_stage(0)) || (rc = pipe.wait_stage(1))) return pipe.finish(rc);
         if (pack_bases &&
             ((rc = bsw_unpack4(dref_p.as<uint8_t>(), dref.as<uint8_t>(), lo_r[0], hi_r[0], L->compute)) ||
              (rc = bsw_unpack4(dqer_p.as<uint8_t>(), dqer.as<uint8_t>(), lo_q[0], hi_q[0], L->compute))))
@@ -220,20 +222,37 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     }
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int64_t a = cut[(size_t)c], m = cut[(size_t)c + 1] - a;
-        if ((rc = pipe.wait_stage(c))) return pipe.finish(rc);
-        mark("uploads queued, chunk", c);
         // pipelined calls: no barrier between the chunks, the launch records one event per kernel stream, and what
-        // prepares a chunk (unpacking, classify, the lane sort) waits for its uploads only (BswChunkPrep)
+        // prepares a chunk (classify, the lane sort; unpacking, if it has row-kernel pairs) waits for its uploads only
+        // (BswChunkPrep) - in two calls where the launch allows it: the preparing passes behind the index arrays, while
+        // the bases are still on their way, the kernels behind the bases
         hipEvent_t *je = n_chunks > 1 ? pipe.join_events(c) : nullptr;
-        BswChunkPrep prep = {je ? pipe.stage_event() : nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, rows_pairs[(size_t)c]};
+        BswChunkPrep prep = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, rows_pairs[(size_t)c], 0, L->ev_pre, L->ev_aux};
         if (pack_bases) {
             prep.ref_packed = dref_p.as<uint8_t>(); prep.ref_bytes = dref.as<uint8_t>();
             prep.qer_packed = dqer_p.as<uint8_t>(); prep.qer_bytes = dqer.as<uint8_t>();
             prep.lo_r = lo_r[(size_t)c]; prep.hi_r = hi_r[(size_t)c]; prep.lo_q = lo_q[(size_t)c]; prep.hi_q = hi_q[(size_t)c];
         }
-        rc = bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,
-                        dl1.as<int32_t>() + a, dl2.as<int32_t>() + a, dh0.as<int32_t>() + a,
-                        dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute, je, &prep);
+        auto launch = [&]() {
+            return bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,
+                              dl1.as<int32_t>() + a, dl2.as<int32_t>() + a, dh0.as<int32_t>() + a,
+                              dout.as<gbx_bsw_result>() + a, (char *)dwork.p + wb1 * (size_t)c, wb1, L->compute, je, &prep);
+        };
+        static const bool split_off = getenv("GBX_BSW_SPLIT_PREP") && atoi(getenv("GBX_BSW_SPLIT_PREP")) == 0;
+        bool split = je && pipe.stage_event() && !split_off;
+        if (split) {
+            if ((rc = pipe.wait_stage(2 * c, L->ev_part))) return pipe.finish(rc);
+            mark("index arrays queued, chunk", c);
+            prep.phase = 1; prep.uploaded = L->ev_part;
+            rc = launch();
+            if (rc == 1) { split = false; rc = GBX_OK; }
+            if (rc) return pipe.finish(rc);
+        } else if ((rc = pipe.wait_stage(2 * c))) return pipe.finish(rc);
+        if ((rc = pipe.wait_stage(2 * c + 1))) return pipe.finish(rc);
+        mark("uploads queued, chunk", c);
+        prep.phase = split ? 2 : 0;
+        prep.uploaded = je ? pipe.stage_event() : nullptr;
+        rc = launch();
         if (!rc) {
             pipe.fetch(c, out + a, dout.as<gbx_bsw_result>() + a, m * sizeof(gbx_bsw_result));
             rc = pipe.chunk_launched(c, je ? Lane::JOIN_EVENTS : 0);

@@ -106,6 +106,11 @@ struct BswChunkPrep {
     uint8_t *ref_bytes, *qer_bytes;
     int64_t lo_r, hi_r, lo_q, hi_q;
     int64_t rows_pairs;                           // pairs of the chunk that bsw_lane_takes() turns down, or an upper bound; -1: not counted
+    // 0: one call does everything.  1: the preparing passes only, behind `uploaded` = the chunk's index arrays (returns 1 and
+    // queues nothing if this chunk's launch cannot be split); 2: the kernels, behind `uploaded` = its bases.  ev_pre / ev_aux:
+    // the caller's own events that tie the two calls together (the side streams' are shared by all callers of a device).
+    int phase;
+    hipEvent_t ev_pre, ev_aux;
 };
 // Which pairs a launch of n pairs puts on the lane kernels (bsw_kernels.hip: lane_ok), for a host pass that counts the
 // others: a launch that knows there are none leaves out the row-kernel classes, twenty-one near-empty launches.

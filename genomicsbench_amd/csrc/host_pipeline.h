@@ -170,6 +170,7 @@ struct Lane {
     // gaps - and the downloads one more instead of queueing between the uploads; without priorities all three are `copy`.)
     hipStream_t compute = nullptr, copy = nullptr, copy2 = nullptr, down = nullptr;
     hipEvent_t ev_stage = nullptr, ev_stage2 = nullptr, ev_half[2] = {nullptr, nullptr};
+    hipEvent_t ev_part = nullptr, ev_pre = nullptr, ev_aux = nullptr;      // bsw: a chunk's index arrays are up; its preparing passes are done
     static constexpr int JOIN_EVENTS = 1 + SideStreams::N;
     std::vector<hipEvent_t> ev_chunk;      // JOIN_EVENTS per pipeline chunk of a call, grown on demand
     char *wslab[MAX_WORKERS][2] = {};
@@ -177,6 +178,15 @@ struct Lane {
     char *dslab = nullptr;
     bool staged_ready = false;
 };
+
+// Events a host thread waits on (a worker for its slab's last DMA, the downloader for a chunk's kernels).  GBX_EVENT_BLOCKING=1:
+// the waiting thread sleeps until the interrupt instead of polling - a tuning aid for hosts where the pollers exhaust a
+// CPU quota (measured on the pool's 16-core cgroups: see DESIGN §8).
+static unsigned host_wait_event_flags()
+{
+    static const bool blocking = getenv("GBX_EVENT_BLOCKING") && atoi(getenv("GBX_EVENT_BLOCKING")) != 0;
+    return hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0u);
+}
 
 static int host_workers()
 {
@@ -193,7 +203,7 @@ static int lane_prepare_staging(Lane *l)
     for (int w = 0; w < Lane::MAX_WORKERS; ++w)
         for (int k = 0; k < 2; ++k) {
             if (!l->wslab[w][k]) GBX_HIP(hipHostMalloc((void **)&l->wslab[w][k], Lane::PIECE, hipHostMallocDefault));
-            if (!l->wev[w][k]) GBX_HIP(hipEventCreateWithFlags(&l->wev[w][k], hipEventDisableTiming));
+            if (!l->wev[w][k]) GBX_HIP(hipEventCreateWithFlags(&l->wev[w][k], host_wait_event_flags()));
         }
     if (!l->dslab) GBX_HIP(hipHostMalloc((void **)&l->dslab, Lane::DOWN, hipHostMallocDefault));
     std::vector<Helper> th;
@@ -272,8 +282,11 @@ struct HostLane {
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_stage2, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[0], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[1], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_part, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_pre, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_aux, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[0], host_wait_event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev_half[1], host_wait_event_flags());
         if (e != hipSuccess) { delete n; return hip_fail(e, "host lane"); }
         l = n;
         return GBX_OK;
@@ -467,7 +480,7 @@ struct HostPipe {
         chunk_nev.assign((size_t)chunks, 0);
         while ((int64_t)L->ev_chunk.size() < chunks * Lane::JOIN_EVENTS) {
             hipEvent_t e = nullptr;
-            GBX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            GBX_HIP(hipEventCreateWithFlags(&e, host_wait_event_flags()));
             L->ev_chunk.push_back(e);
         }
         return staged ? lane_prepare_staging(L) : GBX_OK;
@@ -683,8 +696,12 @@ struct HostPipe {
         pool.start((workers < 6 ? workers : 6) - 1);
         threads.emplace_back([this] { download_worker(); });
     }
-    // returns when every upload of chunk c is queued on the copy stream, and makes the compute stream wait for them
-    int wait_stage(int64_t c)
+    // Upload stages finer than the chunks (after prepare(); default: one stage per chunk): stage*() and wait_stage() then
+    // count stages, fetch() / join_events() / chunk_launched() chunks.  bsw: a chunk's index arrays and its bases.
+    void upload_stages(int64_t k) { remaining.assign((size_t)k, 0); }
+    // returns when every upload of stage c is queued on the copy stream, and makes the compute stream wait for them;
+    // with `ev` (staged, overlapping calls only): records that event behind them instead, and no stream waits
+    int wait_stage(int64_t c, hipEvent_t ev = nullptr)
     {
         if (!staged) {
             RoctxRange range_("gbx:h2d (direct)");
@@ -716,8 +733,8 @@ struct HostPipe {
                 GBX_HIP(hipEventRecord(L->ev_stage2, xfer2));
                 GBX_HIP(hipStreamWaitEvent(xfer, L->ev_stage2, 0));
             }
-            GBX_HIP(hipEventRecord(L->ev_stage, xfer));
-            GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
+            GBX_HIP(hipEventRecord(ev ? ev : L->ev_stage, xfer));
+            if (!ev) GBX_HIP(hipStreamWaitEvent(L->compute, L->ev_stage, 0));
         }
         return GBX_OK;
     }

@@ -267,7 +267,7 @@ def test_lane_non_default_scoring(kw, lane):
     assert_same(extend_host(p, b), O.bsw_oracle(p, b, 4), b)
 
 
-@pytest.mark.parametrize("env", [{}, {"GBX_BSW_PREP": "0"}, {"GBX_BSW_SKIP_ROWS": "0"}, {"GBX_BSW_PACKED_LANES": "0"},
+@pytest.mark.parametrize("env", [{}, {"GBX_BSW_PREP": "0"}, {"GBX_BSW_SKIP_ROWS": "0"}, {"GBX_BSW_PACKED_LANES": "0"}, {"GBX_BSW_SPLIT_PREP": "0"},
                                  {"GBX_COPY_STREAMS": "1", "GBX_DOWN_STREAM": "0"}])
 def test_lane_pipelined_chunks_with_and_without_row_kernel_pairs(lane, monkeypatch, env):
     """The pipelined host call prepares a chunk (unpacking, classify, the lane sort) on streams of their own and leaves out
