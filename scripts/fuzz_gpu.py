@@ -67,14 +67,22 @@ while time.time() < t_end:
                                                   mat=fill_scmat(int(rng.integers(1, 4)), int(rng.integers(1, 6)), -int(rng.integers(0, 3))))
         p = bsw_params(**kw)
         lane = rng.random() < 0.5                                # the lane kernels (large jobs take them by default) on this job too
-        what = "n=%d adversarial=%s lane=%s kw=%s" % (n, adv, lane, kw)
+        # a third of the jobs as a pipelined call: staged uploads, two to a dozen chunks (preparing passes on their own streams,
+        # chunks with and without row-kernel pairs, packed bases read by the lane kernels)
+        piped = n >= 513 and rng.random() < 0.35
+        chunk = 64 * int(rng.integers(max(1, n // 768), max(2, n // 128))) if piped else 0
+        what = "n=%d adversarial=%s lane=%s chunk=%d kw=%s" % (n, adv, lane, chunk, kw)
         run = announce("bsw seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what))
         if lane:
             os.environ["GBX_BSW_LANE"] = "1"
+        if piped:
+            os.environ["GBX_BSW_HOST_CHUNK"] = str(chunk)
+            os.environ["GBX_HOST_STAGE_MIN"] = "0"
         try:
             ok = not run or np.array_equal(extend_host(p, b), O.bsw_oracle(p, b, 8))
         finally:
-            os.environ.pop("GBX_BSW_LANE", None)
+            for v in ("GBX_BSW_LANE", "GBX_BSW_HOST_CHUNK", "GBX_HOST_STAGE_MIN"):
+                os.environ.pop(v, None)
     elif k == "chain":
         nc = int(rng.choice([1, 3, 40, 300]))
         real = bool(rng.random() < 0.5)                          # minimap2's strand / reference structure: calls cut into jobs
