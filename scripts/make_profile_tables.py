@@ -37,7 +37,7 @@ def stage_name(kname):
     m = re.match(r"bsw_rows_kernel<(\d+), (\d+), \w+>", kname)
     if m:
         return "bsw_rows_%sx%s" % (m.group(1), m.group(2))
-    m = re.match(r"bsw_lane_kernel<\w+, (\w+)(?:, \w+)?>(?:@(\d+))?", kname)
+    m = re.match(r"bsw_lane_kernel<\w+, (\w+)(?:, \w+){0,2}>(?:@(\d+))?", kname)
     if m:
         # one symbol, five launches per format: the launch is identified by its grid = resident blocks per CU, which
         # follows from its LDS size (bsw_kernels.hip: bsw_launch; scripts/pmc_summary.py appends it to the name)
