@@ -162,12 +162,13 @@ struct Lane {
     static constexpr size_t PIECE = (size_t)GBX_PIECE_MB << 20;   // upload piece = worker slab
     static constexpr size_t DOWN = (size_t)16 << 20;        // download slab
     int dev = 0;
-    // Two streams only.  The runtime maps all streams of a process onto four hardware queues, and streams that
-    // share a queue run in order: with compute + transfer + two of the kernels' side streams every one has a
-    // queue of its own (measured with more: uploads stalled behind class kernels, or two kernel streams lost
-    // their overlap).  Calls that do not overlap transfer and compute use `compute` for everything.
-    // (Round 5: urgent streams get hardware queues of their own class, so the uploads have two - their DMAs fill each other's
-    // gaps - and the downloads one more instead of queueing between the uploads; without priorities all three are `copy`.)
+    // One stream of ordinary priority only (`compute`).  The runtime maps the ordinary streams of a process onto four
+    // hardware queues, and streams that share a queue run in order: compute + three of the kernels' side streams have a
+    // queue each (measured with more: two kernel streams lost their overlap).  The transfer streams are urgent ones, which
+    // get hardware queues of their own class: two for the uploads - their DMAs fill each other's gaps - and one for the
+    // downloads instead of queueing between the uploads (without stream priorities all three are one ordinary stream,
+    // and its DMAs' marker packets wait behind kernel launches: DESIGN section 1).  Calls that do not overlap transfer and
+    // compute use `compute` for everything.
     hipStream_t compute = nullptr, copy = nullptr, copy2 = nullptr, down = nullptr;
     hipEvent_t ev_stage = nullptr, ev_stage2 = nullptr, ev_half[2] = {nullptr, nullptr};
     hipEvent_t ev_part = nullptr, ev_pre = nullptr, ev_aux = nullptr;      // bsw: a chunk's index arrays are up; its preparing passes are done
