@@ -58,7 +58,8 @@ int  gbx_host_set_devices(int n_gpus);
 int  gbx_split_by_cost(int64_t n_units, const double *cost, int n_parts, int64_t *cuts);
 int  gbx_host_devices(void);             /* devices the *_host entries currently use (>= 1; 0 without any HIP device) */
 /* Optional: creates the calling thread's streams and the pinned staging buffers the *_host entries use for
- * large inputs (about 144 MB of pinned host memory), so that the first large call does not pay for them.  The
+ * large inputs (about 144 MB of pinned host memory) and runs one small transfer from each buffer on its stream,
+ * so that the first large calls do not pay for them.  The
  * counterpart of constructing the reference's aligner object before its timed region
  * (bsw/main_banded.cpp:262-270).  The *_host entries do this themselves on demand. */
 int  gbx_host_prepare(void);

@@ -195,6 +195,29 @@ int main(int argc, char **argv)
         return 0;
     }
     const int threads = argc > 1 ? atoi(argv[1]) : 4, rounds = argc > 2 ? atoi(argv[2]) : 3;
+    // (0) the chunk cuts of gbx_bsw_extend_host: 0 .. n, every inner cut a multiple of 64, ascending; the default rule (at most
+    //     three equal chunks, none below 512 Ki pairs) and the two overrides
+    {
+        auto well_formed = [](const std::vector<int64_t> &c, int64_t n) {
+            if (c.size() < 2 || c.front() != 0 || c.back() != n) return false;
+            for (size_t k = 1; k < c.size(); ++k) if (c[k] <= c[k - 1] || (k + 1 < c.size() && c[k] % 64)) return false;
+            return true;
+        };
+        unsetenv("GBX_BSW_HOST_CHUNK"); unsetenv("GBX_BSW_HOST_CUTS");
+        for (int64_t n : {(int64_t)1, (int64_t)63, (int64_t)524288, (int64_t)524289, (int64_t)1048577, (int64_t)2000000, (int64_t)10000001}) {
+            const std::vector<int64_t> c = bsw_host_cuts(n);
+            CHECK(well_formed(c, n), "default cuts of %lld pairs are malformed", (long long)n);
+            CHECK(c.size() - 1 <= 3, "more than three default chunks for %lld pairs", (long long)n);
+            CHECK(c.size() == 2 || c[1] >= 524288, "a default chunk below 512 Ki pairs for %lld", (long long)n);
+        }
+        CHECK(bsw_host_cuts(2000000).size() == 4 && bsw_host_cuts(524288).size() == 2, "default chunk counts");
+        setenv("GBX_BSW_HOST_CHUNK", "1000", 1);
+        CHECK(well_formed(bsw_host_cuts(4000), 4000) && bsw_host_cuts(4000).size() == 5 && bsw_host_cuts(4000)[1] == 1024, "cuts by GBX_BSW_HOST_CHUNK");
+        unsetenv("GBX_BSW_HOST_CHUNK");
+        setenv("GBX_BSW_HOST_CUTS", "0.5,0.1,0.9,2.0", 1);     // out of order or out of range entries are dropped
+        CHECK(well_formed(bsw_host_cuts(100000), 100000) && bsw_host_cuts(100000).size() == 4, "cuts by GBX_BSW_HOST_CUTS");
+        unsetenv("GBX_BSW_HOST_CUTS");
+    }
     setenv("GBX_HOST_STAGE_MIN", "65536", 1);                 // calls of 64 KB and more are staged
     setenv("GBX_HOST_DOWN_PIECE", "262144", 1);               // downloads span several half-slab pieces
     // (a) every call shape from several caller threads at once, each on its own lane; lanes and their device-block caches
