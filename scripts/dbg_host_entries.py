@@ -1,7 +1,7 @@
 """PCIe-inclusive time of the host-buffer entries on the 'large' sets (pageable numpy arrays in and out, Python wrapper's
 own allocations included): python3 scripts/dbg_host_entries.py [chain] [phmm] [poa]"""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from genomicsbench_amd import _native as N
 N.check(N.lib().gbx_host_prepare())
