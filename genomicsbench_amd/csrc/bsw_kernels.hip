@@ -1284,10 +1284,16 @@ int bsw_launch(const gbx_bsw_params *p, int64_t n,
             GBX_HIP(hipStreamWaitEvent(ss->pre[0], prep->uploaded, 0));
             GBX_HIP(hipStreamWaitEvent(ss->pre[1], prep->uploaded, 0));
         }
-        if (!packed_lanes && prep && prep->ref_packed &&
-            ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, prep->lo_r, prep->hi_r, s_cls)) ||
-             (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, prep->lo_q, prep->hi_q, s_cls))))
-            return rc;
+        if (!packed_lanes && prep && prep->ref_packed) {
+            // from the call's watermark (everything below it is expanded; chunks that ran PACKED expanded nothing) - s_cls waits
+            // for this chunk's uploads, and the host entry queues the chunks' uploads in order, so all of [from, hi) is up
+            const int64_t from_r = prep->unp_r ? *prep->unp_r : prep->lo_r, from_q = prep->unp_q ? *prep->unp_q : prep->lo_q;
+            if ((rc = bsw_unpack4(prep->ref_packed, prep->ref_bytes, from_r, prep->hi_r, s_cls)) ||
+                (rc = bsw_unpack4(prep->qer_packed, prep->qer_bytes, from_q, prep->hi_q, s_cls)))
+                return rc;
+            if (prep->unp_r && prep->hi_r > *prep->unp_r) *prep->unp_r = prep->hi_r;
+            if (prep->unp_q && prep->hi_q > *prep->unp_q) *prep->unp_q = prep->hi_q;
+        }
         GBX_HIP(hipMemsetAsync(d_work, 0, WS_HDR * sizeof(int32_t), s_cls));
         // The lane sort (0.3 ms on 'large': two passes of scattered atomics) runs on a side stream of its own, beside
         // classify and the row-kernel classes on the caller's stream, which do not need it; the lane launches wait for it.

@@ -168,6 +168,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     if (pack_bases && ((rc = dref_p.alloc((size_t)ref_bytes / 2 + 16)) || (rc = dqer_p.alloc((size_t)qer_bytes / 2 + 16)))) return rc;
     std::vector<int64_t> lo_r((size_t)n_chunks), hi_r((size_t)n_chunks), lo_q((size_t)n_chunks), hi_q((size_t)n_chunks);
     int64_t up_r = 0, up_q = 0;
+    int64_t unp_r = 0, unp_q = 0;       // the byte arenas are expanded up to here (BswChunkPrep::unp_r)
     // Two upload stages per chunk: its index arrays (stage 2c: all the preparing passes read) and then its bases (2c + 1)
     pipe.upload_stages(2 * n_chunks);
     auto stage_chunk = [&](int64_t c) {
@@ -232,6 +233,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
             prep.ref_packed = dref_p.as<uint8_t>(); prep.ref_bytes = dref.as<uint8_t>();
             prep.qer_packed = dqer_p.as<uint8_t>(); prep.qer_bytes = dqer.as<uint8_t>();
             prep.lo_r = lo_r[(size_t)c]; prep.hi_r = hi_r[(size_t)c]; prep.lo_q = lo_q[(size_t)c]; prep.hi_q = hi_q[(size_t)c];
+            prep.unp_r = &unp_r; prep.unp_q = &unp_q;
         }
         auto launch = [&]() {
             return bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,

@@ -111,6 +111,10 @@ struct BswChunkPrep {
     // the caller's own events that tie the two calls together (the side streams' are shared by all callers of a device).
     int phase;
     hipEvent_t ev_pre, ev_aux;
+    // How far the caller's byte arenas have been expanded so far (the call's watermarks, nullptr: [lo, hi) as given).  A chunk
+    // the lane kernels take whole reads the packed images and expands nothing, so the next chunk that does need the bytes
+    // expands from the watermark, not from its own lo: its pairs may lie in what an earlier, packed chunk brought up.
+    int64_t *unp_r = nullptr, *unp_q = nullptr;
 };
 // Which pairs a launch of n pairs puts on the lane kernels (bsw_kernels.hip: lane_ok), for a host pass that counts the
 // others: a launch that knows there are none leaves out the row-kernel classes, twenty-one near-empty launches.

@@ -289,6 +289,43 @@ def test_lane_pipelined_chunks_with_and_without_row_kernel_pairs(lane, monkeypat
     assert_same(extend_host(p, m), O.bsw_oracle(p, m, 8), m)
 
 
+@pytest.mark.parametrize("where", ["late_slice_of_later_chunk", "pairs_reuse_first_chunks_bases"])
+def test_lane_packed_chunk_followed_by_unpacked_chunk(lane, monkeypatch, where):
+    """A chunk the lane kernels take whole runs on the packed bases and expands nothing; a later chunk with row-kernel
+    pairs reads the byte arenas, which must then hold everything up to its own end - including what the packed chunks
+    before it brought up (the call's watermark, BswChunkPrep::unp_r).  Several validation slices (32 Ki pairs each), cuts
+    that are not multiples of a slice, the only row-kernel pairs in the last slice of the last chunk; and a layout whose later
+    pairs point back into the first chunk's bases.  The profile shows that both forms ran in the one call."""
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    monkeypatch.setenv("GBX_BSW_HOST_CHUNK", "40000")           # cuts at 40000, 80000 (r64: 40000 = 625 * 64), slices at 32768 k
+    p = make_params()
+    b = gen_bsw(3 * 32768 + 5000, 43)
+    a = adversarial_bsw(24, 5, max_q=900, max_t=1200)           # row-kernel pairs
+    at = 3 * 32768 + 2000                                       # slice 3 (98304..), which only chunk 2 (80000..) overlaps
+    ref = np.concatenate([b.ref, a.ref]); qer = np.concatenate([b.qer, a.qer])
+    ins = lambda x, y: np.concatenate([x[:at], y, x[at:]])
+    idr, idq = ins(b.idr, a.idr + b.ref.size), ins(b.idq, a.idq + b.qer.size)
+    if where == "pairs_reuse_first_chunks_bases":
+        # the 3000 pairs after the spliced ones read the bases of pairs 0..2999 (first chunk: packed, never expanded by itself)
+        k = at + len(a.idr)
+        idr[k:k + 3000] = b.idr[:3000]; idq[k:k + 3000] = b.idq[:3000]
+        l1, l2, h0 = ins(b.len1, a.len1), ins(b.len2, a.len2), ins(b.h0, a.h0)
+        l1[k:k + 3000] = b.len1[:3000]; l2[k:k + 3000] = b.len2[:3000]; h0[k:k + 3000] = b.h0[:3000]
+    else:
+        l1, l2, h0 = ins(b.len1, a.len1), ins(b.len2, a.len2), ins(b.h0, a.h0)
+    m = BswBatch(ref, qer, idr, idq, l1, l2, h0)
+    want = O.bsw_oracle(p, m, 8)
+    N.profile_begin()
+    got = extend_host(p, m)
+    prof = N.profile_end(256)
+    assert_same(got, want, m)
+    assert "bsw_unpack4" in prof, sorted(prof)                   # a chunk that expanded the arenas ...
+    lane_launches = sum(c for k, (ms, c) in prof.items() if k.startswith("bsw_lane_c"))
+    rows_launches = sum(c for k, (ms, c) in prof.items() if k.startswith("bsw_rows") or k == "bsw_lds")
+    assert lane_launches >= 15 and 0 < rows_launches, prof       # ... and three chunks of lane launches, row classes for one only
+    assert prof["bsw_lds"][1] == 1, prof                         # (the two packed chunks launched no row class at all)
+
+
 def test_lane_generated_reads_and_ragged_last_chunk(lane):
     b = gen_bsw(30_011, 77)                        # not a multiple of 64 in any length class
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
