@@ -78,6 +78,8 @@ def _declare(L):
     L.gbx_host_prepare.argtypes = []
     L.gbx_host_release.argtypes = []
     L.gbx_host_reserve.argtypes = [sz]
+    if hasattr(L, "gbx_host_combine_stats"):
+        L.gbx_host_combine_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
     L.gbx_timer_create.argtypes = [C.POINTER(vp)]
     L.gbx_timer_start.argtypes = [vp, vp]
     L.gbx_timer_stop.argtypes = [vp, vp]
@@ -153,6 +155,14 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
+
+
+def combine_stats(kernel, reset=False):
+    """Counters of the host entries' call combiner for one kernel ("bsw", "phmm", "poa") ->
+    dict(calls, device_calls, shared, largest)."""
+    out = (C.c_uint64 * 4)()
+    check(lib().gbx_host_combine_stats({"bsw": 1, "phmm": 3, "poa": 4}[kernel], out, 1 if reset else 0))
+    return dict(calls=int(out[0]), device_calls=int(out[1]), shared=int(out[2]), largest=int(out[3]))
 
 
 def device_count():

@@ -271,12 +271,12 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
 // own cell count, main_banded.cpp:183,323) over the devices of gbx_host_set_devices / GBX_GPUS - the reference's per-thread
 // slices (main_banded.cpp:279-291) as per-device slices.  Each shard's bases are the byte range of the arenas its pairs
 // span, sent by that device's own lane; results are written in place.
-int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
-                        const uint8_t *ref, int64_t ref_bytes,
-                        const uint8_t *qer, int64_t qer_bytes,
-                        const int64_t *idr, const int64_t *idq,
-                        const int32_t *len1, const int32_t *len2,
-                        const int32_t *h0, gbx_bsw_result *out)
+static int bsw_host_entry(const gbx_bsw_params *p, int64_t n,
+                          const uint8_t *ref, int64_t ref_bytes,
+                          const uint8_t *qer, int64_t qer_bytes,
+                          const int64_t *idr, const int64_t *idq,
+                          const int32_t *len1, const int32_t *len2,
+                          const int32_t *h0, gbx_bsw_result *out)
 {
     if (!host_multi_wanted() || !p || n <= 0 || !ref || !qer || !idr || !idq || !len1 || !len2 || !h0 || !out || ref_bytes < 0 || qer_bytes < 0)
         return bsw_host_one(p, n, ref, ref_bytes, qer, qer_bytes, idr, idq, len1, len2, h0, out);
@@ -316,6 +316,100 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
         for (int64_t j = 0; j < m; ++j) { r2[(size_t)j] = idr[lo + j] - ar; q2[(size_t)j] = idq[lo + j] - aq; }
         return bsw_host_one(p, m, ref + ar, br - ar, qer + aq, bq - aq, r2.data(), q2.data(), len1 + lo, len2 + lo, h0 + lo, out + lo, lo);
     });
+}
+
+}  // extern "C"
+
+// ---- small concurrent calls combined (host_combine.h).  The reference's driver calls getScores16 once per 512 pairs from
+// every OpenMP thread (main_banded.cpp:279-291): the calls that are pending together become one job - the pairs of all
+// requests end to end, their bases gathered into two compact arenas (4-byte aligned per pair, as the SeqPair entry does for
+// the driver's strided slots) - and every caller gets its own slice of the results.
+namespace {
+struct BswReq : CombineReq {
+    const gbx_bsw_params *p; int64_t n;
+    const uint8_t *ref; int64_t ref_bytes; const uint8_t *qer; int64_t qer_bytes;
+    const int64_t *idr, *idq; const int32_t *len1, *len2, *h0; gbx_bsw_result *out;
+    int64_t cr, cq;                       // bytes of its pairs in the compact arenas
+};
+struct BswScratch {
+    Scratch<uint8_t> ref, qer; Scratch<int64_t> idr, idq; Scratch<int32_t> l1, l2, h0; Scratch<gbx_bsw_result> out;
+};
+constexpr int64_t BSW_COMBINE_MAX_CALL = 65536, BSW_COMBINE_MAX_JOB = (int64_t)1 << 20;
+}
+namespace gbx { Combiner &combiner_bsw() { static Combiner *c = new Combiner(); return *c; } }
+
+static void bsw_run_alone(BswReq *r)
+{
+    r->rc = bsw_host_entry(r->p, r->n, r->ref, r->ref_bytes, r->qer, r->qer_bytes, r->idr, r->idq, r->len1, r->len2, r->h0, r->out);
+    if (r->rc) r->err = gbx_last_error();
+}
+
+static void bsw_run_combined(const std::vector<CombineReq *> &batch)
+{
+    if (batch.size() == 1) { bsw_run_alone((BswReq *)batch[0]); return; }
+    static BswScratch *S = new BswScratch();      // one leader at a time (Combiner::leading)
+    const size_t nb = batch.size();
+    std::vector<int64_t> p0(nb + 1, 0), r0(nb + 1, 0), q0(nb + 1, 0);
+    for (size_t k = 0; k < nb; ++k) {
+        const BswReq *r = (const BswReq *)batch[k];
+        p0[k + 1] = p0[k] + r->n; r0[k + 1] = r0[k] + r->cr; q0[k + 1] = q0[k] + r->cq;
+    }
+    const int64_t N = p0[nb], R = r0[nb], Q = q0[nb];
+    uint8_t *mref = S->ref.get((size_t)R + 16), *mqer = S->qer.get((size_t)Q + 16);
+    int64_t *midr = S->idr.get((size_t)N), *midq = S->idq.get((size_t)N);
+    int32_t *ml1 = S->l1.get((size_t)N), *ml2 = S->l2.get((size_t)N), *mh0 = S->h0.get((size_t)N);
+    gbx_bsw_result *mout = S->out.get((size_t)N);
+    combine_parallel((int64_t)nb, host_workers(), [&](int64_t k) {
+        const BswReq *r = (const BswReq *)batch[(size_t)k];
+        int64_t pr = r0[(size_t)k], pq = q0[(size_t)k];
+        const int64_t a = p0[(size_t)k];
+        for (int64_t j = 0; j < r->n; ++j) {
+            memcpy(mref + pr, r->ref + r->idr[j], (size_t)r->len1[j]);
+            memcpy(mqer + pq, r->qer + r->idq[j], (size_t)r->len2[j]);
+            midr[a + j] = pr; midq[a + j] = pq;
+            pr += (r->len1[j] + 3) & ~3; pq += (r->len2[j] + 3) & ~3;
+        }
+        memcpy(ml1 + a, r->len1, (size_t)r->n * 4); memcpy(ml2 + a, r->len2, (size_t)r->n * 4); memcpy(mh0 + a, r->h0, (size_t)r->n * 4);
+    });
+    const BswReq *lead = (const BswReq *)batch[0];
+    const int rc = bsw_host_entry(lead->p, N, mref, R + 8, mqer, Q + 8, midr, midq, ml1, ml2, mh0, mout);
+    if (rc) {                                       // redone one by one: every caller gets the status of its own call
+        for (CombineReq *q : batch) bsw_run_alone((BswReq *)q);
+        return;
+    }
+    combine_parallel((int64_t)nb, nb >= 8 ? 4 : 1, [&](int64_t k) {
+        BswReq *r = (BswReq *)batch[(size_t)k];
+        memcpy(r->out, mout + p0[(size_t)k], (size_t)r->n * sizeof(gbx_bsw_result));
+        r->rc = GBX_OK;
+    });
+}
+
+extern "C" {
+
+int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
+                        const uint8_t *ref, int64_t ref_bytes,
+                        const uint8_t *qer, int64_t qer_bytes,
+                        const int64_t *idr, const int64_t *idq,
+                        const int32_t *len1, const int32_t *len2,
+                        const int32_t *h0, gbx_bsw_result *out)
+{
+    auto plain = [&] { return bsw_host_entry(p, n, ref, ref_bytes, qer, qer_bytes, idr, idq, len1, len2, h0, out); };
+    if (!p || n <= 0 || n > BSW_COMBINE_MAX_CALL || !ref || !qer || !idr || !idq || !len1 || !len2 || !h0 || !out || ref_bytes < 0 || qer_bytes < 0 ||
+        !combine_enabled() || profile_active())
+        return plain();
+    BswReq r;
+    r.p = p; r.n = n; r.ref = ref; r.ref_bytes = ref_bytes; r.qer = qer; r.qer_bytes = qer_bytes;
+    r.idr = idr; r.idq = idq; r.len1 = len1; r.len2 = len2; r.h0 = h0; r.out = out; r.units = n; r.cr = r.cq = 0;
+    for (int64_t k = 0; k < n; ++k) {               // a call with a bad pair goes its own way: its error names the pair
+        if (len1[k] < 0 || len2[k] < 0 || idr[k] < 0 || idq[k] < 0 || idr[k] + len1[k] > ref_bytes || idq[k] + len2[k] > qer_bytes ||
+            len2[k] > GBX_BSW_MAX_QLEN || len1[k] > GBX_BSW_MAX_TLEN)
+            return plain();
+        r.cr += (len1[k] + 3) & ~3; r.cq += (len2[k] + 3) & ~3;
+    }
+    if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    return combiner_bsw().submit(&r, BSW_COMBINE_MAX_JOB,
+        [](const CombineReq *a, const CombineReq *b) { return memcmp(((const BswReq *)a)->p, ((const BswReq *)b)->p, offsetof(gbx_bsw_params, pad_)) == 0; },
+        bsw_run_combined);
 }
 
 int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t n,

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -19,3 +20,4 @@ int require_device();      // GBX_OK, or GBX_ERR_NO_DEVICE with the error text s
 
 #include "host_pipeline.h"
 #include "host_multi.h"
+#include "host_combine.h"

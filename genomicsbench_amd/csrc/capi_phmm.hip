@@ -147,11 +147,11 @@ static int phmm_host_one(int64_t n_pairs, const int32_t *pair_read, const int32_
 // (PairHMMUnitTest.cpp:224-247) as a loop over devices.  A shard takes the reads / haplotypes its pairs name (the id
 // ranges they span: the testcase array is read-major, so these are the shard's own batches) and the byte ranges of the
 // arenas those occupy.
-int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
-                          int64_t n_reads, const int64_t *read_off, const int32_t *read_len, int64_t read_bytes,
-                          const uint8_t *rs, const uint8_t *q, const uint8_t *i, const uint8_t *d, const uint8_t *c,
-                          int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
-                          const uint8_t *hap, double *out)
+static int phmm_host_entry(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
+                           int64_t n_reads, const int64_t *read_off, const int32_t *read_len, int64_t read_bytes,
+                           const uint8_t *rs, const uint8_t *q, const uint8_t *i, const uint8_t *d, const uint8_t *c,
+                           int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
+                           const uint8_t *hap, double *out)
 {
     auto one = [&]() { return phmm_host_one(n_pairs, pair_read, pair_hap, n_reads, read_off, read_len, read_bytes, rs, q, i, d, c,
                                             n_haps, hap_off, hap_len, hap_bytes, hap, out); };
@@ -205,6 +205,110 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
         return phmm_host_one(m, pr.data(), ph.data(), nr, ro.data(), read_len + r0, rb - ra, rs + ra, q + ra, i + ra, d + ra, c + ra,
                              nh, ho.data(), hap_len + h0, hb - ha, hap + ha, out + lo, lo, r0, h0);
     });
+}
+
+}  // extern "C"
+
+// ---- small concurrent calls combined (host_combine.h).  The reference's driver calls computelikelihoodsboth once per batch
+// (a few hundred pairs) from every OpenMP thread (PairHMMUnitTest.cpp:224-247): the calls that are pending together become
+// one job - reads, haplotypes and pairs of all requests end to end, ids and offsets re-based.
+namespace {
+struct PhmmReq : CombineReq {
+    int64_t n_pairs; const int32_t *pair_read, *pair_hap;
+    int64_t n_reads; const int64_t *read_off; const int32_t *read_len; int64_t read_bytes;
+    const uint8_t *rs, *q, *i, *d, *c;
+    int64_t n_haps; const int64_t *hap_off; const int32_t *hap_len; int64_t hap_bytes; const uint8_t *hap; double *out;
+    int64_t cr, ch;                       // bytes of its reads / haplotypes laid end to end
+};
+struct PhmmScratch {
+    Scratch<int32_t> pr, ph, rl, hl; Scratch<int64_t> ro, ho; Scratch<uint8_t> rs, q, i, d, c, hap; Scratch<double> out;
+};
+constexpr int64_t PHMM_COMBINE_MAX_CALL = 131072, PHMM_COMBINE_MAX_JOB = (int64_t)4 << 20;
+}
+namespace gbx { Combiner &combiner_phmm() { static Combiner *c = new Combiner(); return *c; } }
+
+static void phmm_run_alone(PhmmReq *r)
+{
+    r->rc = phmm_host_entry(r->n_pairs, r->pair_read, r->pair_hap, r->n_reads, r->read_off, r->read_len, r->read_bytes, r->rs, r->q, r->i, r->d,
+                            r->c, r->n_haps, r->hap_off, r->hap_len, r->hap_bytes, r->hap, r->out);
+    if (r->rc) r->err = gbx_last_error();
+}
+
+static void phmm_run_combined(const std::vector<CombineReq *> &batch)
+{
+    if (batch.size() == 1) { phmm_run_alone((PhmmReq *)batch[0]); return; }
+    static PhmmScratch *S = new PhmmScratch();    // one leader at a time
+    const size_t nb = batch.size();
+    std::vector<int64_t> p0(nb + 1, 0), r0(nb + 1, 0), h0(nb + 1, 0), rb(nb + 1, 0), hb(nb + 1, 0);
+    for (size_t k = 0; k < nb; ++k) {
+        const PhmmReq *r = (const PhmmReq *)batch[k];
+        p0[k + 1] = p0[k] + r->n_pairs; r0[k + 1] = r0[k] + r->n_reads; h0[k + 1] = h0[k] + r->n_haps;
+        rb[k + 1] = rb[k] + r->cr; hb[k + 1] = hb[k] + r->ch;
+    }
+    const int64_t NP = p0[nb], NR = r0[nb], NH = h0[nb], RB = rb[nb], HB = hb[nb];
+    if (NR > 0x7fffffffLL || NH > 0x7fffffffLL) { for (CombineReq *q : batch) phmm_run_alone((PhmmReq *)q); return; }
+    int32_t *mpr = S->pr.get((size_t)NP), *mph = S->ph.get((size_t)NP), *mrl = S->rl.get((size_t)NR), *mhl = S->hl.get((size_t)NH);
+    int64_t *mro = S->ro.get((size_t)NR), *mho = S->ho.get((size_t)NH);
+    uint8_t *mrs = S->rs.get((size_t)RB + 16), *mq = S->q.get((size_t)RB + 16), *mi = S->i.get((size_t)RB + 16), *md = S->d.get((size_t)RB + 16),
+            *mc = S->c.get((size_t)RB + 16), *mhap = S->hap.get((size_t)HB + 16);
+    double *mout = S->out.get((size_t)NP);
+    combine_parallel((int64_t)nb, host_workers(), [&](int64_t k) {
+        const PhmmReq *r = (const PhmmReq *)batch[(size_t)k];
+        int64_t at = rb[(size_t)k];
+        for (int64_t j = 0; j < r->n_reads; ++j) {
+            const int64_t o = r->read_off[j]; const size_t l = (size_t)r->read_len[j];
+            memcpy(mrs + at, r->rs + o, l); memcpy(mq + at, r->q + o, l); memcpy(mi + at, r->i + o, l); memcpy(md + at, r->d + o, l); memcpy(mc + at, r->c + o, l);
+            mro[r0[(size_t)k] + j] = at; mrl[r0[(size_t)k] + j] = r->read_len[j];
+            at += (int64_t)l;
+        }
+        at = hb[(size_t)k];
+        for (int64_t j = 0; j < r->n_haps; ++j) {
+            memcpy(mhap + at, r->hap + r->hap_off[j], (size_t)r->hap_len[j]);
+            mho[h0[(size_t)k] + j] = at; mhl[h0[(size_t)k] + j] = r->hap_len[j];
+            at += r->hap_len[j];
+        }
+        const int32_t dr = (int32_t)r0[(size_t)k], dh = (int32_t)h0[(size_t)k];
+        for (int64_t j = 0; j < r->n_pairs; ++j) { mpr[p0[(size_t)k] + j] = r->pair_read[j] + dr; mph[p0[(size_t)k] + j] = r->pair_hap[j] + dh; }
+    });
+    const int rc = phmm_host_entry(NP, mpr, mph, NR, mro, mrl, RB, mrs, mq, mi, md, mc, NH, mho, mhl, HB, mhap, mout);
+    if (rc) { for (CombineReq *q : batch) phmm_run_alone((PhmmReq *)q); return; }
+    for (size_t k = 0; k < nb; ++k) {
+        PhmmReq *r = (PhmmReq *)batch[k];
+        memcpy(r->out, mout + p0[k], (size_t)r->n_pairs * sizeof(double));
+        r->rc = GBX_OK;
+    }
+}
+
+extern "C" {
+
+int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
+                          int64_t n_reads, const int64_t *read_off, const int32_t *read_len, int64_t read_bytes,
+                          const uint8_t *rs, const uint8_t *q, const uint8_t *i, const uint8_t *d, const uint8_t *c,
+                          int64_t n_haps, const int64_t *hap_off, const int32_t *hap_len, int64_t hap_bytes,
+                          const uint8_t *hap, double *out)
+{
+    auto plain = [&] { return phmm_host_entry(n_pairs, pair_read, pair_hap, n_reads, read_off, read_len, read_bytes, rs, q, i, d, c,
+                                              n_haps, hap_off, hap_len, hap_bytes, hap, out); };
+    if (n_pairs <= 0 || n_pairs > PHMM_COMBINE_MAX_CALL || n_reads <= 0 || n_haps <= 0 || read_bytes < 0 || hap_bytes < 0 || !pair_read || !pair_hap ||
+        !read_off || !read_len || !rs || !q || !i || !d || !c || !hap_off || !hap_len || !hap || !out || !combine_enabled() || profile_active())
+        return plain();
+    PhmmReq r;
+    r.n_pairs = n_pairs; r.pair_read = pair_read; r.pair_hap = pair_hap; r.n_reads = n_reads; r.read_off = read_off; r.read_len = read_len;
+    r.read_bytes = read_bytes; r.rs = rs; r.q = q; r.i = i; r.d = d; r.c = c; r.n_haps = n_haps; r.hap_off = hap_off; r.hap_len = hap_len;
+    r.hap_bytes = hap_bytes; r.hap = hap; r.out = out; r.units = n_pairs; r.cr = r.ch = 0;
+    // a call with a bad table entry goes its own way: its error names the entry
+    for (int64_t k = 0; k < n_reads; ++k) {
+        if (read_len[k] < 0 || read_off[k] < 0 || read_off[k] + read_len[k] > read_bytes) return plain();
+        r.cr += read_len[k];
+    }
+    for (int64_t k = 0; k < n_haps; ++k) {
+        if (hap_len[k] < 0 || hap_off[k] < 0 || hap_off[k] + hap_len[k] > hap_bytes || hap_len[k] > GBX_PHMM_MAX_HAPLEN) return plain();
+        r.ch += hap_len[k];
+    }
+    for (int64_t k = 0; k < n_pairs; ++k)
+        if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) return plain();
+    if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    return combiner_phmm().submit(&r, PHMM_COMBINE_MAX_JOB, [](const CombineReq *, const CombineReq *) { return true; }, phmm_run_combined);
 }
 
 }  // extern "C"

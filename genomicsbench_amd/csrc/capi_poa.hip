@@ -266,10 +266,10 @@ static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_
 // gbx_host_set_devices / GBX_GPUS - the driver's OpenMP loop over windows, one engine per thread
 // (msa_spoa_omp.cpp:184-196,230-260), as a loop over devices.  A window's cells ~ (bases) x (mean length) x (1 + depth / 20)
 // (shard.py:poa_cost: the graph starts as the first sequence and grows by about a tenth of every later one).
-int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
-                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
-                           const char *arena, int64_t arena_bytes,
-                           char *cons, int32_t *cons_len, int64_t cons_stride)
+static int poa_host_entry(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                          int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                          const char *arena, int64_t arena_bytes,
+                          char *cons, int32_t *cons_len, int64_t cons_stride)
 {
     auto one = [&]() { return poa_host_one(p, n_windows, win_first_seq, n_seqs, seq_off, seq_len, arena, arena_bytes, cons, cons_len, cons_stride); };
     if (!host_multi_wanted() || !p || n_windows <= 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0 || !win_first_seq || !seq_off ||
@@ -306,6 +306,102 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         for (int64_t s = a; s < b; ++s) so[(size_t)(s - a)] = seq_off[s] - a0;
         return poa_host_one(p, m, wf.data(), b - a, so.data(), seq_len + a, arena + a0, a1 - a0, cons + lo * cons_stride, cons_len + lo, cons_stride, lo, a);
     });
+}
+
+}  // extern "C"
+
+// ---- small concurrent calls combined (host_combine.h).  The reference's driver builds one window per OpenMP thread and asks
+// for its consensus (msa_spoa_omp.cpp:230-260; through include/spoa/spoa.hpp that is one one-window call per thread): the
+// windows that are pending together become one job.  A request's consensus rows have its own stride; the combined call
+// uses the widest and a consensus that would not have fitted its caller's rows sends that caller back through its own call,
+// which reports it as it always did.
+namespace {
+struct PoaReq : CombineReq {
+    const gbx_poa_params *p; int64_t n_windows; const int64_t *win_first_seq; int64_t n_seqs; const int64_t *seq_off; const int32_t *seq_len;
+    const char *arena; int64_t arena_bytes; char *cons; int32_t *cons_len; int64_t cons_stride;
+    int64_t cb;                           // bytes of its sequences laid end to end
+};
+struct PoaScratch { Scratch<int64_t> wf, off; Scratch<int32_t> len, clen; Scratch<char> arena, cons; };
+constexpr int64_t POA_COMBINE_MAX_CALL = 64, POA_COMBINE_MAX_JOB = 16384;
+}
+namespace gbx { Combiner &combiner_poa() { static Combiner *c = new Combiner(); return *c; } }
+
+static void poa_run_alone(PoaReq *r)
+{
+    r->rc = poa_host_entry(r->p, r->n_windows, r->win_first_seq, r->n_seqs, r->seq_off, r->seq_len, r->arena, r->arena_bytes, r->cons, r->cons_len,
+                           r->cons_stride);
+    if (r->rc) r->err = gbx_last_error();
+}
+
+static void poa_run_combined(const std::vector<CombineReq *> &batch)
+{
+    if (batch.size() == 1) { poa_run_alone((PoaReq *)batch[0]); return; }
+    static PoaScratch *S = new PoaScratch();      // one leader at a time
+    const size_t nb = batch.size();
+    std::vector<int64_t> w0(nb + 1, 0), s0(nb + 1, 0), b0(nb + 1, 0);
+    int64_t stride = 1;
+    for (size_t k = 0; k < nb; ++k) {
+        const PoaReq *r = (const PoaReq *)batch[k];
+        w0[k + 1] = w0[k] + r->n_windows; s0[k + 1] = s0[k] + r->n_seqs; b0[k + 1] = b0[k] + r->cb;
+        stride = r->cons_stride > stride ? r->cons_stride : stride;
+    }
+    const int64_t NW = w0[nb], NS = s0[nb], NB = b0[nb];
+    int64_t *mwf = S->wf.get((size_t)NW + 1), *moff = S->off.get((size_t)NS);
+    int32_t *mlen = S->len.get((size_t)NS), *mcl = S->clen.get((size_t)NW);
+    char *mar = S->arena.get((size_t)NB + 32), *mcons = S->cons.get((size_t)(NW * stride));
+    for (size_t k = 0; k < nb; ++k) {
+        const PoaReq *r = (const PoaReq *)batch[k];
+        int64_t at = b0[k];
+        for (int64_t j = 0; j < r->n_seqs; ++j) {
+            memcpy(mar + at, r->arena + r->seq_off[j], (size_t)r->seq_len[j]);
+            moff[s0[k] + j] = at; mlen[s0[k] + j] = r->seq_len[j];
+            at += r->seq_len[j];
+        }
+        for (int64_t w = 0; w < r->n_windows; ++w) mwf[w0[k] + w] = s0[k] + r->win_first_seq[w];
+    }
+    mwf[NW] = NS;
+    memset(mar + NB, 0, 32);
+    const PoaReq *lead = (const PoaReq *)batch[0];
+    const int rc = poa_host_entry(lead->p, NW, mwf, NS, moff, mlen, mar, NB, mcons, mcl, stride);
+    if (rc) { for (CombineReq *q : batch) poa_run_alone((PoaReq *)q); return; }      // (a window over a capacity: its own call names it)
+    for (size_t k = 0; k < nb; ++k) {
+        PoaReq *r = (PoaReq *)batch[k];
+        bool fits = true;
+        for (int64_t w = 0; w < r->n_windows; ++w) fits = fits && mcl[w0[k] + w] <= r->cons_stride;
+        if (!fits) { poa_run_alone(r); continue; }
+        for (int64_t w = 0; w < r->n_windows; ++w) {
+            r->cons_len[w] = mcl[w0[k] + w];
+            memcpy(r->cons + w * r->cons_stride, mcons + (w0[k] + w) * stride, (size_t)mcl[w0[k] + w]);
+        }
+        r->rc = GBX_OK;
+    }
+}
+
+extern "C" {
+
+int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                           const char *arena, int64_t arena_bytes,
+                           char *cons, int32_t *cons_len, int64_t cons_stride)
+{
+    auto plain = [&] { return poa_host_entry(p, n_windows, win_first_seq, n_seqs, seq_off, seq_len, arena, arena_bytes, cons, cons_len, cons_stride); };
+    if (!p || n_windows <= 0 || n_windows > POA_COMBINE_MAX_CALL || n_seqs <= 0 || arena_bytes < 0 || cons_stride <= 0 || !win_first_seq || !seq_off ||
+        !seq_len || !arena || !cons || !cons_len || win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs || !combine_enabled() ||
+        profile_active())
+        return plain();
+    PoaReq r;
+    r.p = p; r.n_windows = n_windows; r.win_first_seq = win_first_seq; r.n_seqs = n_seqs; r.seq_off = seq_off; r.seq_len = seq_len;
+    r.arena = arena; r.arena_bytes = arena_bytes; r.cons = cons; r.cons_len = cons_len; r.cons_stride = cons_stride; r.units = n_windows; r.cb = 0;
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (win_first_seq[w + 1] < win_first_seq[w] || win_first_seq[w + 1] > n_seqs) return plain();
+    for (int64_t k = 0; k < n_seqs; ++k) {
+        if (seq_len[k] < 0 || seq_off[k] < 0 || seq_off[k] + seq_len[k] > arena_bytes) return plain();
+        r.cb += seq_len[k];
+    }
+    if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
+    return combiner_poa().submit(&r, POA_COMBINE_MAX_JOB,
+        [](const CombineReq *a, const CombineReq *b) { return memcmp(((const PoaReq *)a)->p, ((const PoaReq *)b)->p, offsetof(gbx_poa_params, pad_)) == 0; },
+        poa_run_combined);
 }
 
 }  // extern "C"

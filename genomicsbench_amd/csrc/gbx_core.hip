@@ -48,6 +48,7 @@ int require_device()
 struct StageRec { const char *name; hipEvent_t a, b; };
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<StageRec> g_prof;
+bool profile_active() { return g_prof_on; }
 
 // ---- roctx ranges (optional, GBX_ROCTX=1) -------------------------------------
 namespace {
@@ -306,6 +307,15 @@ int gbx_host_release(void)
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     (void)hipGetLastError();
+    return GBX_OK;
+}
+
+int gbx_host_combine_stats(int kernel, uint64_t out[4], int reset)
+{
+    Combiner *c = kernel == GBX_GK_BSW ? &combiner_bsw() : kernel == GBX_GK_PHMM ? &combiner_phmm() : kernel == GBX_GK_POA ? &combiner_poa() : nullptr;
+    if (!c || !out) { set_error("gbx_host_combine_stats: kernel 1 (bsw), 3 (phmm) or 4 (poa), and four words"); return GBX_ERR_ARG; }
+    out[0] = c->n_calls.load(); out[1] = c->n_batches.load(); out[2] = c->n_shared.load(); out[3] = c->largest.load();
+    if (reset) { c->n_calls = 0; c->n_batches = 0; c->n_shared = 0; c->largest = 0; }
     return GBX_OK;
 }
 

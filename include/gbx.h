@@ -70,6 +70,13 @@ int  gbx_host_prepare(void);
 int  gbx_host_reserve(size_t bytes);
 /* Frees the device memory the *_host entries keep cached between calls (idle lanes only).  Optional. */
 int  gbx_host_release(void);
+/* Concurrent small calls of gbx_bsw_extend_host / _seqpairs, gbx_phmm_forward_host and gbx_poa_consensus_host are
+ * combined: calls that are pending together (the reference drivers' OpenMP threads, one small call each:
+ * bsw/main_banded.cpp:279-291, phmm/PairHMMUnitTest.cpp:224-247, poa/msa_spoa_omp.cpp:230-260) share one upload, one launch
+ * set and one download, and every caller gets its own results and status.  Nothing to call: GBX_COMBINE=0 in the
+ * environment switches it off.  This reads the counters of one kernel (1 bsw, 3 phmm, 4 poa): out[0] calls that were
+ * eligible, out[1] device calls made for them, out[2] calls that shared a device call, out[3] most calls in one. */
+int  gbx_host_combine_stats(int kernel, uint64_t out[4], int reset);
 
 /* Timing helpers on a stream (HIP events), so that a Python/ctypes host can
  * time the exact stream the kernels are launched on without touching HIP. */

@@ -54,6 +54,21 @@ def test_gkl_dropin_library_exports_the_symbols_the_reference_driver_binds():
         assert s in syms, s
 
 
+def test_bsw_class_shim_defines_every_public_entry_point_of_the_class():
+    """csrc/shims/bsw_class_shim.cpp against the reference's bandedSWA.h:116-315: a harness that calls scalarBandedSWA,
+    scalarBandedSWAWrapper, getScores8 / 16 and both batch wrappers links against the shim alone (oracle/build_ref.sh;
+    only where /root/reference was present at build time), i.e. no member of the class is left undefined."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "bsw_members_gbx")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/bsw_members_gbx not built (no /root/reference at build time)")
+    undefined = [l for l in run(["nm", "-u", "-C", exe]).stdout.splitlines() if "BandedPairWiseSW" in l]
+    assert undefined == [], undefined
+    defined = run(["nm", "-C", "--defined-only", exe]).stdout
+    for m in ("scalarBandedSWA(", "scalarBandedSWAWrapper(", "getScores8(", "getScores16(", "smithWatermanBatchWrapper8(",
+              "smithWatermanBatchWrapper16(", "getTicks("):
+        assert "BandedPairWiseSW::" + m in defined, m
+
+
 def _fnv1a(chunks):
     h = 1469598103934665603
     for c in chunks:

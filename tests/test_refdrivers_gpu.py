@@ -100,3 +100,33 @@ def test_reference_poa_driver_rejects_positive_gap_penalties(tmp_path):
     gio.write_poa_windows(inp, ws)
     r = run([driver("poa_refdriver_gbx"), "-s", inp, "-o", "-9,24"])         # -o negates: o1 = +9 -> g = o1+e1 > 0
     assert r.returncode == 1 and "non-positive" in r.stderr
+
+
+def test_every_public_member_of_the_bsw_class_on_gbx(tmp_path):
+    """bandedSWA.h:116-315: scalarBandedSWA (one pair per call, here from eight threads at once: the calls share device
+    calls), scalarBandedSWAWrapper, getScores8 / getScores16 and their batch wrappers, all on the shim, all six output
+    fields against the oracle - and against the reference's own scalar members run from the same harness on the CPU."""
+    b = gen_bsw(300, 31)
+    pairs = str(tmp_path / "pairs.txt")
+    gio.write_bsw_pairs(pairs, b)
+    want = O.bsw_oracle(make_params(), b, 2)
+    r = run([driver("bsw_members_gbx"), pairs, "sw8bB6", "8"])
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
+    got = {}
+    for line in r.stdout.splitlines():
+        f = line.split()
+        got.setdefault(f[0], []).append([int(x) for x in f[1:]])
+    members = ["scalarBandedSWA", "scalarBandedSWAWrapper", "getScores8", "smithWatermanBatchWrapper8", "smithWatermanBatchWrapper16", "getScores16"]
+    assert sorted(got) == sorted(members)
+    for m in members:
+        a = np.array(got[m], dtype=np.int64)
+        a = a[np.argsort(a[:, 0], kind="stable")]
+        assert a.shape[0] == b.n and np.array_equal(a[:, 0], np.arange(b.n)), m
+        assert np.array_equal(a[:, 1:], want), m
+    ref = os.path.join(REF, "bsw_members_ref")
+    if os.path.exists(ref):
+        rr = run([ref, pairs, "sw"])
+        assert rr.returncode == 0, rr.stderr[-400:]
+        for line in rr.stdout.splitlines():
+            f = line.split()
+            assert [int(x) for x in f[2:]] == list(want[int(f[1])]), line
