@@ -344,10 +344,11 @@ static void bsw_run_alone(BswReq *r)
     if (r->rc) r->err = gbx_last_error();
 }
 
-static void bsw_run_combined(const std::vector<CombineReq *> &batch)
+static void bsw_run_combined(const std::vector<CombineReq *> &batch, int slot)
 {
     if (batch.size() == 1) { bsw_run_alone((BswReq *)batch[0]); return; }
-    static BswScratch *S = new BswScratch();      // one leader at a time (Combiner::leading)
+    static BswScratch *slots = new BswScratch[Combiner::MAX_LEADERS];      // one per leader in flight (Combiner::submit)
+    BswScratch *S = slots + slot;
     const size_t nb = batch.size();
     std::vector<int64_t> p0(nb + 1, 0), r0(nb + 1, 0), q0(nb + 1, 0);
     for (size_t k = 0; k < nb; ++k) {
@@ -407,7 +408,7 @@ int gbx_bsw_extend_host(const gbx_bsw_params *p, int64_t n,
         r.cr += (len1[k] + 3) & ~3; r.cq += (len2[k] + 3) & ~3;
     }
     if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    return combiner_bsw().submit(&r, BSW_COMBINE_MAX_JOB,
+    return combiner_bsw().submit(&r, BSW_COMBINE_MAX_JOB, Combiner::max_leaders(1),
         [](const CombineReq *a, const CombineReq *b) { return memcmp(((const BswReq *)a)->p, ((const BswReq *)b)->p, offsetof(gbx_bsw_params, pad_)) == 0; },
         bsw_run_combined);
 }

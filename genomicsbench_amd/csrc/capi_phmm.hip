@@ -234,10 +234,11 @@ static void phmm_run_alone(PhmmReq *r)
     if (r->rc) r->err = gbx_last_error();
 }
 
-static void phmm_run_combined(const std::vector<CombineReq *> &batch)
+static void phmm_run_combined(const std::vector<CombineReq *> &batch, int slot)
 {
     if (batch.size() == 1) { phmm_run_alone((PhmmReq *)batch[0]); return; }
-    static PhmmScratch *S = new PhmmScratch();    // one leader at a time
+    static PhmmScratch *slots = new PhmmScratch[Combiner::MAX_LEADERS];      // one per leader in flight (Combiner::submit)
+    PhmmScratch *S = slots + slot;
     const size_t nb = batch.size();
     std::vector<int64_t> p0(nb + 1, 0), r0(nb + 1, 0), h0(nb + 1, 0), rb(nb + 1, 0), hb(nb + 1, 0);
     for (size_t k = 0; k < nb; ++k) {
@@ -308,7 +309,7 @@ int gbx_phmm_forward_host(int64_t n_pairs, const int32_t *pair_read, const int32
     for (int64_t k = 0; k < n_pairs; ++k)
         if (pair_read[k] < 0 || pair_read[k] >= n_reads || pair_hap[k] < 0 || pair_hap[k] >= n_haps) return plain();
     if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    return combiner_phmm().submit(&r, PHMM_COMBINE_MAX_JOB, [](const CombineReq *, const CombineReq *) { return true; }, phmm_run_combined);
+    return combiner_phmm().submit(&r, PHMM_COMBINE_MAX_JOB, Combiner::max_leaders(2), [](const CombineReq *, const CombineReq *) { return true; }, phmm_run_combined);
 }
 
 }  // extern "C"

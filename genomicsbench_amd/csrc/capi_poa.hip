@@ -333,10 +333,11 @@ static void poa_run_alone(PoaReq *r)
     if (r->rc) r->err = gbx_last_error();
 }
 
-static void poa_run_combined(const std::vector<CombineReq *> &batch)
+static void poa_run_combined(const std::vector<CombineReq *> &batch, int slot)
 {
     if (batch.size() == 1) { poa_run_alone((PoaReq *)batch[0]); return; }
-    static PoaScratch *S = new PoaScratch();      // one leader at a time
+    static PoaScratch *slots = new PoaScratch[Combiner::MAX_LEADERS];      // one per leader in flight (Combiner::submit)
+    PoaScratch *S = slots + slot;
     const size_t nb = batch.size();
     std::vector<int64_t> w0(nb + 1, 0), s0(nb + 1, 0), b0(nb + 1, 0);
     int64_t stride = 1;
@@ -399,7 +400,7 @@ int gbx_poa_consensus_host(const gbx_poa_params *p, int64_t n_windows, const int
         r.cb += seq_len[k];
     }
     if (hipGetDevice(&r.dev) != hipSuccess) { (void)hipGetLastError(); return plain(); }
-    return combiner_poa().submit(&r, POA_COMBINE_MAX_JOB,
+    return combiner_poa().submit(&r, POA_COMBINE_MAX_JOB, Combiner::max_leaders(1),
         [](const CombineReq *a, const CombineReq *b) { return memcmp(((const PoaReq *)a)->p, ((const PoaReq *)b)->p, offsetof(gbx_poa_params, pad_)) == 0; },
         poa_run_combined);
 }

@@ -12,7 +12,8 @@
 // takes everything that is pending and compatible (same device, same scoring parameters), lays the inputs end to end in
 // scratch arrays (a few helper threads copy), issues ONE call of the kernel's ordinary host path - one packed upload, one
 // launch set, one download -, hands every caller its slice of the results and wakes them; whoever is pending by then is
-// led by one of the woken.  A call that meets nobody runs on its own arrays exactly as before (one mutex taken).
+// led by one of the woken.  A call that meets nobody runs on its own arrays exactly as before (one mutex taken).  Up to
+// two leaders work at a time (GBX_COMBINE_LEADERS): the host side of one combined call overlaps the device side of the other.
 //
 // Callers come in crowds (an OpenMP team leaves one combined call together and is back within microseconds of each other),
 // but the first one back would lead alone and the crowd would wait behind its tiny call: a leader that finds fewer
@@ -49,10 +50,12 @@ static bool combine_enabled()
 }
 
 struct Combiner {
+    static constexpr int MAX_LEADERS = 4;
     std::mutex mu;
     std::condition_variable cv_done, cv_arrive;
     std::vector<CombineReq *> pending;
-    bool leading = false;
+    bool slot_busy[MAX_LEADERS] = {false, false, false, false};
+    int leaders = 0;
     double crowd = 1.0;                   // requests per combined call, lately (decaying maximum)
     // counters (gbx_host_combine_stats): calls submitted, device calls made, calls that shared one, most calls in one
     std::atomic<uint64_t> n_calls{0}, n_batches{0}, n_shared{0}, largest{0};
@@ -63,39 +66,57 @@ struct Combiner {
         const int v = e ? atoi(e) : 150;
         return v < 0 ? 0 : v > 100000 ? 100000 : v;
     }
+    // Combined calls in flight at once.  Two: while one crowd's call is on the device the callers that arrive meanwhile are
+    // laid out and sent by a leader of their own, on a lane of its own - the host side of one call (gathering, copying,
+    // handing out results, the driver's own work between calls) overlaps the device side of the other.
+    static int max_leaders(int dflt)
+    {
+        const char *e = getenv("GBX_COMBINE_LEADERS");
+        const int v = e ? atoi(e) : dflt;
+        return v < 1 ? 1 : v > MAX_LEADERS ? MAX_LEADERS : v;
+    }
 
-    // same(a, b): may b ride in a's call.  run(batch): performs every request of batch (batch[0] is the leader's own) and sets
-    // their rc / err; it must not throw past bad_alloc.  Returns the caller's status with its error text set on its thread.
-    template <class Same, class Run> int submit(CombineReq *r, int64_t max_units, Same same, Run run)
+    // same(a, b): may b ride in a's call.  run(batch, slot): performs every request of batch (batch[0] is the leader's own) and
+    // sets their rc / err; slot (0 .. MAX_LEADERS-1) is this leader's alone while it runs (scratch arrays are kept per slot);
+    // it must not throw past bad_alloc.  Returns the caller's status with its error text set on its thread.
+    template <class Same, class Run> int submit(CombineReq *r, int64_t max_units, int n_leaders, Same same, Run run)
     {
         std::unique_lock<std::mutex> lk(mu);
         n_calls.fetch_add(1, std::memory_order_relaxed);
         pending.push_back(r);
-        cv_arrive.notify_one();
+        cv_arrive.notify_all();
         while (!r->done) {
-            if (leading || r->taken) { cv_done.wait(lk); continue; }
-            leading = true;
+            if (r->taken || leaders >= n_leaders) { cv_done.wait(lk); continue; }
+            // this caller leads: its request leaves the pool now, so that no other leader can take it meanwhile
+            ++leaders;
+            int slot = 0;
+            while (slot_busy[slot]) ++slot;
+            slot_busy[slot] = true;
+            r->taken = true;
+            for (size_t k = 0; k < pending.size(); ++k) if (pending[k] == r) { pending.erase(pending.begin() + (long)k); break; }
             const size_t want = (size_t)(crowd + 0.5);
             const int wait_us = gather_us();
-            if (pending.size() < want && wait_us > 0)
-                cv_arrive.wait_for(lk, std::chrono::microseconds(wait_us), [&] { return pending.size() >= want; });
+            if (pending.size() + 1 < want && wait_us > 0)
+                // (a deadline on the system clock: pthread_cond_timedwait, which ThreadSanitizer sees through - wait_for's
+                // pthread_cond_clockwait it does not, and reports the mutex as held across the wait; a clock step only
+                // shortens or lengthens one gathering pause)
+                cv_arrive.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(wait_us), [&] { return pending.size() + 1 >= want; });
             std::vector<CombineReq *> batch(1, r), rest;
             int64_t units = r->units;
             for (CombineReq *q : pending) {
-                if (q == r) continue;
                 if (q->dev == r->dev && units + q->units <= max_units && same(r, q)) { batch.push_back(q); units += q->units; q->taken = true; }
                 else rest.push_back(q);
             }
-            r->taken = true;
             pending.swap(rest);
             lk.unlock();
-            try { run(batch); }
+            try { run(batch, slot); }
             catch (const std::bad_alloc &) {
                 for (CombineReq *q : batch) { q->rc = GBX_ERR_NOMEM; q->err = "out of host memory while combining host calls"; }
             }
             lk.lock();
             for (CombineReq *q : batch) q->done = true;
-            leading = false;
+            --leaders;
+            slot_busy[slot] = false;
             const double got = (double)batch.size();
             crowd = got > crowd * 0.75 ? got : crowd * 0.75;
             if (crowd < 1.0) crowd = 1.0;

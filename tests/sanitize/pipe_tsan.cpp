@@ -33,7 +33,10 @@ namespace gbx {
 int host_device_set(int *map) { for (int k = 0; k < 3; ++k) map[k] = 0; return 3; }
 int host_next_small_call_device(int n) { static std::atomic<unsigned> rr{0}; return (int)(rr.fetch_add(1) % (unsigned)n); }
 bool host_multi_wanted() { return true; }
+bool profile_active() { return false; }
 }
+// the call combiner of the host entries (csrc/host_combine.h, unmodified)
+#include "host_combine.h"
 
 using namespace gbx;
 
@@ -278,6 +281,95 @@ int main(int argc, char **argv)
         const int rc = multi_job(20000, 5003, 1);
         CHECK(rc == GBX_ERR_ARG && strstr(g_err, "shard 1 was told to fail") && strstr(g_err, "[shard 1 of 3"), "failing shard: rc %d, text '%s'", rc, g_err);
         CHECK(call_one_chunk((size_t)1 << 20, 5004, true) == GBX_OK, "call after a failed multi-device job: %s", g_err);
+    }
+    // (e) the call combiner (host_combine.h): many caller threads submit small requests round after round; a leader lays a
+    //     batch's inputs end to end in its slot's scratch arrays (helper threads copy), runs ONE staged call for all of them and
+    //     hands every caller its slice; two leaders in flight, requests of two "scoring" classes that must not mix, one request
+    //     in twenty a bad one whose combined call fails and is redone request by request: every caller gets the result and the
+    //     status of its own call
+    {
+        struct Req : CombineReq { int cls; std::vector<uint8_t> in, out; bool bad; };
+        struct Slot { Scratch<uint8_t> in, out; };
+        static Combiner comb;
+        static Slot slots[Combiner::MAX_LEADERS];
+        static std::atomic<int> mixed{0}, combined_calls{0};
+        auto alone = [](Req *r) {
+            if (r->bad) { r->rc = GBX_ERR_ARG; r->err = "request was told to fail"; return; }
+            for (size_t i = 0; i < r->in.size(); ++i) r->out[i] = (uint8_t)(r->in[i] * 3 + r->cls);
+            r->rc = GBX_OK;
+        };
+        auto run = [&](const std::vector<CombineReq *> &batch, int slot) {
+            if (batch.size() == 1) { alone((Req *)batch[0]); return; }
+            ++combined_calls;
+            std::vector<size_t> off(batch.size() + 1, 0);
+            bool any_bad = false;
+            for (size_t k = 0; k < batch.size(); ++k) {
+                const Req *r = (const Req *)batch[k];
+                off[k + 1] = off[k] + r->in.size();
+                any_bad = any_bad || r->bad;
+                if (r->cls != ((const Req *)batch[0])->cls) ++mixed;
+            }
+            uint8_t *in = slots[slot].in.get(off.back() + 1), *out = slots[slot].out.get(off.back() + 1);
+            combine_parallel((int64_t)batch.size(), 4, [&](int64_t k) { const Req *r = (const Req *)batch[(size_t)k]; memcpy(in + off[(size_t)k], r->in.data(), r->in.size()); });
+            if (any_bad) { for (CombineReq *q : batch) alone((Req *)q); return; }      // the combined call failed: one by one
+            // the device call of the batch: a staged one-chunk upload / "kernel" / download through a lane (host_pipeline.h)
+            {
+                HostLane lane;
+                int rc = lane.acquire();
+                DevBuf din(lane.l), dout(lane.l);
+                if (!rc) rc = din.alloc(off.back() + 1);
+                if (!rc) rc = dout.alloc(off.back() + 1);
+                if (!rc) {
+                    HostPipe pipe(lane.l, off.back(), false);
+                    rc = pipe.prepare(1);
+                    if (!rc) {
+                        pipe.stage(0, din.p, in, off.back());
+                        pipe.start();
+                        rc = pipe.wait_stage(0);
+                        const int cls = ((const Req *)batch[0])->cls;
+                        const size_t total = off.back();
+                        uint8_t *a = din.as<uint8_t>(), *b = dout.as<uint8_t>();
+                        if (!rc) mock_launch(lane.l->compute, [=] { for (size_t i = 0; i < total; ++i) b[i] = (uint8_t)(a[i] * 3 + cls); });
+                        if (!rc) { pipe.fetch(0, out, dout.p, total); rc = pipe.chunk_launched(0); }
+                        rc = pipe.finish(rc);
+                    }
+                }
+                if (rc) { for (CombineReq *q : batch) { q->rc = rc; q->err = g_err; } return; }
+            }
+            for (size_t k = 0; k < batch.size(); ++k) {
+                Req *r = (Req *)batch[k];
+                memcpy(r->out.data(), out + off[k], r->in.size());
+                r->rc = GBX_OK;
+            }
+        };
+        setenv("GBX_COMBINE_GATHER_US", "300", 1);
+        const int callers = threads * 3;
+        std::vector<std::thread> ct;
+        for (int t = 0; t < callers; ++t)
+            ct.emplace_back([&, t] {
+                std::mt19937_64 rng(7000u + (uint64_t)t);
+                for (int it = 0; it < 40 * rounds; ++it) {
+                    Req r;
+                    r.cls = (t + it) & 1;
+                    r.bad = rng() % 20 == 0;
+                    r.in = random_bytes(200 + (size_t)(rng() % 30000), rng());
+                    r.out.assign(r.in.size(), 0);
+                    r.units = (int64_t)r.in.size();
+                    const int rc = comb.submit(&r, (int64_t)1 << 20, 2,
+                        [](const CombineReq *a, const CombineReq *b) { return ((const Req *)a)->cls == ((const Req *)b)->cls; }, run);
+                    if (r.bad) { CHECK(rc == GBX_ERR_ARG && strstr(g_err, "told to fail"), "a bad request's status: %d '%s'", rc, g_err); continue; }
+                    CHECK(rc == GBX_OK, "combined request: %s", g_err);
+                    bool ok = true;
+                    for (size_t i = 0; i < r.in.size() && ok; ++i) ok = r.out[i] == (uint8_t)(r.in[i] * 3 + r.cls);
+                    CHECK(ok, "a combined request came back with another request's results");
+                }
+            });
+        for (auto &x : ct) x.join();
+        CHECK(mixed.load() == 0, "requests of different classes shared a call");
+        CHECK(comb.n_calls.load() == (uint64_t)callers * 40u * (uint64_t)rounds, "combiner call count");
+        CHECK(combined_calls.load() > 0 && comb.largest.load() >= 2, "no call was ever combined (largest %llu)", (unsigned long long)comb.largest.load());
+        printf("pipe_tsan: combiner %llu calls in %llu device calls, %llu shared, largest %llu\n", (unsigned long long)comb.n_calls.load(),
+               (unsigned long long)comb.n_batches.load(), (unsigned long long)comb.n_shared.load(), (unsigned long long)comb.largest.load());
     }
     if (g_fail.load()) { fprintf(stderr, "pipe_tsan: %d check(s) failed\n", g_fail.load()); return 1; }
     printf("pipe_tsan: ok (%d caller threads x %d rounds)\n", threads, rounds);

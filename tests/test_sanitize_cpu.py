@@ -84,10 +84,13 @@ def test_host_pipeline_under_thread_sanitizer(san_build):
     unmodified against a mock HIP runtime (tests/sanitize/mock_hip: streams are in-order worker threads) and driven by
     four caller threads at once through every call shape the host entries use - staged, unstaged / packed, three
     overlapped chunks with packed bases, strided-field upload + scattered download, a call abandoned after start(), a
-    transfer failing mid-call: no data race, no hang, right results.  The harness is checked to see a race when there is one."""
+    transfer failing mid-call: no data race, no hang, right results; and the call combiner (csrc/host_combine.h, unmodified):
+    twelve callers submitting small requests of two classes, two leaders in flight, failing requests redone one by one, every
+    caller its own results and status.  The harness is checked to see a race when there is one."""
     exe = os.path.join(SAN, "_build", "pipe_tsan")
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
     r = subprocess.run([exe, "--selftest-race"], capture_output=True, text=True, timeout=120, env=env)
     assert "ThreadSanitizer: data race" in r.stderr, "the TSan build does not report a deliberate race"
     r = subprocess.run([exe, "4", "1"], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "pipe_tsan: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-4000:]
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr and "pipe_tsan: ok" in r.stdout and "pipe_tsan: combiner" in r.stdout, \
+        r.stdout[-1500:] + r.stderr[-4000:]
