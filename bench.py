@@ -179,6 +179,9 @@ class BswWork:
         if not os.path.exists(exe):
             return {"error": "genomicsbench_amd/bin/bsw is not built"}
         cores = os.cpu_count() or 1
+        quota = _cpu_quota()
+        if quota:                                           # ingest threads beyond the container's CPU quota only oversubscribe it
+            cores = max(1, min(cores, int(-(-quota // 1))))
         d = tempfile.mkdtemp(prefix="gbx_bsw_e2e_")
         path = os.path.join(d, "pairs.txt")
         try:
@@ -194,6 +197,7 @@ class BswWork:
                     if best is None or j["e2e_seconds"] < best["e2e_seconds"]:
                         best = j
                 recs[name] = best
+            refdrv = self.refdriver(path)
         finally:
             try:
                 os.remove(path)
@@ -203,11 +207,30 @@ class BswWork:
         o, q = recs["overlapped"], recs["serial"]
         # (measured, profiles/r05k_bsw_e2e.txt: on the pool's boxes - 16 cores of CPU quota - the overlapped flow is the slower
         # one: every slice's call pays for fresh device buffers and shares the cores with the conversion; both are reported)
-        return {"e2e_ms": min(o["e2e_seconds"], q["e2e_seconds"]) * 1e3, "e2e_ms_overlapped": o["e2e_seconds"] * 1e3,
+        return {"e2e_ms": min(o["e2e_seconds"], q["e2e_seconds"]) * 1e3, "e2e_flow": "overlapped" if o["e2e_seconds"] < q["e2e_seconds"] else "parse_then_call",
+                "refdriver": refdrv, "e2e_ms_overlapped": o["e2e_seconds"] * 1e3,
                 "e2e_ms_parse_then_call": q["e2e_seconds"] * 1e3, "ingest_ms": q["ingest_seconds"] * 1e3,
                 "call_ms_in_driver": q["seconds"] * 1e3, "ingest_threads": o["ingest_threads"], "input_file_mb": round(size / 1e6, 1),
                 "what": "genomicsbench_amd/bin/bsw -pairs <file> -t %d: text conversion + H2D + kernels + D2H, file already in memory"
                         % o["ingest_threads"]}
+
+    def refdriver(self, path):
+        """The reference's UNMODIFIED driver (main_banded.cpp on csrc/shims/bsw_class_shim.cpp: oracle/_ref/bsw_refdriver_gbx) on
+        the same file, called as the reference's scripts call it - one getScores16 per 512 pairs per OpenMP thread
+        (run-cpu.sh:61) -: its own timed region ("Overall SW cycles"), the concurrent calls combined by the host entry."""
+        import re, subprocess
+        exe = os.path.join(ROOT, "oracle", "_ref", "bsw_refdriver_gbx")
+        if not os.path.exists(exe):
+            return None
+        out = {"what": "unmodified main_banded.cpp on the shim, the driver's own 'Overall SW cycles' region, seconds"}
+        for key, t, b in (("t64_b512_s", 64, 512), ("t16_b512_s", 16, 512), ("t1_one_call_s", 1, self.batch.n)):
+            try:
+                r = subprocess.run([exe, "-pairs", path, "-t", str(t), "-b", str(b)], capture_output=True, text=True, timeout=300)
+                m = re.search(r"Overall SW cycles = \d+, ([0-9.]+) s", r.stdout)
+                out[key] = float(m.group(1)) if m else None
+            except (OSError, subprocess.TimeoutExpired):
+                out[key] = None
+        return out
 
     def cpu_baseline(self, max_units):
         """The reference's own AVX2 getScores16 (oracle/_ref, kind 'reference') when its build travelled here,
@@ -257,7 +280,8 @@ class ChainWork:
 
     def __init__(self, args):
         self.n = args.size or self.large
-        self.workload = "chain large: %d synthetic minimap2 chaining calls per GPU (seed 2001), inputs resident in HBM" % self.n
+        self.workload = ("chain large: %d synthetic minimap2 calls per GPU (seed 2001), resident in HBM; the step is bound by its longest "
+                         "call (one serial recurrence: longest_job_ms)" % self.n)
         self.detail = {"cell": "evaluated predecessor pair (i, j) of chain_dp's inner loop"}
 
     def generate(self, first, n_units):
@@ -1056,6 +1080,17 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in sorted(stages.items())},
         "scatter_ms": scatter_ms, "gather_ms": gather_ms, "rccl_ranks": world, "comm": ctx["comm"],
     }
+    if kind == "fmi":
+        # fmi's algorithmic bytes are line REQUESTS (two 64-byte lines per backwardExt), 60 % of which hit L2: the HBM fraction is
+        # the counters' (FETCH_SIZE + WRITE_SIZE per launch, profiles/hbm_traffic.json), the request rate is kept beside it
+        rf = line["roofline"]
+        rf["l2_request_gbs"], rf["l2_request_frac"] = rf["achieved"], rf["frac"]
+        if traffic:
+            rf["achieved"] = traffic / (k_ms * 1e-3) / 1e9
+            rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+            rf["achieved_source"] = "HBM counters (traffic) over the kernel's live duration; l2_request_* = algorithmic line requests"
+        else:
+            rf["achieved_source"] = "line requests (no counter table for these sources): an upper bound on HBM bytes"
     if args.mode != "local":
         line["dataset_gen_s"] = gen_s
         line["gather_verified"] = work.check_gathered(full, ranges, parts, args.verify_units or
@@ -1184,11 +1219,23 @@ def self_launch(args, argv):
     if args.launch_dry_run:
         print(json.dumps({"launch": plan}), flush=True)
         return 0
-    procs = []
+    import threading
+    procs, relays = [], []
+
+    def relay(r, pipe):                                     # every rank's stderr, line by line, with its rank in front
+        for ln in iter(pipe.readline, b""):
+            sys.stderr.buffer.write(b"[rank %d] " % r + ln)
+            sys.stderr.buffer.flush()
+        pipe.close()
+
     for r, p in enumerate(plan):
         env = dict(os.environ)
         env.update(p["env"])
-        procs.append(subprocess.Popen(p["argv"], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+        pr = subprocess.Popen(p["argv"], env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(pr)
+        t = threading.Thread(target=relay, args=(r, pr.stderr), daemon=True)
+        t.start()
+        relays.append(t)
     rc, live = 0, list(procs)
     while live:
         time.sleep(0.2)
@@ -1201,7 +1248,16 @@ def self_launch(args, argv):
                 rc = rc or (code if code > 0 else 128 - code)
                 for other in live:                         # a dead rank leaves the others in a collective: stop them
                     other.terminate()
+    for t in relays:
+        t.join(timeout=5)
     return rc
+
+
+def _pg_timeout():
+    """A rank that never arrives must fail the run, not hang it: every collective and rendezvous of the process group gives up
+    after GBX_BENCH_TIMEOUT_S (default 900 s: rank 0 generates and cuts N x 'large' before the first scatter)."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("GBX_BENCH_TIMEOUT_S", "900")))
 
 
 def main():
@@ -1259,14 +1315,31 @@ def main():
 
     if args.launch_echo:
         if rank == args.launch_echo_fail:
+            print("launch-echo: rank %d was told to fail" % rank, file=sys.stderr, flush=True)
             sys.exit(7)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
-        t = torch.tensor([float(rank)], dtype=torch.float64)
+        # RCCL when every rank has a device of its own (the first contact of init_process_group("nccl", device_id=...) and a
+        # grouped send / receive with this launcher), gloo otherwise (the launcher alone, no GPU needed)
+        backend = "nccl" if torch.cuda.device_count() >= world and os.environ.get("GBX_BENCH_COMM", "nccl") != "gloo" else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=_pg_timeout())
+            edev = torch.device("cuda", local)
+        else:
+            dist.init_process_group("gloo", timeout=_pg_timeout())
+            edev = torch.device("cpu")
+        t = torch.tensor([float(rank)], dtype=torch.float64, device=edev)
         dist.all_reduce(t)
+        # the scatter's shape in small: rank 0 sends every rank a buffer in several capped pieces, gets it back
+        from genomicsbench_amd import shard as SH
+        payload = [{"x": np.arange(50000 + 1000 * r, dtype=np.int32), "y": np.full(3000, r, dtype=np.uint8)} for r in range(world)]
+        os.environ.setdefault("GBX_SHARD_MSG_BYTES", "65536")
+        mine, _ = SH.scatter_arrays(payload if rank == 0 else None, device=edev)
+        back = SH.gather_array(mine["x"])
+        echo_ok = rank != 0 or all(np.array_equal(b.cpu().numpy(), payload[r]["x"]) for r, b in enumerate(back))
         if rank == 0:
-            print(json.dumps({"launch_echo": True, "world": world, "rank_sum": float(t.item()),
-                              "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}), flush=True)
+            print(json.dumps({"launch_echo": True, "world": world, "rank_sum": float(t.item()), "backend": backend,
+                              "scatter_gather_ok": bool(echo_ok), "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -1281,9 +1354,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if comm == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=_pg_timeout())
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=_pg_timeout())
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "comm_dev": torch.device("cpu") if comm == "gloo" else dev,
            "comm": "rccl" if comm != "gloo" else "gloo (test aid)"}
     if comm == "gloo" and world > 1:
@@ -1322,6 +1395,7 @@ def main():
             torch.cuda.empty_cache()
             others["poa"]["config4_predicted"] = predict_shards("poa", args, ctx, 8, 2, 1, whole_ms=others["poa"]["ms_per_step"])
         if line is not None:
+            flat_config(line, others)
             # the headline line stays as measured; the five other kernels ride along in short form (what a reader of the
             # line's tail needs: value, time, roofline figures, what was checked) and in full on stderr
             if rank == 0 and not args.full_kernels:
@@ -1333,6 +1407,49 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _verified(rec):
+    """True / False from a record's check strings (gather check, CPU-baseline check, host entry), None when nothing was checked."""
+    texts = [rec.get("gather_verified"), (rec.get("cpu_baseline") or {}).get("verified")]
+    texts = [t for t in texts if t]
+    he = (rec.get("host_entry") or {}).get("same_as_device_entry")
+    if not texts and he is None:
+        return None
+    return all("DIFFER" not in t for t in texts) and he is not False
+
+
+def flat_config(line, others):
+    """The numbers that answer BASELINE's configs 2-5, as flat keys of `config` (the driver's record of the line keeps `config`,
+    the flat keys of `roofline` and `cpu_baseline` - nothing nested): SURVEY 8d's timing legs of the headline, and per
+    kernel its value, step time, roofline fractions, host-entry time, CPU figure and whether every check passed."""
+    cfg = line["config"]
+    cfg["timing_leg"] = "i: device-resident (value); ii: host_entry_* (H2D + kernels + D2H); iii: e2e_ms (text parse + ii)"
+    he = line.get("host_entry") or {}
+    cfg.update({"host_entry_ms": he.get("best_ms"), "host_entry_median_ms": he.get("median_ms"), "host_entry_gcups": he.get("value"),
+                "e2e_ms": line.get("e2e_ms"), "bsw_verified": _verified(line)})
+    rd = (line.get("e2e") or {}).get("refdriver") or {}
+    for k in ("t64_b512_s", "t16_b512_s", "t1_one_call_s"):
+        if rd.get(k) is not None:
+            cfg["refdriver_" + k] = rd[k]
+    names = {"chain": "gpairs_per_s", "phmm": "gcups", "poa": "gcups", "abea": "gcups", "fmi": "gext_per_s"}
+    for kind, rec in others.items():
+        if not rec:
+            continue
+        rf, cb, h = rec.get("roofline") or {}, rec.get("cpu_baseline") or {}, rec.get("host_entry") or {}
+        cfg.update({"%s_large_%s" % (kind, names[kind]): rec.get("value"), "%s_ms" % kind: rec.get("ms_per_step"),
+                    "%s_hbm_frac" % kind: rf.get("frac"), "%s_valu_busy" % kind: rf.get("valu_busy"),
+                    "%s_valu_frac" % kind: rf.get("valu_frac"), "%s_host_entry_ms" % kind: h.get("best_ms"),
+                    "%s_cpu_value" % kind: cb.get("value"), "%s_verified" % kind: _verified(rec)})
+        if kind == "chain":
+            cfg["chain_realistic_ms"] = (rec.get("realistic") or {}).get("ms_per_step")
+            cfg["chain_longest_job_ms"] = rec.get("longest_job_ms")
+        if kind == "poa":
+            cfg["poa_config4_predicted_speedup"] = (rec.get("config4_predicted") or {}).get("predicted_speedup")
+        if kind == "fmi":
+            cfg["fmi_l2_request_frac"] = rf.get("l2_request_frac")
+    for k in [k for k, v in cfg.items() if v is None]:
+        del cfg[k]
 
 
 _COMPACT_DROP = {"n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline", "data", "rccl_ranks", "comm", "parallelism", "inputs", "mode",

@@ -56,6 +56,20 @@ def unpack_tensor(buf, meta):
     return out
 
 
+def _msg_cap():
+    """Largest single send / receive, in bytes (default 1 GiB; GBX_SHARD_MSG_BYTES for the tests): a packed shard of fmi's
+    reads or poa's windows runs to 1.5 GB, and one message of that size is the first thing a transport's internal 32-bit
+    counts or staging buffers would trip over - larger buffers travel as several pieces of one grouped launch."""
+    import os
+    return max(256, int(os.environ.get("GBX_SHARD_MSG_BYTES", str(1 << 30))))
+
+
+def _pieces(buf):
+    """A contiguous 1-D uint8 tensor as views of at most _msg_cap() bytes (sender and receiver cut alike)."""
+    cap, n = _msg_cap(), int(buf.numel())
+    return [buf[a:min(n, a + cap)] for a in range(0, n, cap)] or [buf]
+
+
 def scatter_arrays(per_rank, device="cpu", root=0):
     """root passes a list (one dict name -> numpy array per rank); every rank returns its own dict of torch tensors.
 
@@ -70,11 +84,11 @@ def scatter_arrays(per_rank, device="cpu", root=0):
     meta, nbytes = box[0][rank]
     if rank == root:
         bufs = [torch.from_numpy(b).to(device) for b, _ in packed]
-        ops = [dist.P2POp(dist.isend, bufs[r], r) for r in range(world) if r != root]
+        ops = [dist.P2POp(dist.isend, piece, r) for r in range(world) if r != root for piece in _pieces(bufs[r])]
         mine = bufs[root]
     else:
         mine = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        ops = [dist.P2POp(dist.irecv, mine, root)]
+        ops = [dist.P2POp(dist.irecv, piece, root) for piece in _pieces(mine)]
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()
@@ -89,9 +103,11 @@ def gather_array(local, root=0):
     shapes = [None] * world
     dist.all_gather_object(shapes, (tuple(local.shape), str(local.dtype)))
     local = local.contiguous()
+    as_bytes = lambda t: t.reshape(-1).view(torch.uint8) if t.numel() else t.reshape(-1)
     if rank != root:
-        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root)]):
-            q.wait()
+        if local.numel():
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, piece, root) for piece in _pieces(as_bytes(local))]):
+                q.wait()
         return None
     out, ops = [], []
     for r in range(world):
@@ -100,7 +116,8 @@ def gather_array(local, root=0):
         else:
             shape, dt = shapes[r]
             t = torch.empty(shape, dtype=getattr(torch, dt.split(".")[-1]), device=local.device)
-            ops.append(dist.P2POp(dist.irecv, t, r))
+            if t.numel():
+                ops += [dist.P2POp(dist.irecv, piece, r) for piece in _pieces(as_bytes(t))]
             out.append(t)
     if ops:
         for q in dist.batch_isend_irecv(ops):

@@ -49,6 +49,15 @@ def test_self_launch_two_ranks_relays_rank0_line():
     assert len(lines) == 1, r.stdout                     # rank 1's stdout is not relayed
     line = json.loads(lines[0])
     assert line["launch_echo"] and line["world"] == 2 and line["rank_sum"] == 1.0
+    # the echo also runs the scatter / gather of genomicsbench_amd/shard.py in capped pieces, over RCCL when both ranks have a
+    # device of their own (backend "nccl": the first contact of the judged path), over gloo here
+    assert line["scatter_gather_ok"] is True and line["backend"] in ("gloo", "nccl")
+
+
+def test_rank_stderr_reaches_the_parent_with_its_rank():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-echo", "--launch-echo-fail", "1"],
+                       capture_output=True, text=True, env=dict(_env(), GBX_ECHO_NOISE="1"), timeout=300)
+    assert "[rank 1] launch-echo: rank 1 was told to fail" in r.stderr, r.stderr[-1500:]
 
 
 def test_failing_rank_fails_the_launch():

@@ -273,3 +273,29 @@ def test_scatter_compute_gather_world2(tmp_path, kernel, total):
     mp.spawn(_worker, args=(2, port, str(tmp_path), kernel), nprocs=2, join=True)
     ok = np.load(str(tmp_path / "ok.npy"))
     assert ok[0] == 1 and ok[1] == 2 and 0 < ok[2] < total
+
+
+@pytest.mark.parametrize("kernel,total", [("bsw", 3000), ("poa", 10)])
+def test_scatter_gather_in_capped_pieces_world2(tmp_path, kernel, total, monkeypatch):
+    """A packed shard larger than the per-message cap (default 1 GiB: fmi's and poa's 'large' shards run to 1.5 GB) travels
+    as several pieces of one grouped send / receive, cut alike on both sides; here the cap is 4 KiB, so every shard and
+    every gathered result is tens of pieces."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("GBX_SHARD_MSG_BYTES", "4096")
+    port = 29500 + (os.getpid() % 2000) + {"bsw": 10, "poa": 11}[kernel]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), kernel), nprocs=2, join=True)
+    ok = np.load(str(tmp_path / "ok.npy"))
+    assert ok[0] == 1 and ok[1] == 2 and 0 < ok[2] < total
+
+
+def test_message_pieces_cover_the_buffer(monkeypatch):
+    import torch
+    monkeypatch.setenv("GBX_SHARD_MSG_BYTES", "1000")
+    for n in (0, 1, 999, 1000, 1001, 5000):
+        buf = torch.arange(n, dtype=torch.int64).to(torch.uint8)
+        ps = S._pieces(buf)
+        assert sum(int(p.numel()) for p in ps) == n and all(int(p.numel()) <= 1000 for p in ps)
+        if n:
+            assert torch.equal(torch.cat(ps), buf) and ps[0].data_ptr() == buf.data_ptr()      # views, not copies
+    monkeypatch.delenv("GBX_SHARD_MSG_BYTES")
+    assert S._msg_cap() == 1 << 30
