@@ -179,9 +179,9 @@ class BswWork:
         if not os.path.exists(exe):
             return {"error": "genomicsbench_amd/bin/bsw is not built"}
         cores = os.cpu_count() or 1
-        quota = _cpu_quota()
-        if quota:                                           # ingest threads beyond the container's CPU quota only oversubscribe it
-            cores = max(1, min(cores, int(-(-quota // 1))))
+        # (ingest threads capped at the container's CPU quota were measured slower on the pool's boxes - 16-core quota, 256 hardware
+        # threads: 66.6 ms end to end with -t 16 against 50.9 with -t 64, profiles/r06e_bench.json: a quota is CPU time per period,
+        # and a short burst on many cores finishes inside it - so the cap stays at 64; `e2e_flow` says which flow won)
         d = tempfile.mkdtemp(prefix="gbx_bsw_e2e_")
         path = os.path.join(d, "pairs.txt")
         try:
@@ -197,6 +197,20 @@ class BswWork:
                     if best is None or j["e2e_seconds"] < best["e2e_seconds"]:
                         best = j
                 recs[name] = best
+            # the same driver with its binary input cache (--cache: the converted arrays mapped instead of the text parsed again);
+            # the first run writes it, the timed ones map it
+            cpath = os.path.join(d, "pairs.gbxcache")
+            cached = None
+            for k in range(3):
+                r = subprocess.run([exe, "-pairs", path, "-t", str(min(cores, 64)), "-b", str(self.batch.n), "--cache", cpath], capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    cached = None
+                    break
+                j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                if k and "mapped from the cache" in r.stdout and (cached is None or j["e2e_seconds"] < cached["e2e_seconds"]):
+                    cached = j
+            if os.path.exists(cpath):
+                os.remove(cpath)
             refdrv = self.refdriver(path)
         finally:
             try:
@@ -208,7 +222,8 @@ class BswWork:
         # (measured, profiles/r05k_bsw_e2e.txt: on the pool's boxes - 16 cores of CPU quota - the overlapped flow is the slower
         # one: every slice's call pays for fresh device buffers and shares the cores with the conversion; both are reported)
         return {"e2e_ms": min(o["e2e_seconds"], q["e2e_seconds"]) * 1e3, "e2e_flow": "overlapped" if o["e2e_seconds"] < q["e2e_seconds"] else "parse_then_call",
-                "refdriver": refdrv, "e2e_ms_overlapped": o["e2e_seconds"] * 1e3,
+                "refdriver": refdrv, "e2e_ms_cached_input": cached["e2e_seconds"] * 1e3 if cached else None,
+                "cached_ingest_ms": cached["ingest_seconds"] * 1e3 if cached else None, "e2e_ms_overlapped": o["e2e_seconds"] * 1e3,
                 "e2e_ms_parse_then_call": q["e2e_seconds"] * 1e3, "ingest_ms": q["ingest_seconds"] * 1e3,
                 "call_ms_in_driver": q["seconds"] * 1e3, "ingest_threads": o["ingest_threads"], "input_file_mb": round(size / 1e6, 1),
                 "what": "genomicsbench_amd/bin/bsw -pairs <file> -t %d: text conversion + H2D + kernels + D2H, file already in memory"
@@ -1427,7 +1442,7 @@ def flat_config(line, others):
     cfg["timing_leg"] = "i: device-resident (value); ii: host_entry_* (H2D + kernels + D2H); iii: e2e_ms (text parse + ii)"
     he = line.get("host_entry") or {}
     cfg.update({"host_entry_ms": he.get("best_ms"), "host_entry_median_ms": he.get("median_ms"), "host_entry_gcups": he.get("value"),
-                "e2e_ms": line.get("e2e_ms"), "bsw_verified": _verified(line)})
+                "e2e_ms": line.get("e2e_ms"), "e2e_ms_cached_input": (line.get("e2e") or {}).get("e2e_ms_cached_input"), "bsw_verified": _verified(line)})
     rd = (line.get("e2e") or {}).get("refdriver") or {}
     for k in ("t64_b512_s", "t16_b512_s", "t1_one_call_s"):
         if rd.get(k) is not None:

@@ -103,34 +103,16 @@ int gbx_poa_consensus_device(const gbx_poa_params *p, const gbx_poa_plan *plan, 
                       d_status, cons_stride, d_work, work_bytes, (hipStream_t)stream);
 }
 
-// One device (the calling thread's current one).  win_base / seq_base = indices of window 0 / sequence 0 in the caller's job
-// (error texts only).
-static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
-                        int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
-                        const char *arena, int64_t arena_bytes,
-                        char *cons, int32_t *cons_len, int64_t cons_stride, int64_t win_base = 0, int64_t seq_base = 0)
+// The int16 paths (poa_launch: window kernel, team kernel, long-window launch) over the windows of one validated job on the
+// calling thread's device; status[w] = GBX_POA_ST_* bits of window w afterwards (0: its consensus is in place).  Windows whose
+// graph outgrew the plan's node capacity have been run again with the largest capacity int16 cells admit; what still carries
+// GBX_POA_ST_NODES then belongs to the wide path (poa_host_wide).
+static int poa_host_narrow(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                           int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                           const char *arena, int64_t arena_bytes,
+                           char *cons, int32_t *cons_len, int64_t cons_stride, std::vector<int32_t> &status)
 {
-    RoctxRange range_("gbx_poa_consensus_host");
-    if (!p || n_windows < 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0) {
-        set_error("gbx_poa_consensus_host: bad argument");
-        return GBX_ERR_ARG;
-    }
-    if (n_windows == 0) return GBX_OK;
-    if (!win_first_seq || !seq_off || !seq_len || !arena || !cons || !cons_len) {
-        set_error("gbx_poa_consensus_host: null pointer");
-        return GBX_ERR_ARG;
-    }
-    if (win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs) {
-        set_error("gbx_poa_consensus_host: win_first_seq must span [0, n_seqs]");
-        return GBX_ERR_ARG;
-    }
-    for (int64_t s = 0; s < n_seqs; ++s)
-        if (seq_len[s] < 0 || seq_off[s] < 0 || seq_off[s] + seq_len[s] > arena_bytes) {
-            set_error("gbx_poa_consensus_host: sequence %lld lies outside the arena", (long long)(seq_base + s));
-            return GBX_ERR_ARG;
-        }
-    int rc = require_device();
-    if (rc) return rc;
+    int rc;
     gbx_poa_plan plan;
     if ((rc = gbx_poa_plan_host(n_windows, win_first_seq, seq_len, &plan))) return rc;
     const size_t wb = gbx_poa_workspace_bytes(&plan);
@@ -146,7 +128,7 @@ static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_
         (rc = dst.alloc(n_windows * 4)) || (rc = dw.alloc(wb)))
         return rc;
     mark("allocated");
-    std::vector<int32_t> status(n_windows);
+    status.assign((size_t)n_windows, 0);
     {
         HostPipe pipe(lane.l, (size_t)arena_bytes + (size_t)n_seqs * 12 + (size_t)n_windows * 8, false);
         if ((rc = pipe.prepare(1))) return rc;
@@ -250,9 +232,190 @@ static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_
             mark("oversized windows redone");
         }
     }
+    return GBX_OK;
+}
+
+// The wide path (poa_launch_wide: int32 cells) over the windows `list` of a validated job: windows whose scores may leave the
+// int16 range (long reads) and windows whose graph outgrew every capacity int16 admits - where spoa switches to 32-bit lanes.
+// First with the plan's usual capacity (six times the longest read), then, for a graph that outgrew that too, with a node
+// per base, which cannot overflow.  Slots: what the device has room for, at most one per window.
+static int poa_host_wide(const gbx_poa_params *p, const std::vector<int64_t> &list, const int64_t *win_first_seq,
+                         const int64_t *seq_off, const int32_t *seq_len, const char *arena, int64_t arena_bytes,
+                         char *cons, int32_t *cons_len, int64_t cons_stride, std::vector<int32_t> &status)
+{
+    if (list.empty()) return GBX_OK;
+    int rc;
+    HostLane lane;
+    if ((rc = lane.acquire())) return rc;
+    Lane *L = lane.l;
+    hipStream_t st = L->compute;
+    DevBuf dar(L);
+    if ((rc = dar.alloc((size_t)arena_bytes + 64))) return rc;
+    GBX_HIP(hipMemcpyAsync(dar.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice, st));
+    std::vector<int64_t> todo = list;
+    for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+        const int64_t nr = (int64_t)todo.size();
+        std::vector<int64_t> wf((size_t)nr + 1, 0), off;
+        std::vector<int32_t> len;
+        int64_t bmax = 1;
+        int lmax = 1, smax = 1;
+        for (int64_t k = 0; k < nr; ++k) {
+            const int64_t a = win_first_seq[todo[(size_t)k]], b = win_first_seq[todo[(size_t)k] + 1];
+            int64_t bases = 0;
+            for (int64_t sidx = a; sidx < b; ++sidx) {
+                off.push_back(seq_off[sidx]); len.push_back(seq_len[sidx]);
+                bases += seq_len[sidx];
+                if (seq_len[sidx] > lmax) lmax = seq_len[sidx];
+            }
+            if (b - a > smax) smax = (int)(b - a);
+            if (bases > bmax) bmax = bases;
+            wf[(size_t)k + 1] = (int64_t)off.size();
+        }
+        int64_t cap = pass == 0 ? (int64_t)6 * lmax + 256 : bmax + 8;
+        if (bmax + 8 < cap) cap = bmax + 8;
+        if (cap > 0x7fffff00LL) { set_error("gbx_poa_consensus_host: a window of %lld bases is beyond the device path", (long long)bmax); return GBX_ERR_UNSUPPORTED; }
+        const int deg = smax < 4 ? 4 : ((smax + 3) & ~3);
+        const int64_t ns = (int64_t)off.size();
+        const size_t slot = poa_wide_slot_bytes((int)cap, deg, lmax);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)64 << 30; }
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int64_t slots = (int64_t)((double)free_b * 0.8 / (double)slot);
+        if (slots > nr) slots = nr;
+        if (slots > (int64_t)cus * 4) slots = (int64_t)cus * 4;
+        if (const char *e = getenv("GBX_POA_WIDE_SLOTS")) { const long long v = atoll(e); if (v >= 1 && v < slots) slots = v; }      /* test aid */
+        if (slots < 1) {
+            set_error("gbx_poa_consensus_host: a window of %lld nodes x %d columns needs %.1f GB of 32-bit DP planes, the device has %.1f GB free",
+                      (long long)cap, lmax, (double)slot / 1e9, (double)free_b / 1e9);
+            return GBX_ERR_NOMEM;
+        }
+        DevBuf dwf(L), doff(L), dlen(L), dcons(L), dcl(L), dst(L), dw(L);
+        size_t wb = 0;
+        for (;;) {                                          // fewer slots when the allocation fails
+            wb = poa_wide_workspace_bytes((int)cap, deg, lmax, (int)slots);
+            if (dw.alloc(wb) == GBX_OK) break;
+            if (slots == 1) { set_error("gbx_poa_consensus_host: no device memory for the 32-bit DP planes of a window (%.1f GB)", (double)slot / 1e9); return GBX_ERR_NOMEM; }
+            slots = (slots + 1) / 2;
+        }
+        if ((rc = dwf.alloc((size_t)(nr + 1) * 8)) || (rc = doff.alloc((size_t)ns * 8)) || (rc = dlen.alloc((size_t)ns * 4)) ||
+            (rc = dcons.alloc((size_t)nr * (size_t)cons_stride)) || (rc = dcl.alloc((size_t)nr * 4)) || (rc = dst.alloc((size_t)nr * 4)))
+            return rc;
+        GBX_HIP(hipMemcpyAsync(dwf.p, wf.data(), (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, st));
+        GBX_HIP(hipMemcpyAsync(doff.p, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st));
+        GBX_HIP(hipMemcpyAsync(dlen.p, len.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+        if ((rc = poa_launch_wide(p, nr, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(), dcons.as<uint8_t>(),
+                                  dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, (int)cap, deg, lmax, (int)slots, dw.p, wb, st)))
+            return rc;
+        std::vector<char> c2((size_t)nr * (size_t)cons_stride);
+        std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);
+        GBX_HIP(hipMemcpyAsync(c2.data(), dcons.p, c2.size(), hipMemcpyDeviceToHost, st));
+        GBX_HIP(hipMemcpyAsync(l2.data(), dcl.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        GBX_HIP(hipMemcpyAsync(s2.data(), dst.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+        GBX_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> again;
+        for (int64_t k = 0; k < nr; ++k) {
+            const int64_t w = todo[(size_t)k];
+            status[(size_t)w] = s2[(size_t)k];
+            if (s2[(size_t)k] & GBX_POA_ST_NODES) { again.push_back(w); continue; }
+            if (s2[(size_t)k]) continue;
+            cons_len[w] = l2[(size_t)k];
+            memcpy(cons + w * cons_stride, c2.data() + (size_t)k * (size_t)cons_stride, (size_t)cons_stride);
+        }
+        todo.swap(again);
+    }
+    return GBX_OK;
+}
+
+// One device (the calling thread's current one).  win_base / seq_base = indices of window 0 / sequence 0 in the caller's job
+// (error texts only).
+static int poa_host_one(const gbx_poa_params *p, int64_t n_windows, const int64_t *win_first_seq,
+                        int64_t n_seqs, const int64_t *seq_off, const int32_t *seq_len,
+                        const char *arena, int64_t arena_bytes,
+                        char *cons, int32_t *cons_len, int64_t cons_stride, int64_t win_base = 0, int64_t seq_base = 0)
+{
+    RoctxRange range_("gbx_poa_consensus_host");
+    if (!p || n_windows < 0 || n_seqs < 0 || arena_bytes < 0 || cons_stride <= 0) {
+        set_error("gbx_poa_consensus_host: bad argument");
+        return GBX_ERR_ARG;
+    }
+    if (n_windows == 0) return GBX_OK;
+    if (!win_first_seq || !seq_off || !seq_len || !arena || !cons || !cons_len) {
+        set_error("gbx_poa_consensus_host: null pointer");
+        return GBX_ERR_ARG;
+    }
+    if (win_first_seq[0] != 0 || win_first_seq[n_windows] != n_seqs) {
+        set_error("gbx_poa_consensus_host: win_first_seq must span [0, n_seqs]");
+        return GBX_ERR_ARG;
+    }
+    for (int64_t s = 0; s < n_seqs; ++s)
+        if (seq_len[s] < 0 || seq_off[s] < 0 || seq_off[s] + seq_len[s] > arena_bytes) {
+            set_error("gbx_poa_consensus_host: sequence %lld lies outside the arena", (long long)(seq_base + s));
+            return GBX_ERR_ARG;
+        }
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (win_first_seq[w + 1] < win_first_seq[w]) { set_error("gbx_poa_consensus_host: win_first_seq not monotone at window %lld", (long long)(win_base + w)); return GBX_ERR_ARG; }
+    int rc = require_device();
+    if (rc) return rc;
+    // Which windows int16 cells can hold: the plan of the job (longest sequence, node capacity) must pass poa_scores_fit_int16;
+    // while it does not, the windows with the longest sequences leave for the wide path (int32 cells), as spoa's engine
+    // switches to 32-bit lanes for them.  GBX_POA_FORCE_WIDE=1 (a test aid) sends everything there.
+    std::vector<int> wl((size_t)n_windows, 0);
+    std::vector<int64_t> wbases((size_t)n_windows, 0);
+    for (int64_t w = 0; w < n_windows; ++w)
+        for (int64_t sidx = win_first_seq[w]; sidx < win_first_seq[w + 1]; ++sidx) {
+            wl[(size_t)w] = seq_len[sidx] > wl[(size_t)w] ? seq_len[sidx] : wl[(size_t)w];
+            wbases[(size_t)w] += seq_len[sidx];
+        }
+    std::vector<char> is_wide((size_t)n_windows, 0);
+    int64_t n_wide = 0;
+    if (getenv("GBX_POA_FORCE_WIDE") && atoi(getenv("GBX_POA_FORCE_WIDE")) != 0) { is_wide.assign((size_t)n_windows, 1); n_wide = n_windows; }
+    while (n_wide < n_windows) {
+        int lmax = 1;
+        int64_t bmax = 1;
+        for (int64_t w = 0; w < n_windows; ++w)
+            if (!is_wide[(size_t)w]) { lmax = wl[(size_t)w] > lmax ? wl[(size_t)w] : lmax; bmax = wbases[(size_t)w] > bmax ? wbases[(size_t)w] : bmax; }
+        int64_t cap = (int64_t)6 * lmax + 256;             // (gbx_poa_plan_host's rule)
+        if (bmax + 8 < cap) cap = bmax + 8;
+        if (poa_scores_fit_int16(p, cap, lmax)) break;
+        for (int64_t w = 0; w < n_windows; ++w)
+            if (!is_wide[(size_t)w] && wl[(size_t)w] == lmax) { is_wide[(size_t)w] = 1; ++n_wide; }
+    }
+    std::vector<int32_t> status((size_t)n_windows, 0);
+    std::vector<int64_t> wide;
+    if (n_wide == 0) {
+        if ((rc = poa_host_narrow(p, n_windows, win_first_seq, n_seqs, seq_off, seq_len, arena, arena_bytes, cons, cons_len, cons_stride, status))) return rc;
+    } else {
+        // the windows that stay: a job of their own over the same arena, results handed back to the caller's rows
+        std::vector<int64_t> keep, wf(1, 0), off;
+        std::vector<int32_t> len;
+        for (int64_t w = 0; w < n_windows; ++w) {
+            if (is_wide[(size_t)w]) { wide.push_back(w); continue; }
+            keep.push_back(w);
+            for (int64_t sidx = win_first_seq[w]; sidx < win_first_seq[w + 1]; ++sidx) { off.push_back(seq_off[sidx]); len.push_back(seq_len[sidx]); }
+            wf.push_back((int64_t)off.size());
+        }
+        if (!keep.empty()) {
+            const int64_t nk = (int64_t)keep.size();
+            std::vector<char> c2((size_t)nk * (size_t)cons_stride);
+            std::vector<int32_t> l2((size_t)nk, 0), s2;
+            if (off.empty()) { off.push_back(0); len.push_back(0); }      // (arrays must not be null)
+            if ((rc = poa_host_narrow(p, nk, wf.data(), wf.back(), off.data(), len.data(), arena, arena_bytes, c2.data(), l2.data(), cons_stride, s2))) return rc;
+            for (int64_t k = 0; k < nk; ++k) {
+                status[(size_t)keep[(size_t)k]] = s2[(size_t)k];
+                if (s2[(size_t)k]) continue;
+                cons_len[keep[(size_t)k]] = l2[(size_t)k];
+                memcpy(cons + keep[(size_t)k] * cons_stride, c2.data() + (size_t)k * (size_t)cons_stride, (size_t)cons_stride);
+            }
+        }
+    }
+    // a graph that outgrew every node capacity int16 scores admit: the wide path has room (spoa has no such limit)
+    for (int64_t w = 0; w < n_windows; ++w)
+        if (!is_wide[(size_t)w] && (status[(size_t)w] & GBX_POA_ST_NODES)) wide.push_back(w);
+    if ((rc = poa_host_wide(p, wide, win_first_seq, seq_off, seq_len, arena, arena_bytes, cons, cons_len, cons_stride, status))) return rc;
     int64_t n_bad = 0, first_bad = -1;
     for (int64_t w = 0; w < n_windows; ++w)
-        if (status[w]) { if (first_bad < 0) first_bad = w; ++n_bad; }
+        if (status[(size_t)w]) { if (first_bad < 0) first_bad = w; ++n_bad; }
     if (n_bad) {
         set_error("gbx_poa_consensus_host: %lld window(s) exceeded a device capacity, first is window %lld (status bits 0x%x, "
                   "see GBX_POA_ST_*); the others' results are valid", (long long)n_bad, (long long)(win_base + first_bad), status[(size_t)first_bad]);

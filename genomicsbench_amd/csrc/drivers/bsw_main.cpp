@@ -10,6 +10,8 @@
 // --overlap S (round 5, SURVEY 8f rank 1 "ingest overlapped with compute"): the pairs are parsed in S slices and slice k is
 // on its way through gbx_bsw_extend_host (a caller thread and host lane of its own: upload, kernels, download) while slice
 // k+1 is still being converted; "e2e" = first byte parsed to last result in the caller's array (SURVEY 8d leg iii).
+// --cache FILE (round 6, SURVEY 8f rank 1 "binary cache"): the converted arrays are written to FILE after the first run and
+// mapped by later runs of the same input (size and modification time are checked) instead of converting the text again.
 #include "driver_common.h"
 #include <thread>
 #include <algorithm>
@@ -22,7 +24,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     int a = 1, b = 4, ambig = -1, o = 6, e = 1, threads = 1, batch = 0, repeat = 1, overlap = 0;
-    const char *pairs = nullptr, *dump = nullptr;
+    const char *pairs = nullptr, *dump = nullptr, *cache = nullptr;
     bool parse_only = false;
     for (int i = 1; i + 1 < argc; i += 2) {
         const char *k = argv[i], *v = argv[i + 1];
@@ -38,12 +40,18 @@ int main(int argc, char **argv)
         else if (!strcmp(k, "--repeat")) repeat = atoi(v) > 0 ? atoi(v) : 1;
         else if (!strcmp(k, "--parse-only")) parse_only = atoi(v) != 0;
         else if (!strcmp(k, "--overlap")) overlap = atoi(v);
+        else if (!strcmp(k, "--cache")) cache = v;
     }
     (void)batch;
     if (threads < 1) threads = 1;
     if (!pairs) { fprintf(stderr, "ERROR! pairFileName not specified.\n"); return EXIT_FAILURE; }
+    // --cache FILE: the converted arrays of this input, written after the first conversion and mapped by later runs (driver_common.h:
+    // InputCache; sections: idr, idq, len1, len2, h0, ref, qer).  A hit skips the text altogether: the ingest is a mmap, and the
+    // host entry's upload workers read the page-cache pages directly.
+    InputCache icache;
+    const bool cache_hit = cache && !overlap && icache.open(cache, pairs, 0x777362 /* "bsw" */, 7);
     std::vector<char> text;
-    if (!slurp(pairs, text)) { fprintf(stderr, "Could not open file: %s\n", pairs); return EXIT_FAILURE; }
+    if (!cache_hit && !slurp(pairs, text)) { fprintf(stderr, "Could not open file: %s\n", pairs); return EXIT_FAILURE; }
 
     if (overlap > 1 && !parse_only) {
         // device and host-lane set-up is not part of the timed region (the reference constructs its aligner objects before its
@@ -68,21 +76,36 @@ int main(int argc, char **argv)
     const double t_read0 = now_s();
     // split lines; numPairs = lines / 3 (main_banded.cpp:235)
     RawVec<const char *> line; RawVec<int> llen;
-    split_lines(text.data(), text.size() - 1, threads, line, llen);
-    const int64_t n = (int64_t)line.size() / 3;
+    if (!cache_hit) split_lines(text.data(), text.size() - 1, threads, line, llen);
+    const int64_t n = cache_hit ? (int64_t)(icache.sec[0].second / 8) : (int64_t)line.size() / 3;
     printf("Number of input pairs: %ld\n", (long)n);
     // (arrays first touched by the threads that fill them: see RawVec)
-    RawVec<int64_t> idr((size_t)n), idq((size_t)n);
-    RawVec<int32_t> len1((size_t)n), len2((size_t)n), h0((size_t)n);
+    RawVec<int64_t> idr, idq;
+    RawVec<int32_t> len1, len2, h0;
+    RawVec<uint8_t> ref, qer;
     int64_t rb = 0, qb = 0;
-    for (int64_t k = 0; k < n; ++k) {                           // offsets: a serial prefix over two ints per pair
+    if (cache_hit) {
+        idr.adopt((int64_t *)icache.sec[0].first, (size_t)n); idq.adopt((int64_t *)icache.sec[1].first, (size_t)n);
+        len1.adopt((int32_t *)icache.sec[2].first, (size_t)n); len2.adopt((int32_t *)icache.sec[3].first, (size_t)n);
+        h0.adopt((int32_t *)icache.sec[4].first, (size_t)n);
+        ref.adopt((uint8_t *)icache.sec[5].first, icache.sec[5].second); qer.adopt((uint8_t *)icache.sec[6].first, icache.sec[6].second);
+        rb = (int64_t)icache.sec[5].second - 8; qb = (int64_t)icache.sec[6].second - 8;
+        if (icache.sec[1].second != (size_t)n * 8 || icache.sec[2].second != (size_t)n * 4 || icache.sec[3].second != (size_t)n * 4 ||
+            icache.sec[4].second != (size_t)n * 4 || rb < 0 || qb < 0) { fprintf(stderr, "%s: malformed cache\n", cache); return EXIT_FAILURE; }
+        printf("Input arrays mapped from the cache %s\n", cache);
+    } else {
+        idr.resize((size_t)n); idq.resize((size_t)n); len1.resize((size_t)n); len2.resize((size_t)n); h0.resize((size_t)n);
+    }
+    for (int64_t k = 0; k < n && !cache_hit; ++k) {             // offsets: a serial prefix over two ints per pair
         len1[k] = llen[3 * k + 1]; len2[k] = llen[3 * k + 2];
         if (len1[k] <= 0 || len2[k] <= 0) { fprintf(stderr, "pair %ld has an empty sequence\n", (long)k); return EXIT_FAILURE; }
         idr[k] = rb; idq[k] = qb;
         rb += (len1[k] + 3) & ~3; qb += (len2[k] + 3) & ~3;
     }
-    RawVec<uint8_t> ref((size_t)rb + 8), qer((size_t)qb + 8);
-    memset(ref.data() + rb, 0, 8); memset(qer.data() + qb, 0, 8);
+    if (!cache_hit) {
+        ref.resize((size_t)rb + 8); qer.resize((size_t)qb + 8);
+        memset(ref.data() + rb, 0, 8); memset(qer.data() + qb, 0, 8);
+    }
     gbx_bsw_params P;
     gbx_bsw_default_params(&P);
     P.o_del = P.o_ins = o; P.e_del = P.e_ins = e;
@@ -144,6 +167,10 @@ int main(int argc, char **argv)
         t_gpu_span = now_s() - t_first;
         for (int s = 0; s < overlap; ++s)
             if (rcs[(size_t)s]) { fprintf(stderr, "gbx_bsw_extend_host failed (%d) on slice %d: %s\n", rcs[(size_t)s], s, errs[(size_t)s].c_str()); return EXIT_FAILURE; }
+    } else if (cache_hit) {
+        overlap = 0;
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t k = 0; k < n; ++k) out[k] = gbx_bsw_result{-1, -1, -1, -1, -1, -1};      // (the result array's pages)
     } else {
         overlap = 0;
         convert(0, n);
@@ -155,6 +182,9 @@ int main(int argc, char **argv)
         for (int64_t k = 0; k < n; ++k) { h = fnv1a(&ref[idr[k]], (size_t)len1[k], h); h = fnv1a(&qer[idq[k]], (size_t)len2[k], h); }
         printf("{\"benchmark\":\"bsw\",\"pairs\":%ld,\"ingest_threads\":%d,\"ingest_seconds\":%.4f,\"ingest_mb_per_s\":%.1f,\"checksum\":\"%016llx\"}\n",
                (long)n, threads, t_read, text.size() / 1e6 / t_read, (unsigned long long)h);
+        if (cache && !cache_hit && !InputCache::write(cache, pairs, 0x777362, {{idr.data(), (size_t)n * 8}, {idq.data(), (size_t)n * 8}, {len1.data(), (size_t)n * 4},
+                {len2.data(), (size_t)n * 4}, {h0.data(), (size_t)n * 4}, {ref.data(), (size_t)rb + 8}, {qer.data(), (size_t)qb + 8}}))
+            fprintf(stderr, "warning: could not write the cache %s\n", cache);
         return 0;
     }
 
@@ -187,6 +217,10 @@ int main(int argc, char **argv)
     printf("SW cells(T)  = %.0f\nSW GCUPS  = %lf\n", cells, cells / dt / 1e9);
     printf("{\"benchmark\":\"bsw\",\"pairs\":%ld,\"cells\":%.0f,\"seconds\":%.6f,\"gcups\":%.3f,\"ingest_threads\":%d,\"ingest_seconds\":%.6f,\"overlap_slices\":%d,\"e2e_seconds\":%.6f}\n",
            (long)n, cells, dt, cells / dt / 1e9, threads, t_read, overlap, t_e2e);
+    if (cache && !cache_hit && !overlap &&
+        !InputCache::write(cache, pairs, 0x777362, {{idr.data(), (size_t)n * 8}, {idq.data(), (size_t)n * 8}, {len1.data(), (size_t)n * 4}, {len2.data(), (size_t)n * 4},
+                                                   {h0.data(), (size_t)n * 4}, {ref.data(), (size_t)rb + 8}, {qer.data(), (size_t)qb + 8}}))
+        fprintf(stderr, "warning: could not write the cache %s\n", cache);
     if (dump) {
         FILE *f = fopen(dump, "w");
         if (!f) { fprintf(stderr, "cannot write %s\n", dump); return EXIT_FAILURE; }

@@ -39,6 +39,83 @@ static inline bool slurp(const char *path, std::vector<char> &buf)
     return true;
 }
 
+// ---- binary input cache ("optional"): the converted arrays of an input file, written once beside it and
+// mapped read-only by later runs instead of converting the text again.  One file: a 64-byte header - magic, the source
+// file's size and modification time (a cache of another or an edited input is ignored), the section count - then the
+// sections, each 4 KiB-aligned so that a mapped section is page-aligned: {bytes, payload}.  The caller names the sections'
+// meaning by their order.  Nothing of the reference corresponds to this; its drivers convert their text on every run.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+struct InputCache {
+    static constexpr uint64_t MAGIC = 0x3143584247ull;        // "GBXC1"
+    struct Header { uint64_t magic, kind, src_size, src_mtime_ns, n_sections, pad[3]; };
+    char *base = nullptr; size_t bytes = 0;
+    std::vector<std::pair<char *, size_t>> sec;
+    static bool source_stamp(const char *src, uint64_t *size, uint64_t *mtime_ns)
+    {
+        struct stat st;
+        if (stat(src, &st) != 0) return false;
+        *size = (uint64_t)st.st_size;
+        *mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+        return true;
+    }
+    // maps `path` if it is a cache of `src` as it is now and of this kind with this many sections
+    bool open(const char *path, const char *src, uint64_t kind, size_t want_sections)
+    {
+        uint64_t ssz = 0, smt = 0;
+        if (!source_stamp(src, &ssz, &smt)) return false;
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(Header)) { ::close(fd); return false; }
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        base = (char *)m; bytes = (size_t)st.st_size;
+        const Header *h = (const Header *)base;
+        bool ok = h->magic == MAGIC && h->kind == kind && h->src_size == ssz && h->src_mtime_ns == smt && h->n_sections == want_sections;
+        size_t at = 4096;
+        for (size_t k = 0; ok && k < want_sections; ++k) {
+            if (at + 8 > bytes) { ok = false; break; }
+            const uint64_t len = *(const uint64_t *)(base + at);
+            if (at + 4096 + len > bytes) { ok = false; break; }
+            sec.emplace_back(base + at + 4096, (size_t)len);
+            at += 4096 + ((len + 4095) & ~(uint64_t)4095);
+        }
+        if (!ok) { close(); return false; }
+        (void)madvise(base, bytes, MADV_WILLNEED);
+        return true;
+    }
+    void close() { if (base) munmap(base, bytes); base = nullptr; bytes = 0; sec.clear(); }
+    ~InputCache() { close(); }
+    // writes the cache (to a temporary name, renamed into place: a reader never sees half a file)
+    static bool write(const char *path, const char *src, uint64_t kind, const std::vector<std::pair<const void *, size_t>> &sections)
+    {
+        Header h;
+        memset(&h, 0, sizeof h);
+        h.magic = MAGIC; h.kind = kind; h.n_sections = sections.size();
+        if (!source_stamp(src, &h.src_size, &h.src_mtime_ns)) return false;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return false;
+        std::vector<char> zero(4096, 0);
+        bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(zero.data(), 4096 - sizeof h, 1, f) == 1;
+        for (const auto &s : sections) {
+            const uint64_t len = s.second;
+            ok = ok && fwrite(&len, 8, 1, f) == 1 && fwrite(zero.data(), 4096 - 8, 1, f) == 1;
+            ok = ok && (len == 0 || fwrite(s.first, 1, (size_t)len, f) == (size_t)len);
+            const size_t pad = (size_t)(((len + 4095) & ~(uint64_t)4095) - len);
+            ok = ok && (pad == 0 || fwrite(zero.data(), 1, pad, f) == pad);
+        }
+        ok = fclose(f) == 0 && ok;
+        if (ok) ok = rename(tmp.c_str(), path) == 0;
+        if (!ok) remove(tmp.c_str());
+        return ok;
+    }
+};
+
 // ---- parallel ingest: the input text is split and converted by `threads` OpenMP threads.
 // Chunk boundaries never cut a record: every thread finds the delimiters of its own byte range, the ranges
 // are stitched by a prefix sum, and the records are then parsed independently.
@@ -48,11 +125,13 @@ static inline bool slurp(const char *path, std::vector<char> &buf)
 // 0.4 GB of arrays of a 2 M-pair bsw job that was most of the ingest).  Trivial element types only.
 template <class T> struct RawVec {
     T *p = nullptr; size_t n = 0;
+    bool own = true;                       // false: a view of memory someone else holds (adopt(): a mapped input cache)
     RawVec() {}
     explicit RawVec(size_t k) { resize(k); }
     RawVec(const RawVec &) = delete;
-    ~RawVec() { free(p); }
-    void resize(size_t k) { free(p); p = k ? (T *)malloc(k * sizeof(T)) : nullptr; n = k; if (k && !p) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); } }
+    ~RawVec() { if (own) free(p); }
+    void resize(size_t k) { if (own) free(p); own = true; p = k ? (T *)malloc(k * sizeof(T)) : nullptr; n = k; if (k && !p) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); } }
+    void adopt(T *q, size_t k) { if (own) free(p); own = false; p = q; n = k; }
     T *data() { return p; } const T *data() const { return p; }
     size_t size() const { return n; }
     T &operator[](size_t k) { return p[k]; } const T &operator[](size_t k) const { return p[k]; }

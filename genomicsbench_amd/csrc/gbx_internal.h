@@ -188,6 +188,12 @@ size_t poa_workspace_bytes(const gbx_poa_plan *plan);
 int poa_waves_per_cu(int ncap);
 bool poa_lockstep_wanted(int64_t n_main, int64_t resident);      // the lock-step form (a slot per window) pays for this job
 bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax);
+// int32 cells (poa_wide_kernel): windows whose scores may leave the int16 range, or whose graph outgrew what int16 admits
+size_t poa_wide_slot_bytes(int ncap, int deg, int lmax);
+size_t poa_wide_workspace_bytes(int ncap, int deg, int lmax, int n_slots);
+int poa_launch_wide(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
+                    const uint8_t *d_arena, uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
+                    int ncap, int deg, int lmax, int n_slots, void *d_work, size_t work_bytes, hipStream_t s);
 int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off,
                const int32_t *d_seq_len, const uint8_t *d_arena,
                uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,

@@ -305,12 +305,21 @@ PG_HD int poa_consensus(PoaGraph &g, uint8_t *out, int cap)
 }
 
 // DP matrices of one alignment: (n_nodes+1) rows x W = len+1 columns, row-major
-struct PoaMatrices {
-    poa_cell_t *H, *F, *E, *O, *Q;
+// Cell = int16 (the device's fast paths; real scores above -30000, checked by the host plan) or int32 (the wide path: windows
+// whose scores may leave that range - long reads - as spoa falls back to 32-bit lanes); `neg` = the -infinity sentinel of each.
+template <class Cell> struct PoaMatricesT {
+    typedef Cell cell;
+    static constexpr int neg = sizeof(Cell) == 2 ? POA_NEG_INF : -(1 << 29);
+    Cell *H, *F, *E, *O, *Q;
     int Wp;                                       // row stride in cells (poa_row_stride)
 };
+typedef PoaMatricesT<poa_cell_t> PoaMatrices;
+typedef PoaMatricesT<int32_t> PoaMatricesW;
 
-struct PoaScore { int m, n, g, e, q, c; };
+// linear: spoa's LINEAR subtype (g >= e at createAlignmentEngine: one gap cost g, no gap states).  Its score matrix is the affine
+// one with e = q = c = g - the launch sets them so and the DP runs unchanged - but its backtrack takes one cell per step and
+// never walks an extension (a vertical or horizontal candidate is H + g only), which the tracebacks honour.
+struct PoaScore { int m, n, g, e, q, c, linear; };
 
 // Row descriptors of the current topological order, indexed by rank r (DP row r+1); stored in
 // g.score / g.pred, which are free until the consensus:
@@ -332,7 +341,7 @@ PG_HD void poa_rowdesc_one(PoaGraph &g, int r)
 // traceback order (the reference reverses it afterwards; poa_add_alignment reads it backwards).
 // Needs the row descriptors.  All candidate cells of a step are read up front (independent loads),
 // then the reference's priority order (diagonal, vertical F/H/O/H, horizontal E/H/Q/H) is applied.
-PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, const uint8_t *seq, int max_i, int max_j)
+template <class MT> PG_HD void poa_traceback(PoaGraph &g, const MT &M, const PoaScore &S, const uint8_t *seq, int max_i, int max_j)
 {
     g.n_path = 0;
     if (max_i == -1 && max_j == -1) return;
@@ -359,9 +368,9 @@ PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, c
                 for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
                     const int pi = p ? g.n2r[PG_IN_SRC(g, node, p)] + 1 : p0;
                     const int fv = PG_AT(M.F, pi, j), hv = PG_AT(M.H, pi, j), ov = PG_AT(M.O, pi, j);
-                    const bool c1 = Hij == fv + S.e;
+                    const bool c1 = !S.linear && Hij == fv + S.e;
                     const bool c2 = !c1 && Hij == hv + S.g;
-                    const bool c3 = !c1 && !c2 && Hij == ov + S.c;
+                    const bool c3 = !S.linear && !c1 && !c2 && Hij == ov + S.c;
                     const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
                     ext_up = ext_up || c1 || c3;
                     if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; }
@@ -370,9 +379,9 @@ PG_HD void poa_traceback(PoaGraph &g, const PoaMatrices &M, const PoaScore &S, c
         }
         if (!found && j != 0) {
             const int ev = PG_AT(M.E, i, j - 1), hv = PG_AT(M.H, i, j - 1), qv = PG_AT(M.Q, i, j - 1);
-            const bool c1 = Hij == ev + S.e;
+            const bool c1 = !S.linear && Hij == ev + S.e;
             const bool c2 = !c1 && Hij == hv + S.g;
-            const bool c3 = !c1 && !c2 && Hij == qv + S.c;
+            const bool c3 = !S.linear && !c1 && !c2 && Hij == qv + S.c;
             const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
             ext_left = c1 || c3;
             if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; }

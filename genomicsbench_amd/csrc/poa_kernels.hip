@@ -91,7 +91,7 @@ struct SlotLayout {
 
 __host__ __device__ inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-__host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, bool long_slot)
+__host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, bool long_slot, int cell_bytes = (int)sizeof(poa_cell_t))
 {
     SlotLayout L;
     int64_t o = 0;
@@ -134,7 +134,7 @@ __host__ __device__ inline SlotLayout make_layout(int ncap, int deg, int lmax, b
 #endif
     // pipelined DP (sequences up to 512 columns): the H plane + one plane of (H-F, H-O) byte pairs.  Only the slots of the
     // second launch (windows that hold a longer sequence: column-block DP) keep spoa's five int16 planes.
-    L.mat = take((int64_t)(ncap + 1) * (long_slot ? poa_cap_stride(lmax) : POA_PIPE_STRIDE) * (long_slot ? 5 : GBX_POA_PLANES) * (int64_t)sizeof(poa_cell_t) + 64);
+    L.mat = take((int64_t)(ncap + 1) * (long_slot ? poa_cap_stride(lmax) : POA_PIPE_STRIDE) * (long_slot ? 5 : GBX_POA_PLANES) * (int64_t)cell_bytes + 64);
     L.total = align_up(o, 256);
     return L;
 }
@@ -168,6 +168,30 @@ __device__ inline void store_cells(poa_cell_t *p, const int *in)
     }
 }
 
+// int32 cells (the wide path): the lane's 8 columns are two 16-byte vectors
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int CPL>
+__device__ inline void load_cells(const int32_t *p, int *out)
+{
+#pragma unroll
+    for (int k = 0; k < CPL / 4; ++k) {
+        const v4i t = *(const v4i *)(p + 4 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[4 * k + e] = t[e];
+    }
+}
+template <int CPL>
+__device__ inline void store_cells(int32_t *p, const int *in)
+{
+#pragma unroll
+    for (int k = 0; k < CPL / 4; ++k) {
+        v4i t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = in[4 * k + e];
+        *(v4i *)(p + 4 * k) = t;
+    }
+}
+
 // (the team's words in LDS: poa_dp_team below, and the column-block DP when a team runs it)
 struct PoaTeamSync {
     int prog[4];                 // last DP row (1-based) wavefront w has completed
@@ -180,11 +204,13 @@ typedef __attribute__((address_space(3))) int lds_i32;
 // NW > 1 (round 5, the long windows of a team launch): the rows go to the NW wavefronts of the workgroup in turn, a row starts when its
 // predecessor rows are complete (sy->prog, as in poa_dp_team) and is complete once its stores are acknowledged - this DP already ends
 // every row waiting for them.  n_team = the graph's size (only wavefront 0's PoaGraph knows it).
-template <int CPL, int NW = 1>
-__device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A, const uint8_t *seq, int len,
+template <int CPL, int NW = 1, class MT = PoaMatrices>
+__device__ void poa_dp(const PoaGraph &g, const MT &M, const PoaArgs &A, const uint8_t *seq, int len,
                        int &max_i, int &max_j, lds_team *sy = nullptr, int wave = 0, int n_team = 0)
 {
     static_assert(CPL == 8 || CPL == 16, "a lane owns one or two 16-byte vectors of cells");
+    typedef typename MT::cell cell_t;
+    constexpr int NEG = MT::neg;              // -infinity of the cell type (poa_graph.h)
     const int lane = threadIdx.x & 63;
     const int tid = NW > 1 ? (int)threadIdx.x : lane;
     constexpr int NT = 64 * NW;
@@ -201,9 +227,9 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
     // row 0 (sisd_alignment_engine `initialize`) and the row descriptors
     for (int j = tid; j <= len; j += NT) {
         const int e0 = j == 0 ? 0 : S.g + (j - 1) * S.e, q0 = j == 0 ? 0 : S.q + (j - 1) * S.c;
-        M.E[j + POA_COL0] = (poa_cell_t)e0; M.Q[j + POA_COL0] = (poa_cell_t)q0;
-        M.F[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF); M.O[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : POA_NEG_INF);
-        M.H[j + POA_COL0] = (poa_cell_t)(j == 0 ? 0 : max(q0, e0));
+        M.E[j + POA_COL0] = (cell_t)e0; M.Q[j + POA_COL0] = (cell_t)q0;
+        M.F[j + POA_COL0] = (cell_t)(j == 0 ? 0 : NEG); M.O[j + POA_COL0] = (cell_t)(j == 0 ? 0 : NEG);
+        M.H[j + POA_COL0] = (cell_t)(j == 0 ? 0 : max(q0, e0));
     }
     int32_t *d_pred = g.score, *d_info = g.pred;       // [rank] first predecessor row | letter, in-degree, sink
     {
@@ -226,7 +252,7 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
     };
     if (single) load_seq(0);
 
-    int best = POA_NEG_INF;
+    int best = NEG;
     max_i = -1; max_j = -1;
     const int32_t *d_pred1 = g.path_node, *d_pred2 = g.path_pos;   // 2nd / 3rd predecessor rows (free until the traceback)
     const int r0 = NW > 1 ? wave : 0;
@@ -255,7 +281,7 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
             }
             asm volatile("" ::: "memory");                       // nothing of the rows waited for is read before this point
         }
-        int po = ic == 0 ? S.q - S.c : POA_NEG_INF, pf = ic == 0 ? S.g - S.e : POA_NEG_INF;
+        int po = ic == 0 ? S.q - S.c : NEG, pf = ic == 0 ? S.g - S.e : NEG;
         {
             // column 0 of up to three predecessor rows: independent loads, one round trip
             const int64_t i0 = (int64_t)p0 * Wp + POA_COL0, i1 = (int64_t)p1 * Wp + POA_COL0, i2 = (int64_t)p2 * Wp + POA_COL0;
@@ -270,8 +296,8 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
         }
         const int O0 = po + S.c, F0 = pf + S.e, H0 = max(O0, F0);
         if (lane == 0) {
-            M.O[ro] = (poa_cell_t)O0; M.F[ro] = (poa_cell_t)F0; M.H[ro] = (poa_cell_t)H0;
-            M.E[ro] = (poa_cell_t)POA_NEG_INF; M.Q[ro] = (poa_cell_t)POA_NEG_INF;
+            M.O[ro] = (cell_t)O0; M.F[ro] = (cell_t)F0; M.H[ro] = (cell_t)H0;
+            M.E[ro] = (cell_t)NEG; M.Q[ro] = (cell_t)NEG;
         }
         // (E,Q) at the first column of the block; column 1: E = H0+g, Q = H0+q (E[0] = Q[0] = -inf)
         int cE = H0 + S.g, cQ = H0 + S.q;
@@ -370,7 +396,7 @@ __device__ void poa_dp(const PoaGraph &g, const PoaMatrices &M, const PoaArgs &A
         // the team's best sink: ties go to the first row in topological order (the serial loop's strict `<`)
         if (lane == 0) { sy->best[wave] = best; sy->best_i[wave] = max_i; }
         __syncthreads();
-        int b = POA_NEG_INF, bi = -1;
+        int b = NEG, bi = -1;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int v = *(volatile lds_i32 *)&sy->best[w], vi = *(volatile lds_i32 *)&sy->best_i[w];
@@ -1249,9 +1275,9 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
                 for (int p = 0; p < (ic ? ic : 1) && !found; ++p) {
                     const int pi = p ? pred_row(i - 1, node, p) : p0;
                     const int hv = PG_AT(M.H, pi, j), fv = fo_at(pi, j, hv, 0), ov = fo_at(pi, j, hv, 1);
-                    const bool c1 = Hij == fv + S.e;
+                    const bool c1 = !S.linear && Hij == fv + S.e;
                     const bool c2 = !c1 && Hij == hv + S.g;
-                    const bool c3 = !c1 && !c2 && Hij == ov + S.c;
+                    const bool c3 = !S.linear && !c1 && !c2 && Hij == ov + S.c;
                     const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
                     ext_up = ext_up || c1 || c3;
                     if (c1 || c2 || c3 || c4) { prev_i = pi; prev_j = j; found = true; Hnext = hv; hn_known = true; dn_first = p == 0 && p0 > 0; }
@@ -1260,10 +1286,11 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         }
         bool same_row = false;
         if (!found && j != 0) {
-            const int ev = E_at(i, j - 1), hv = PG_AT(M.H, i, j - 1), qv = Q_at(i, j - 1);
-            const bool c1 = Hij == ev + S.e;
+            const int hv = PG_AT(M.H, i, j - 1);
+            const int ev = S.linear ? 0 : E_at(i, j - 1), qv = S.linear ? 0 : Q_at(i, j - 1);      // (linear: no gap states to rebuild)
+            const bool c1 = !S.linear && Hij == ev + S.e;
             const bool c2 = !c1 && Hij == hv + S.g;
-            const bool c3 = !c1 && !c2 && Hij == qv + S.c;
+            const bool c3 = !S.linear && !c1 && !c2 && Hij == qv + S.c;
             const bool c4 = !c1 && !c2 && !c3 && Hij == hv + S.q;
             ext_left = c1 || c3;
             if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; Hnext = hv; hn_known = true; same_row = i != 0; }
@@ -2081,6 +2108,56 @@ __global__ void __launch_bounds__(64, WAVES) poa_kernel(PoaArgs A, SlotLayout L)
 }
 
 
+// ---- the wide kernel (round 6): int32 cells ---------------------------------------------------------------------------------------
+// spoa switches to 32-bit lanes when a window's scores may leave the int16 range (long reads: with c = -1 a graph of 25 000
+// nodes and a 5 000-base read is already past -30 000 in the worst case the plan must assume).  Here such windows - and
+// windows whose graph outgrew every capacity the int16 paths admit - run on this kernel: poa_kernel's window loop with the
+// column-block DP and the five-plane traceback instantiated for int32 cells (PoaMatricesW), the topological sort in global
+// memory (node ids need not fit 16 bits), one window per wavefront, slots handed out by a cursor.  A fallback: correct for
+// every window spoa accepts and the device has memory for, not tuned (the fast paths serve everything that fits them).
+__global__ void __launch_bounds__(64, 1) poa_wide_kernel(PoaArgs A, SlotLayout L)
+{
+    char *slot = A.work + (int64_t)blockIdx.x * A.slot_bytes;
+    PoaGraph g;
+    poa_bind_graph(g, slot, L, A);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    PoaTopoLds T;
+    poa_bind_lds(T, lds_raw, A);                               // (A.lds_marks = 0: T.use = 0, nothing of the sort lives in LDS)
+    int32_t *mat = (int32_t *)(slot + L.mat);
+    unsigned long long cells = 0;
+    for (;;) {
+        unsigned long long wq = 0;
+        if ((threadIdx.x & 63) == 0) wq = atomicAdd(A.cells + A.cur_idx, 1ull);
+        const unsigned q32 = (unsigned)__builtin_amdgcn_readfirstlane((int)wq);
+        if ((int64_t)q32 >= A.n_windows) break;
+        const int64_t w = (int64_t)q32;
+        poa_graph_reset(g);
+        T.n_sorted = 0; T.flags_ok = 0; T.use = 0;
+        const int64_t s0 = A.win_first_seq[w], s1 = A.win_first_seq[w + 1];
+        for (int64_t s = s0; s < s1; ++s) {
+            const uint8_t *seq = A.arena + A.seq_off[s];
+            const int len = A.seq_len[s];
+            g.n_path = 0;
+            if (g.n_nodes != 0 && len != 0 && g.err == 0) {
+                const int wp = poa_row_stride(len);
+                const int64_t plane = (int64_t)(g.n_nodes + 1) * wp;
+                PoaMatricesW M = {mat, mat + plane, mat + 2 * plane, mat + 3 * plane, mat + 4 * plane, wp};
+                int mi, mj;
+                cells += (unsigned long long)g.n_nodes * (unsigned long long)len;
+                poa_dp<8, 1, PoaMatricesW>(g, M, A, seq, len, mi, mj);
+                poa_traceback(g, M, A.S, seq, mi, mj);
+            }
+            if (g.err == 0) poa_add_alignment_wave<false>(g, seq, len, T);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        int clen = 0;
+        if (g.err == 0) clen = poa_consensus(g, A.cons + w * A.cons_stride, (int)A.cons_stride);
+        if ((threadIdx.x & 63) == 0) { A.cons_len[w] = clen; A.status[w] = g.err; }
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(A.cells, cells);
+}
+
 // ---- the team kernel (round 5): one window per WORKGROUP of NW wavefronts ---------------------------------------------------------
 // poa_kernel's window loop with the DP of a sequence run by all NW wavefronts (poa_dp_team) and everything else - traceback,
 // add_alignment with the sort, consensus - by wavefront 0 while the others wait at a barrier (a waiting wavefront takes no issue
@@ -2696,8 +2773,9 @@ int poa_read_cells(const void *d_work, size_t slots_bytes, int64_t *cells, hipSt
 
 bool poa_scores_fit_int16(const gbx_poa_params *p, int64_t ncap, int lmax)
 {
-    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c};
-    if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
+    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c, 0};
+    if (S.g >= S.e) { S.e = S.q = S.c = S.g; S.linear = 1; }           // the linear subtype (poa_graph.h: PoaScore)
+    else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
     const int64_t worst = -(int64_t)(S.q < S.g ? -S.q : -S.g) * 2 - (int64_t)(S.c > S.e ? -S.c : -S.e) * (ncap + lmax);
     const int64_t worst_mis = (int64_t)S.n * lmax, hi = (int64_t)S.m * lmax;
     // the pipelined DP keeps H - F and H - O in one byte each (PoaPredIn): H - F <= smax - max(g,q) - g, H - O likewise with q
@@ -2714,10 +2792,12 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
     if (n_windows == 0) return GBX_OK;
     if (n_windows != plan->n_windows) { set_error("poa: the plan was made for %lld windows, the call has %lld", (long long)plan->n_windows, (long long)n_windows); return GBX_ERR_ARG; }
     const int lmax = plan->max_seq_len, deg = plan->max_seqs_per_window, ncap = plan->node_cap;
-    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c};
+    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c, 0};
     if (S.g > 0 || S.q > 0 || S.e > 0 || S.c > 0) { set_error("poa: gap penalties must be non-positive"); return GBX_ERR_ARG; }
-    if (S.g >= S.e) { set_error("poa: linear gap mode (g >= e) is not supported by the device path"); return GBX_ERR_UNSUPPORTED; }
-    if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }          // affine == convex with both pieces equal
+    // spoa's createAlignmentEngine: g >= e is the LINEAR subtype (one gap cost g: msa_spoa_omp.cpp:170-196 lets -o / -e produce it),
+    // g <= q or e >= c the affine one (convex with both pieces equal), else convex
+    if (S.g >= S.e) { S.e = S.q = S.c = S.g; S.linear = 1; }
+    else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
     const PoaWs ws = poa_ws(plan);
     if (work_bytes < ws.total) { set_error("poa: workspace too small"); return GBX_ERR_ARG; }
     if (n_windows >= ((int64_t)1 << 31)) { set_error("poa: more than 2^31 windows in one call"); return GBX_ERR_UNSUPPORTED; }
@@ -2866,6 +2946,49 @@ int poa_launch(const gbx_poa_params *p, const gbx_poa_plan *plan, int64_t n_wind
     if (ss && (rc = ss->join(s))) return rc;
     GBX_HIP(hipGetLastError());
     side_lock = std::unique_lock<std::mutex>();
+    GBX_GUARD_CHECK("poa");
+    return GBX_OK;
+}
+
+// The wide launch (poa_wide_kernel): every window of the call on int32 cells.  Workspace = counter block | n_slots slots of
+// poa_wide_slot_bytes(ncap, deg, lmax).
+size_t poa_wide_slot_bytes(int ncap, int deg, int lmax) { return (size_t)make_layout(ncap, deg, lmax, true, 4).total; }
+size_t poa_wide_workspace_bytes(int ncap, int deg, int lmax, int n_slots)
+{
+    return (size_t)POA_NCOUNTERS * 8 + 256 + poa_wide_slot_bytes(ncap, deg, lmax) * (size_t)(n_slots > 0 ? n_slots : 0);
+}
+int poa_launch_wide(const gbx_poa_params *p, int64_t n_windows, const int64_t *d_win_first_seq, const int64_t *d_seq_off, const int32_t *d_seq_len,
+                    const uint8_t *d_arena, uint8_t *d_cons, int32_t *d_cons_len, int32_t *d_status, int64_t cons_stride,
+                    int ncap, int deg, int lmax, int n_slots, void *d_work, size_t work_bytes, hipStream_t s)
+{
+    if (n_windows == 0) return GBX_OK;
+    if (n_slots < 1 || work_bytes < poa_wide_workspace_bytes(ncap, deg, lmax, n_slots)) { set_error("poa: wide workspace too small"); return GBX_ERR_ARG; }
+    if (n_windows >= ((int64_t)1 << 31)) { set_error("poa: more than 2^31 windows in one call"); return GBX_ERR_UNSUPPORTED; }
+    PoaScore S = {p->m, p->n, p->g, p->e, p->q, p->c, 0};
+    if (S.g > 0 || S.q > 0 || S.e > 0 || S.c > 0) { set_error("poa: gap penalties must be non-positive"); return GBX_ERR_ARG; }
+    if (S.g >= S.e) { S.e = S.q = S.c = S.g; S.linear = 1; }
+    else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
+    // int32 cells with -2^29 as -infinity: real scores stay far above it (|score| <= 128 x (nodes + length))
+    if (((int64_t)ncap + lmax) * 130 > ((int64_t)1 << 28)) { set_error("poa: window too large even for 32-bit cells (%d nodes, length %d)", ncap, lmax); return GBX_ERR_UNSUPPORTED; }
+    char *wb = (char *)d_work;
+    unsigned long long *d_cells = (unsigned long long *)wb;
+    GBX_HIP(hipMemsetAsync(d_cells, 0, POA_NCOUNTERS * 8, s));
+    const Mat2 T = {S.e, S.g, S.q, S.c};
+    PoaArgs A;
+    A.n_windows = n_windows; A.win_first_seq = d_win_first_seq; A.seq_off = d_seq_off; A.seq_len = d_seq_len;
+    A.arena = d_arena; A.cons = d_cons; A.cons_len = d_cons_len; A.status = d_status; A.cons_stride = cons_stride;
+    A.cells = d_cells; A.ncap = ncap; A.deg = deg; A.lmax = lmax; A.S = S;
+    for (int v = 0; v < 2; ++v) {
+        A.Tc[v][0] = mp_pow(T, v == 0 ? 8 : 16);
+        for (int k = 1; k < 4; ++k) A.Tc[v][k] = mp_mul(A.Tc[v][k - 1], A.Tc[v][k - 1]);
+    }
+    A.lds_marks = 0; A.lds_stack = 0; A.lds_ncap = 0;
+    const SlotLayout L = make_layout(ncap, deg, lmax, true, 4);
+    A.work = wb + (size_t)POA_NCOUNTERS * 8 + 256; A.slot_bytes = L.total; A.wlist = nullptr; A.cnt_idx = POA_CNT_MAIN; A.cur_idx = POA_CUR_MAIN;
+    const int grid = (int)std::min<int64_t>(n_windows, n_slots);
+    Stage st("poa_window_wide", s);
+    hipLaunchKernelGGL(poa_wide_kernel, dim3(grid), dim3(64), (size_t)POA_LDS_FIXED + 64, s, A, L);
+    GBX_HIP(hipGetLastError());
     GBX_GUARD_CHECK("poa");
     return GBX_OK;
 }

@@ -7,7 +7,7 @@
  * submodule tools/spoa (arun-sub/spoa, default branch, commit unknown:
  * R/.gitmodules:18-20; the directory is empty in this checkout) and the
  * reference tree holds no expected consensus.  This file restates the published
- * spoa v3 algorithm (sisd_alignment_engine convex/affine NW, Graph::add_alignment,
+ * spoa v3 algorithm (sisd_alignment_engine linear / affine / convex NW, Graph::add_alignment,
  * Graph::topological_sort, Graph::traverse_heaviest_bundle + branch_completion;
  * SURVEY.md Appendix D) and is anchored by the known-answer tests in
  * tests/test_poa_cpu.py (identical reads, majority votes, order invariants).
@@ -322,6 +322,79 @@ static int64_t align_nw(const graph_t *gr, const char *seq, int len, const gbx_p
     return (int64_t)gr->n_nodes * (int64_t)len;
 }
 
+/* SisdAlignmentEngine::align for the LINEAR subtype (spoa v3 createAlignmentEngine: `g >= e` selects it and sets e = g; the
+ * driver's CLI reaches it with -o 0,... : msa_spoa_omp.cpp:170-196).  One matrix: H(i,j) = max over the in-edge sources p of
+ * H(p,j-1) + score and H(p,j) + g, then H(i,j-1) + g along the row; first row j*g, first column max over sources of H(p,0) + g
+ * (g for a node without in-edges).  Backtrack: diagonal candidates in in-edge order, then vertical ones in in-edge order, then
+ * the horizontal one - one cell per step, no extension walks. */
+static int64_t align_nw_linear(const graph_t *gr, const char *seq, int len, const gbx_poa_params *P, avec *out)
+{
+    out->n = 0;
+    if (gr->n_nodes == 0 || len == 0) return 0;
+    const int m_ = P->m, n_ = P->n, g_ = P->g;
+    const int W = len + 1, Hh = gr->n_nodes + 1;
+    int *H = (int *)malloc(sizeof(int) * (size_t)W * (size_t)Hh);
+    int *rank = (int *)malloc(sizeof(int) * (size_t)gr->n_nodes);
+    const int *r2n = gr->rank_to_node.v;
+    for (int i = 0; i < gr->n_nodes; ++i) rank[r2n[i]] = i;
+#define AT(a, b) H[(size_t)(a) * W + (b)]
+    AT(0, 0) = 0;
+    for (int j = 1; j < W; ++j) AT(0, j) = j * g_;
+    for (int i = 1; i < Hh; ++i) {
+        const node_t *nd = &gr->nodes[r2n[i - 1]];
+        int pen = nd->in.n == 0 ? 0 : NEG_INF;
+        for (int k = 0; k < nd->in.n; ++k) {
+            const int v = AT(rank[gr->edges[nd->in.v[k]].begin] + 1, 0);
+            if (v > pen) pen = v;
+        }
+        AT(i, 0) = pen + g_;
+    }
+    int max_score = NEG_INF, max_i = -1, max_j = -1;
+    for (int r = 0; r < gr->n_nodes; ++r) {
+        const node_t *nd = &gr->nodes[r2n[r]];
+        const char letter = gr->decoder[nd->code];
+        const int i = r + 1;
+        for (int p = 0; p < (nd->in.n ? nd->in.n : 1); ++p) {
+            const int pi = nd->in.n ? rank[gr->edges[nd->in.v[p]].begin] + 1 : 0;
+            for (int j = 1; j < W; ++j) {
+                const int d = AT(pi, j - 1) + (letter == seq[j - 1] ? m_ : n_), v = AT(pi, j) + g_;
+                const int h = d > v ? d : v;
+                if (p == 0 || h > AT(i, j)) AT(i, j) = h;
+            }
+        }
+        for (int j = 1; j < W; ++j) if (AT(i, j - 1) + g_ > AT(i, j)) AT(i, j) = AT(i, j - 1) + g_;
+        if (nd->out.n == 0 && max_score < AT(i, W - 1)) { max_score = AT(i, W - 1); max_i = i; max_j = W - 1; }
+    }
+    if (!(max_i == -1 && max_j == -1)) {
+        int i = max_i, j = max_j, prev_i = 0, prev_j = 0;
+        while (!(i == 0 && j == 0)) {
+            const int Hij = AT(i, j);
+            int found = 0;
+            const node_t *nd = i ? &gr->nodes[r2n[i - 1]] : NULL;
+            if (i != 0 && j != 0) {
+                const int mc = gr->decoder[nd->code] == seq[j - 1] ? m_ : n_;
+                for (int p = 0; p < (nd->in.n ? nd->in.n : 1) && !found; ++p) {
+                    const int pi = nd->in.n ? rank[gr->edges[nd->in.v[p]].begin] + 1 : 0;
+                    if (Hij == AT(pi, j - 1) + mc) { prev_i = pi; prev_j = j - 1; found = 1; }
+                }
+            }
+            if (!found && i != 0) {
+                for (int p = 0; p < (nd->in.n ? nd->in.n : 1) && !found; ++p) {
+                    const int pi = nd->in.n ? rank[gr->edges[nd->in.v[p]].begin] + 1 : 0;
+                    if (Hij == AT(pi, j) + g_) { prev_i = pi; prev_j = j; found = 1; }
+                }
+            }
+            if (!found && j != 0 && Hij == AT(i, j - 1) + g_) { prev_i = i; prev_j = j - 1; found = 1; }
+            av_push(out, i == prev_i ? -1 : r2n[i - 1], j == prev_j ? -1 : j - 1);
+            i = prev_i; j = prev_j;
+        }
+        for (int a = 0, b = out->n - 1; a < b; ++a, --b) { apair t = out->v[a]; out->v[a] = out->v[b]; out->v[b] = t; }
+    }
+#undef AT
+    free(H); free(rank);
+    return (int64_t)gr->n_nodes * (int64_t)len;
+}
+
 /* Graph::branch_completion */
 static int branch_completion(const graph_t *g, int64_t *scores, int *pred, int rank)
 {
@@ -400,7 +473,8 @@ int oracle_poa_window(const gbx_poa_params *P, int n_seqs, const char *const *se
     avec aln = {0, 0, 0};
     int64_t cells = 0;
     for (int s = 0; s < n_seqs; ++s) {
-        cells += align_nw(&g, seqs[s], lens[s], P, &aln);
+        /* createAlignmentEngine: g >= e is the linear subtype, else affine / convex (align_nw decides between those two) */
+        cells += P->g >= P->e ? align_nw_linear(&g, seqs[s], lens[s], P, &aln) : align_nw(&g, seqs[s], lens[s], P, &aln);
         add_alignment(&g, &aln, seqs[s], lens[s]);
     }
     const int len = consensus(&g, cons, cons_cap);

@@ -53,8 +53,9 @@ extern "C" int hostcheck_poa_topo_inc(const gbx_poa_params *P, int n_seqs, const
     g.score = score.data(); g.pred = pred.data(); std::vector<int32_t> cpath(ncap + 1); g.cons_path = cpath.data(); g.path_node = pn.data(); g.path_pos = pp.data();
     g.coder = coder.data(); g.decoder = dec.data();
     poa_graph_reset(g);
-    PoaScore S = {P->m, P->n, P->g, P->e, P->q, P->c};
-    if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
+    PoaScore S = {P->m, P->n, P->g, P->e, P->q, P->c, 0};
+    if (S.g >= S.e) { S.e = S.q = S.c = S.g; S.linear = 1; }      // as poa_launch does (poa_kernels.hip)
+    else if (S.g <= S.q || S.e >= S.c) { S.q = S.g; S.c = S.e; }
     const size_t plane = (size_t)(ncap + 1) * poa_row_stride(lmax);
     std::vector<poa_cell_t> mat(plane * 5);
     PoaMatrices M = {mat.data(), mat.data() + plane, mat.data() + 2 * plane, mat.data() + 3 * plane, mat.data() + 4 * plane, 0};

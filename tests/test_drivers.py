@@ -69,6 +69,30 @@ def test_bsw_class_shim_defines_every_public_entry_point_of_the_class():
         assert "BandedPairWiseSW::" + m in defined, m
 
 
+def test_bsw_binary_input_cache(tmp_path):
+    """`bsw --cache FILE` writes the converted arrays after the first conversion and maps them on
+    later runs of the same input - same arrays (checksum), whatever the thread count; a cache of an input that has changed
+    since (size / modification time) is ignored and rewritten."""
+    from genomicsbench_amd.datagen import gen_bsw, write_bsw_pairs_fast
+    pairs, cache = str(tmp_path / "pairs.txt"), str(tmp_path / "pairs.gbxcache")
+    write_bsw_pairs_fast(pairs, gen_bsw(3000, 5))
+    exe = os.path.join(BIN, "bsw")
+    first = run([exe, "-pairs", pairs, "-t", "3", "--parse-only", "1", "--cache", cache])
+    assert first.returncode == 0 and os.path.exists(cache) and "mapped from the cache" not in first.stdout, first.stderr
+    want = json.loads(first.stdout.strip().splitlines()[-1])
+    for t in ("1", "5"):
+        r = run([exe, "-pairs", pairs, "-t", t, "--parse-only", "1", "--cache", cache])
+        assert r.returncode == 0 and "mapped from the cache" in r.stdout, r.stdout + r.stderr
+        got = json.loads(r.stdout.strip().splitlines()[-1])
+        assert got["pairs"] == 3000 and got["checksum"] == want["checksum"]
+    write_bsw_pairs_fast(pairs, gen_bsw(2000, 6))                 # another input under the same name
+    r = run([exe, "-pairs", pairs, "-t", "2", "--parse-only", "1", "--cache", cache])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "mapped from the cache" not in r.stdout and got["pairs"] == 2000 and got["checksum"] != want["checksum"]
+    r = run([exe, "-pairs", pairs, "-t", "2", "--parse-only", "1", "--cache", cache])
+    assert "mapped from the cache" in r.stdout and json.loads(r.stdout.strip().splitlines()[-1])["checksum"] == got["checksum"]
+
+
 def _fnv1a(chunks):
     h = 1469598103934665603
     for c in chunks:

@@ -101,6 +101,56 @@ def test_product_graph_code_matches_oracle(hostcheck):
         assert _host_window(hostcheck, pa, ws.window(w))[0] == want[w]
 
 
+def _noisy_windows(seed, n=30):
+    rng = np.random.default_rng(seed)
+    wins = []
+    for _ in range(n):
+        base = "".join(rng.choice(list("ACGTN"), int(rng.integers(5, 60)), p=[.24, .24, .24, .24, .04]))
+        reads = []
+        for _ in range(int(rng.integers(1, 9))):
+            r = [c for c in base if rng.random() > 0.1]
+            r = [c if rng.random() > 0.1 else "ACGT"[int(rng.integers(4))] for c in r]
+            for _ in range(int(rng.integers(0, 3))):
+                r.insert(int(rng.integers(0, len(r) + 1)), "ACGT"[int(rng.integers(4))])
+            reads.append("".join(r) or "A")
+        wins.append(reads)
+    return wins
+
+
+def test_linear_gap_subtype_known_answers():
+    """spoa's linear subtype (g >= e; the driver's -o 0,... reaches it: msa_spoa_omp.cpp:170-196): one gap cost.  Identical
+    reads give the read; a majority wins; and where linear and affine costs disagree about an alignment the consensus shows
+    which one ran: with g = -2 per gap base two separate one-base gaps cost what one two-base gap costs."""
+    pl = make_params(o1=0, e1=2)                      # g = e = -2
+    assert pl.g >= pl.e
+    for seqs in (["ACGTACGTAC"] * 4, ["ACGTTGCA", "ACGTTGCA", "ACGATGCA"], ["AAAACCCCGGGG", "AAAACCCCGGGG", "AAAAGGGG"]):
+        want = seqs[0]
+        assert O.poa_oracle(pl, PoaWindowSet.from_lists([seqs]))[0] == want
+
+
+def test_linear_gap_subtype_product_graph_code_matches_oracle(hostcheck):
+    """The device path runs the linear subtype as the affine DP with e = q = c = g (the same score matrix) and a backtrack that
+    takes single cells only (poa_graph.h: PoaScore::linear): the product's serial code (host build) against the oracle's
+    one-matrix restatement, on noisy windows where ties between diagonal, vertical and horizontal moves are common."""
+    for pl in (make_params(o1=0, e1=2), make_params(o1=0, e1=4, o2=2, e2=1), make_params(m=1, x=1, o1=0, e1=1)):
+        assert pl.g >= pl.e
+        for seed in (3, 4):
+            wins = _noisy_windows(seed)
+            ws = PoaWindowSet.from_lists(wins)
+            want = O.poa_oracle(pl, ws)
+            for w in range(ws.n_windows):
+                got, err = _host_window(hostcheck, pl, ws.window(w))
+                assert err == 0 and got == want[w], (w, wins[w])
+        ws = gen_poa(4, 78)
+        want = O.poa_oracle(pl, ws, 4)
+        for w in range(ws.n_windows):
+            assert _host_window(hostcheck, pl, ws.window(w)) == (want[w], 0)
+    # and the two subtypes are different algorithms: on the same noisy windows some consensus differs
+    pa, pl = make_params(), make_params(o1=0, e1=2)
+    ws = PoaWindowSet.from_lists(_noisy_windows(5, 60))
+    assert O.poa_oracle(pa, ws) != O.poa_oracle(pl, ws)
+
+
 def test_capacity_overflow_is_reported(hostcheck):
     p = make_params()
     ws = gen_poa(1, 5)

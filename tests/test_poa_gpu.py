@@ -64,11 +64,71 @@ def test_affine_scoring_and_shard_equivalence():
     assert consensus_host(pa, ws.take(0, 5)) + consensus_host(pa, ws.take(5, 16)) == full
 
 
-def test_linear_gap_mode_is_rejected():
-    ws = gen_poa(1, 1)
-    with pytest.raises(N.GbxError) as e:
-        consensus_host(make_params(o1=0, e1=2), ws)          # g >= e -> spoa's linear subtype
-    assert e.value.code == N.GBX_ERR_UNSUPPORTED
+@pytest.mark.parametrize("kw", [dict(o1=0, e1=2), dict(o1=0, e1=4, o2=2, e2=1), dict(m=1, x=1, o1=0, e1=1)])
+def test_linear_gap_subtype(kw, monkeypatch):
+    """g >= e is spoa's linear subtype (the driver's -o 0,... : msa_spoa_omp.cpp:170-196): the device runs it as the affine DP
+    with e = q = c = g and a backtrack of single cells (PoaScore::linear); consensus == the oracle's one-matrix restatement,
+    through the window kernel, the team kernel (small jobs) and the long-window launch."""
+    p = make_params(**kw)
+    assert p.g >= p.e
+    ws = gen_poa(24, 31)
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws, 8))
+    monkeypatch.setenv("GBX_POA_TEAM", "0")
+    diff(consensus_host(p, ws), O.poa_oracle(p, ws, 8))
+    monkeypatch.delenv("GBX_POA_TEAM")
+    long_ws = PoaWindowSet.from_lists([[s * 3 for s in ws.window(w)[:6]] for w in range(3)])      # sequences over 512 bases
+    diff(consensus_host(p, long_ws), O.poa_oracle(p, long_ws, 8))
+
+
+def _long_read_window(length, n_reads, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 4, length)
+    reads = []
+    for _ in range(n_reads):
+        r = base[rng.random(length) > 0.03]                      # deletions
+        sub = rng.random(r.size) < 0.05
+        r = np.where(sub, rng.integers(0, 4, r.size), r)
+        ins = np.sort(rng.integers(0, r.size, max(1, length // 40)))
+        r = np.insert(r, ins, rng.integers(0, 4, ins.size))
+        reads.append("".join("ACGT"[c] for c in r))
+    return reads
+
+
+def test_wide_path_on_ordinary_windows(monkeypatch):
+    """The int32 path (poa_wide_kernel: column-block DP and five-plane traceback on 32-bit cells, global-memory sort) forced
+    onto windows the int16 paths usually take: same consensus as the oracle, with fewer slots than windows (the cursor hands a
+    slot its next window) and with the linear subtype."""
+    monkeypatch.setenv("GBX_POA_FORCE_WIDE", "1")
+    ws = gen_poa(20, 57)
+    p = make_params()
+    want = O.poa_oracle(p, ws, 8)
+    diff(consensus_host(p, ws), want)
+    monkeypatch.setenv("GBX_POA_WIDE_SLOTS", "3")
+    diff(consensus_host(p, ws), want)
+    pl = make_params(o1=0, e1=2)
+    diff(consensus_host(pl, ws), O.poa_oracle(pl, ws, 8))
+
+
+def test_long_read_window_takes_the_wide_path_beside_ordinary_windows():
+    """Reads of 6 kb: the plan's worst-case score leaves the int16 range (poa_scores_fit_int16), where the entry used to
+    return GBX_ERR_UNSUPPORTED and spoa switches to 32-bit lanes; now that window runs on int32 cells while the ordinary
+    windows of the same call keep their kernels.  Consensus of every window == the oracle's."""
+    ws0 = gen_poa(6, 58)
+    wins = [ws0.window(w) for w in range(3)] + [_long_read_window(6000, 4, 1)] + [ws0.window(w) for w in range(3, 6)]
+    ws = PoaWindowSet.from_lists(wins)
+    p = make_params()
+    got = consensus_host(p, ws)
+    diff(got, O.poa_oracle(p, ws, 8))
+    assert len(got[3]) > 5000
+
+
+def test_window_of_12_kb_reads():
+    """a window of 12-kb reads (three of them: the oracle's five int planes are 3.4 GB) against the oracle."""
+    ws = PoaWindowSet.from_lists([_long_read_window(12000, 3, 2)])
+    p = make_params()
+    got = consensus_host(p, ws)
+    diff(got, O.poa_oracle(p, ws, 2))
+    assert len(got[0]) > 11000
 
 
 def test_host_entry_staged_transfers(monkeypatch):
