@@ -72,16 +72,20 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     const int64_t SL = 32768, n_slices = (n + SL - 1) / SL;
     std::vector<int64_t> slice_r((size_t)n_slices), slice_q((size_t)n_slices), slice_bad((size_t)n_slices, -1);
     std::vector<int64_t> slice_rows((size_t)n_slices, 0);   // pairs the lane kernels will not take (BswChunkPrep::rows_pairs)
+    std::vector<int64_t> slice_cls((size_t)n_slices * 10, 0);      // ... and the others per lane launch (BswChunkPrep::class_pairs)
     BswLaneRule rule = {0, 0, 0, 0};
     if (bsw_lane_rule(p, chunk, &rule) != GBX_OK) rule.on = 0;      // (bad parameters: the launch reports them)
     std::vector<int> slice_plain((size_t)n_slices, 0);      // longest query if every pair has 1 <= qlen <= 256, tlen >= 1 and a small h0 (bsw_launch_direct), else 0
     auto check_slice = [&](int64_t sl) {
         const int64_t a = sl * SL, b = a + SL < n ? a + SL : n;
         int64_t mr = 0, mq = 0, rows = 0;
+        int64_t cls[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool plain = true;
         int maxq = 1;
         for (int64_t k = a; k < b; ++k) {
-            rows += !bsw_lane_takes(rule, len2[k], len1[k], h0[k]) && len1[k] != 0 && len2[k] != 0;
+            const bool takes = bsw_lane_takes(rule, len2[k], len1[k], h0[k]);
+            if (takes) ++cls[bsw_lane_class(rule, len2[k], h0[k])];
+            rows += !takes && len1[k] != 0 && len2[k] != 0;
             plain = plain && len2[k] >= 1 && len2[k] <= 256 && len1[k] >= 1 && h0[k] < 1000000;
             maxq = len2[k] > maxq ? len2[k] : maxq;
             const int64_t er = idr[k] + len1[k], eq = idq[k] + len2[k];
@@ -93,6 +97,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
             mr = er > mr ? er : mr; mq = eq > mq ? eq : mq;
         }
         slice_r[(size_t)sl] = mr; slice_q[(size_t)sl] = mq; slice_plain[(size_t)sl] = plain ? maxq : 0; slice_rows[(size_t)sl] = rows;
+        for (int c = 0; c < 10; ++c) slice_cls[(size_t)sl * 10 + (size_t)c] = cls[c];
     };
     // slices [s0, s1): checked by a few threads; the lowest failing pair is reported
     auto validate = [&](int64_t s0, int64_t s1) -> int {
@@ -120,7 +125,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
     const int64_t s_first = n_chunks > 1 && (cut[1] + SL - 1) / SL < n_slices ? (cut[1] + SL - 1) / SL : n_slices;
     int rc = validate(0, s_first);
     if (rc) return rc;
-    std::vector<int64_t> rows_pairs((size_t)n_chunks, -1);
+    std::vector<int64_t> rows_pairs((size_t)n_chunks, -1), cls_pairs((size_t)n_chunks * 10, 0);
     auto chunk_needs = [&](int64_t c) {
         int64_t mr = 0, mq = 0, rows = 0;
         // chunks are multiples of 64 pairs, slices of 32768: a slice may straddle two chunks, which only makes
@@ -129,6 +134,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
             mr = slice_r[(size_t)sl] > mr ? slice_r[(size_t)sl] : mr;
             mq = slice_q[(size_t)sl] > mq ? slice_q[(size_t)sl] : mq;
             rows += slice_rows[(size_t)sl];
+            for (int k = 0; k < 10; ++k) cls_pairs[(size_t)c * 10 + (size_t)k] += slice_cls[(size_t)sl * 10 + (size_t)k];
         }
         need_r[(size_t)c] = mr; need_q[(size_t)c] = mq;
         // (an upper bound: a slice that straddles two chunks counts for both; a short last chunk may run without the lane path)
@@ -234,6 +240,10 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
             prep.qer_packed = dqer_p.as<uint8_t>(); prep.qer_bytes = dqer.as<uint8_t>();
             prep.lo_r = lo_r[(size_t)c]; prep.hi_r = hi_r[(size_t)c]; prep.lo_q = lo_q[(size_t)c]; prep.hi_q = hi_q[(size_t)c];
             prep.unp_r = &unp_r; prep.unp_q = &unp_q;
+        }
+        if (rows_pairs[(size_t)c] >= 0) {                    // (counted with the rule this chunk's launch applies)
+            prep.class_known = 1;
+            for (int k = 0; k < 10; ++k) prep.class_pairs[k] = cls_pairs[(size_t)c * 10 + (size_t)k];
         }
         auto launch = [&]() {
             return bsw_launch(p, m, dref.as<uint8_t>(), dqer.as<uint8_t>(), didr.as<int64_t>() + a, didq.as<int64_t>() + a,

@@ -115,14 +115,28 @@ struct BswChunkPrep {
     // the lane kernels take whole reads the packed images and expands nothing, so the next chunk that does need the bytes
     // expands from the watermark, not from its own lo: its pairs may lie in what an earlier, packed chunk brought up.
     int64_t *unp_r = nullptr, *unp_q = nullptr;
+    // Pairs of the chunk per lane launch (bsw_lane_class: format x query-length range), or upper bounds; class_known = 0: not
+    // counted.  With GBX_BSW_SKIP_EMPTY=1 a launch whose class is empty is left out (it has to be given its LDS before its
+    // wavefronts can see that their list is empty: 0.1-0.85 ms on its stream in profiles/r05al_host_timeline.txt) - measured no
+    // faster on 'large' (six of ten classes empty; profiles/r06h_bsw_skip_empty_ab.txt), so not the default.
+    int class_known = 0;
+    int64_t class_pairs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 // Which pairs a launch of n pairs puts on the lane kernels (bsw_kernels.hip: lane_ok), for a host pass that counts the
 // others: a launch that knows there are none leaves out the row-kernel classes, twenty-one near-empty launches.
-struct BswLaneRule { int on, max_mat, qmax, limit; };
+struct BswLaneRule { int on, max_mat, qmax, limit; int compact_limit = 0; int range_hi[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}}; };
 int bsw_lane_rule(const gbx_bsw_params *p, int64_t n, BswLaneRule *r);
 static inline bool bsw_lane_takes(const BswLaneRule &r, int qlen, int tlen, int h0)
 {
     return r.on && qlen >= 1 && qlen <= r.qmax && tlen >= 1 && h0 >= 0 && h0 + qlen * r.max_mat < r.limit;
+}
+// the lane launch that takes a pair bsw_lane_takes() accepts: format (0 compact cells, 1 wide) x 5 + query-length range
+static inline int bsw_lane_class(const BswLaneRule &r, int qlen, int h0)
+{
+    const int fmt = h0 + qlen * r.max_mat < r.compact_limit ? 0 : 1;
+    int k = 0;
+    while (k < 4 && qlen > r.range_hi[fmt][k]) ++k;
+    return fmt * 5 + k;
 }
 size_t bsw_workspace_bytes(int64_t n);
 int bsw_launch(const gbx_bsw_params *p, int64_t n,

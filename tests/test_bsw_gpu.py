@@ -322,7 +322,7 @@ def test_lane_packed_chunk_followed_by_unpacked_chunk(lane, monkeypatch, where):
     assert "bsw_unpack4" in prof, sorted(prof)                   # a chunk that expanded the arenas ...
     lane_launches = sum(c for k, (ms, c) in prof.items() if k.startswith("bsw_lane_c"))
     rows_launches = sum(c for k, (ms, c) in prof.items() if k.startswith("bsw_rows") or k == "bsw_lds")
-    assert lane_launches >= 15 and 0 < rows_launches, prof       # ... and three chunks of lane launches, row classes for one only
+    assert lane_launches >= 6 and 0 < rows_launches, prof        # ... and three chunks of lane launches (a chunk's empty classes are not launched), row classes for one only
     assert prof["bsw_lds"][1] == 1, prof                         # (the two packed chunks launched no row class at all)
 
 
