@@ -90,6 +90,7 @@ struct PhmmWork {
     int64_t scratch_stride;
     // stream path (reads of <= stream_rows rows), all indexed by read id unless noted
     int32_t stream_rows; // STREAM_MAX_ROWS, or 0 for small jobs: every pair takes the one-pair-per-wavefront kernels
+    int32_t seg_max;     // pairs per unit of the stream path (SEG_MAX_PAIRS; fewer for jobs too small to fill the chip with long units)
     int64_t n_reads;
     int32_t *rcount;     // pairs of the read
     int32_t *rslen;      // stream symbols of the read: sum (H+1)
@@ -120,8 +121,8 @@ __host__ __device__ inline int unit_bin(int R, int slen)
     return cls * UBUCKETS + (UBUCKETS - 1 - (b < UBUCKETS - 1 ? b : UBUCKETS - 1));
 }
 // unit = (read, segment): pairs [seg*q, min(c, seg*q+q)) of the read's c grouped pairs
-__host__ __device__ inline int seg_count(int c) { return (c + SEG_MAX_PAIRS - 1) / SEG_MAX_PAIRS; }
-__host__ __device__ inline int seg_pairs(int c) { const int ns = seg_count(c); return (c + ns - 1) / ns; }
+__host__ __device__ inline int seg_count(int c, int seg_max) { return (c + seg_max - 1) / seg_max; }
+__host__ __device__ inline int seg_pairs(int c, int seg_max) { const int ns = seg_count(c, seg_max); return (c + ns - 1) / ns; }
 __host__ __device__ inline int64_t stream_bytes_of(int slen) { return ((int64_t)slen + 1 + 15 + 16) & ~(int64_t)15; }
 
 __device__ inline float shr1(float fill, float x)
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) phmm_read_sum_kernel(PhmmArgs A,
     const int64_t r = (int64_t)blockIdx.x * SCAN_THREADS + tid;
     int c; long long bytes;
     read_contrib(W, r, c, bytes);
-    if (c) { const int ns = seg_count(c); atomicAdd(&bins[unit_bin(A.read_len[r], W.rslen[r] / ns)], ns); }
+    if (c) { const int ns = seg_count(c, W.seg_max); atomicAdd(&bins[unit_bin(A.read_len[r], W.rslen[r] / ns)], ns); }
     long long wb = bytes; int wc = c;
     for (int d = 32; d; d >>= 1) { wb += __shfl_down(wb, d); wc += __shfl_down(wc, d); }
     if ((tid & 63) == 0) { sb[tid >> 6] = wb; sc[tid >> 6] = wc; }
@@ -436,14 +437,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) phmm_read_place_kernel(PhmmArgs 
     const int poff = off_c + ic - c;
     if (r < W.n_reads) { W.rfirst[r] = poff; W.rsbase[r] = off_b + ib - bytes; }
     // units: block-aggregated allocation inside the (class, length) bins
-    const int ns = c ? seg_count(c) : 0;
+    const int ns = c ? seg_count(c, W.seg_max) : 0;
     const int bin = c ? unit_bin(A.read_len[r], W.rslen[r] / ns) : 0;
     const int local = c ? atomicAdd(&lbin[bin], ns) : 0;
     __syncthreads();
     for (int b = tid; b < UBINS; b += SCAN_THREADS) lbase[b] = lbin[b] ? W.ubase[b] + atomicAdd(&W.ucur[b], lbin[b]) : 0;
     __syncthreads();
     if (c) {
-        const int q = seg_pairs(c), at = lbase[bin] + local;
+        const int q = seg_pairs(c, W.seg_max), at = lbase[bin] + local;
         for (int g = 0; g < ns; ++g) W.ulist[at + g] = poff + g * q;         // first grouped pair of the unit
     }
 }
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
         int64_t s_beg = 0, s_end = 0;                           // stream bytes [s_beg, s_end]: s_end = closing boundary
         if (have) {
             const int c = W.rcount[rd], r0 = W.rfirst[rd];
-            cnt = min(seg_pairs(c), c - (first - r0));
+            cnt = min(seg_pairs(c, W.seg_max), c - (first - r0));
             s_beg = W.soff[first];
             s_end = first + cnt < r0 + c ? W.soff[first + cnt] : W.rsbase[rd] + W.rslen[rd];
         }
@@ -802,8 +803,18 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     // thousand pairs one pair per wavefront on the tiled kernels (one round of the chip) is faster.  The
     // reference's driver calls per batch of a few hundred pairs (PairHMMUnitTest.cpp:228-245), so this is its path.
     const char *small_env = getenv("GBX_PHMM_SMALL");
-    const bool small_job = small_env ? atoi(small_env) != 0 : n_pairs < 24000;
+    const bool small_job = small_env ? atoi(small_env) != 0 : n_pairs < 12000;      // (with short units the stream path wins from ~12 000 pairs on: same sweep)
     W.stream_rows = small_job ? 0 : STREAM_MAX_ROWS;
+    // Units of up to eight pairs keep a half-wavefront busy for a long stream, which is what a job that oversubscribes the chip
+    // wants; a job of a few ten thousand pairs (sixty-four of the reference driver's batches combined, host_combine.h) is then a
+    // handful of long units per SIMD and as long as its longest one: such jobs take shorter units (GBX_PHMM_SEG overrides)
+    {
+        const char *se = getenv("GBX_PHMM_SEG");
+        // (measured, profiles/r06i_phmm_seg_sweep.txt: 64 batches 2.10 -> 1.64 ms, 32 batches 1.86 -> 1.12 ms with one pair per unit;
+        // from about a thousand batches on eight per unit is the faster form again)
+        int sm = se ? atoi(se) : n_pairs < 200000 ? 1 : n_pairs < 400000 ? 2 : SEG_MAX_PAIRS;
+        W.seg_max = sm < 1 ? 1 : sm > SEG_MAX_PAIRS ? SEG_MAX_PAIRS : sm;
+    }
     W.rcount = (int32_t *)(wb + L.rcount); W.rslen = (int32_t *)(wb + L.rslen); W.rcur = (int32_t *)(wb + L.rcur);
     W.rfirst = (int32_t *)(wb + L.rfirst); W.rsbase = (int64_t *)(wb + L.rsbase);
     W.porder = (int32_t *)(wb + L.porder); W.soff = (int64_t *)(wb + L.soff);
