@@ -137,6 +137,13 @@ __device__ inline double shr1(double fill, double x)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ inline int shr1(int fill, int x) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+// zero for lane 0: with bound_ctrl the shift needs no register holding the fill, and the compiler may fold it into the
+// instruction that uses the value (a DPP operand) instead of a move
+#ifndef GBX_PHMM_DPP_BC
+#define GBX_PHMM_DPP_BC 1            // 0: the round-5 form (a register holds the fill), for A/B builds
+#endif
+__device__ inline float shr1z(float x) { return GBX_PHMM_DPP_BC ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true)) : shr1(0.f, x); }
+__device__ inline int shr1z(int x) { return GBX_PHMM_DPP_BC ? __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true) : shr1(0, x); }
 
 __device__ inline float fmaT(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ inline double fmaT(double a, double b, double c) { return fma(a, b, c); }
@@ -581,10 +588,10 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
         auto step = [&](int sym_in, const float (&P)[3][RPL], float (&N)[3][RPL]) {
             // the row above slot 0: previous lane's last slot (this column = its previous step, P; the column
             // before = two steps ago, N before it is overwritten); DP row 0 for the top lane
-            const float uM = shr1(zero, P[0][RPL - 1]), uX = shr1(zero, P[1][RPL - 1]);
-            const float dM = shr1(zero, N[0][RPL - 1]), dX = shr1(zero, N[1][RPL - 1]);
-            float dY = shr1(zero, N[2][RPL - 1]);
-            h = shr1(0, h);
+            const float uM = shr1z(P[0][RPL - 1]), uX = shr1z(P[1][RPL - 1]);
+            const float dM = shr1z(N[0][RPL - 1]), dX = shr1z(N[1][RPL - 1]);
+            float dY = shr1z(N[2][RPL - 1]);
+            h = shr1z(h);
             if (top) { dY = ycur; h = sym_in; }
             const bool isb = h == 0;
             const bool hN = h == 'N';
