@@ -104,7 +104,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         const int64_t cnt = s1 - s0;
         const int vt = cnt >= 24 ? 12 : cnt >= 8 ? (int)(cnt / 2) : 1;      // 2.5 ns a pair and thread: 0.9 ms with 4 threads at 2 M pairs
         std::vector<Helper> th;
-        for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = s0 + t; sl < s1; sl += vt) check_slice(sl); });
+        for (int t = 1; t < vt; ++t) th.emplace_back([&, t] { for (int64_t sl = s0 + t; sl < s1; sl += vt) check_slice(sl); }, true);
         for (int64_t sl = s0; sl < s1; sl += vt) check_slice(sl);
         for (auto &x : th) x.join();
         for (int64_t sl = s0; sl < s1; ++sl) {

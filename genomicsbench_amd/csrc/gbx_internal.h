@@ -48,7 +48,8 @@ struct Stage {
 // the bounds that are free (a comparison the loop makes anyway).
 //   GBX_GUARD(var, bound)                   declares the counter (nothing in the product build)
 //   GBX_GUARD_TRIP(var, kernel, loop, unit) true when the bound is exhausted (constant false in the product build)
-//   GBX_GUARD_CHECK(what, stream)           in a launch function, after its launches: synchronises and turns a record into an error
+//   GBX_GUARD_CHECK(what)                   in a launch function, after its launches: hipDeviceSynchronize() (the whole device, other
+//                                           callers' streams included: the guard build is diagnostic only and its timings mean nothing), then a record becomes an error
 enum { GBX_GK_BSW = 1, GBX_GK_CHAIN = 2, GBX_GK_PHMM = 3, GBX_GK_POA = 4, GBX_GK_ABEA = 5, GBX_GK_FMI = 6 };
 #ifdef GBX_LOOP_GUARD
 namespace { __device__ unsigned long long gbx_guard_word; }      // one per translation unit

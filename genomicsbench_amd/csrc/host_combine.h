@@ -144,7 +144,7 @@ template <class F> static void combine_parallel(int64_t n, int threads, F fn)
     std::atomic<int64_t> next{0};
     auto body = [&] { for (int64_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(k); };
     std::vector<Helper> th;
-    for (int t = 1; t < threads; ++t) th.emplace_back(body);
+    for (int t = 1; t < threads; ++t) th.emplace_back(body, true);      // (no thread to be had: the slice runs here)
     body();
     for (auto &x : th) x.join();
 }

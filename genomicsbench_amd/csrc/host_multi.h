@@ -73,7 +73,7 @@ template <class CostFn> static std::vector<int64_t> split_by_cost(int64_t n, int
     {
         const int T = nb >= 32 ? host_workers() : 1;
         std::vector<Helper> th;
-        for (int t = 1; t < T; ++t) th.emplace_back([&, t] { for (int64_t b = t; b < nb; b += T) block_sum(b); });
+        for (int t = 1; t < T; ++t) th.emplace_back([&, t] { for (int64_t b = t; b < nb; b += T) block_sum(b); }, true);
         for (int64_t b = 0; b < nb; b += T) block_sum(b);
         for (auto &x : th) x.join();
     }

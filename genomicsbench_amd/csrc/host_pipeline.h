@@ -30,20 +30,22 @@ static double wall_s()
 
 // A thread from a cache of idle ones: what std::thread is used for in the host entries (a few helpers for the length of one
 // call or one pass), without creating threads per call - eighteen of them cost a 2 M-pair bsw call 0.5-0.7 ms of its 10.
-// Same use as std::thread: construct from a callable, join().  The operating-system threads are detached and never end;
-// one that has finished its task waits for the next.  A task always starts at once (an idle thread, else a new one), so
+// Same use as std::thread: construct from a callable, join().  The operating-system threads are detached; one that has finished
+// its task waits for the next (at most 64 idle ones are kept, a surplus worker ends).  They run code of this library: a process
+// must not unload libgbx.so (dlclose) or fork() and go on using it in the child while workers are parked.  A task always starts at once (an idle thread, else a new one), so
 // tasks that wait for each other (upload workers, the downloader) cannot block one another out.
 class Helper {
     struct Worker {
         std::mutex m;
         std::condition_variable cv;
         std::function<void()> job;
-        bool has = false, done = false;
+        bool has = false, done = false, quit = false;
         void loop()
         {
             for (;;) {
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return has; });
+                cv.wait(lk, [&] { return has || quit; });
+                if (!has) { lk.unlock(); delete this; return; }      // surplus to the cache (join): nobody holds a pointer to it any more
                 std::function<void()> f = std::move(job);
                 has = false;
                 lk.unlock();
@@ -57,12 +59,22 @@ class Helper {
     };
     struct Cache { std::mutex mu; std::vector<Worker *> idle; };
     static Cache &cache() { static Cache *c = new Cache(); return *c; }      // never destroyed: its threads outlive static destruction
+    // idle workers kept for the next task; beyond that a worker that finishes its task exits (a process whose many caller threads
+    // once ran the host entries at the same time would otherwise keep its peak helper count for good)
+    static size_t cache_cap()
+    {
+        static const size_t cap = getenv("GBX_HELPER_CACHE") ? (size_t)atoll(getenv("GBX_HELPER_CACHE")) : 64;      // (the TSan harness sets a small one)
+        return cap;
+    }
     Worker *w = nullptr;
+    bool failed_ = false;
 
 public:
     Helper() = default;
+    // inline_on_failure: a task that does not wait for other tasks (a slice of a parallel loop) runs on the calling thread when no
+    // thread can be started; otherwise failed() is set and nothing has run (the pipeline's workers wait for each other)
     template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Helper>::value>::type>
-    explicit Helper(F &&f)
+    explicit Helper(F &&f, bool inline_on_failure = false)
     {
         Cache &c = cache();
         {
@@ -70,9 +82,15 @@ public:
             if (!c.idle.empty()) { w = c.idle.back(); c.idle.pop_back(); }
         }
         if (!w) {
-            Worker *n = new Worker();
-            try { std::thread([n] { n->loop(); }).detach(); }
-            catch (...) { delete n; throw; }
+            Worker *n = nullptr;
+            try {
+                n = new Worker();
+                std::thread([n] { n->loop(); }).detach();
+            } catch (...) {                                       // no thread, or no memory for it: never through an extern "C" entry
+                delete n;
+                if (inline_on_failure) f(); else failed_ = true;
+                return;
+            }
             w = n;
         }
         {
@@ -83,11 +101,12 @@ public:
         }
         w->cv.notify_all();
     }
-    Helper(Helper &&o) noexcept : w(o.w) { o.w = nullptr; }
-    Helper &operator=(Helper &&o) noexcept { if (this != &o) { join(); w = o.w; o.w = nullptr; } return *this; }
+    Helper(Helper &&o) noexcept : w(o.w), failed_(o.failed_) { o.w = nullptr; }
+    Helper &operator=(Helper &&o) noexcept { if (this != &o) { join(); w = o.w; failed_ = o.failed_; o.w = nullptr; } return *this; }
     Helper(const Helper &) = delete;
     Helper &operator=(const Helper &) = delete;
     bool joinable() const { return w != nullptr; }
+    bool failed() const { return failed_; }
     void join()
     {
         if (!w) return;
@@ -96,8 +115,17 @@ public:
             w->cv.wait(lk, [&] { return w->done; });
         }
         Cache &c = cache();
-        std::lock_guard<std::mutex> lk(c.mu);
-        c.idle.push_back(w);
+        bool keep;
+        {
+            std::lock_guard<std::mutex> lk(c.mu);
+            keep = c.idle.size() < cache_cap();
+            if (keep) c.idle.push_back(w);
+        }
+        if (!keep) {                                               // told to go while we hold its lock; it frees itself, we let go of it
+            std::lock_guard<std::mutex> lk(w->m);
+            w->quit = true;
+            w->cv.notify_all();
+        }
         w = nullptr;
     }
     ~Helper() { join(); }
@@ -110,7 +138,7 @@ template <class F> static void parallel_ranges(int64_t n, int threads, F fn)
     if (threads > n / 4096) threads = (int)(n / 4096);
     if (threads <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<Helper> th;
-    for (int t = 1; t < threads; ++t) th.emplace_back([=] { fn(t, n * t / threads, n * (t + 1) / threads); });
+    for (int t = 1; t < threads; ++t) th.emplace_back([=] { fn(t, n * t / threads, n * (t + 1) / threads); }, true);
     fn(0, (int64_t)0, n / threads);
     for (auto &x : th) x.join();
 }
@@ -209,7 +237,7 @@ static int lane_prepare_staging(Lane *l)
     if (!l->dslab) GBX_HIP(hipHostMalloc((void **)&l->dslab, Lane::DOWN, hipHostMallocDefault));
     std::vector<Helper> th;
     for (int w = 0; w < Lane::MAX_WORKERS; ++w)
-        th.emplace_back([=] { memset(l->wslab[w][0], 0, Lane::PIECE); memset(l->wslab[w][1], 0, Lane::PIECE); });
+        th.emplace_back([=] { memset(l->wslab[w][0], 0, Lane::PIECE); memset(l->wslab[w][1], 0, Lane::PIECE); }, true);
     memset(l->dslab, 0, Lane::DOWN);
     for (auto &x : th) x.join();
     // one small DMA from every slab on the stream its worker will use, one to the download slab, an event behind each: what
@@ -693,9 +721,13 @@ struct HostPipe {
     {
         started = true;
         if (!staged) return;
-        for (int w = 0; w < workers; ++w) threads.emplace_back([this, w] { upload_worker(w); });
+        int up_ok = 0;
+        for (int w = 0; w < workers; ++w) { threads.emplace_back([this, w] { upload_worker(w); }); up_ok += threads.back().failed() ? 0 : 1; }
         pool.start((workers < 6 ? workers : 6) - 1);
         threads.emplace_back([this] { download_worker(); });
+        // no thread to be had for the uploads or the downloads (fewer upload workers than asked for is fine): the call fails at
+        // its next wait_stage() instead of waiting for ever
+        if (up_ok == 0 || threads.back().failed()) fail_hip(hipErrorOutOfMemory);
     }
     // Upload stages finer than the chunks (after prepare(); default: one stage per chunk): stage*() and wait_stage() then
     // count stages, fetch() / join_events() / chunk_launched() chunks.  bsw: a chunk's index arrays and its bases.

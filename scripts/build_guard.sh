@@ -1,5 +1,7 @@
 #!/bin/bash
 # The diagnostic build of libgbx.so with every data-dependent device loop bounded (-DGBX_LOOP_GUARD, csrc/gbx_internal.h):
+# DIAGNOSTIC ONLY: every launch function of this build ends in hipDeviceSynchronize() (GBX_GUARD_CHECK), which serialises the whole
+# device - other callers' streams and the pipelined bsw chunks included - so nothing timed under it is representative.
 #   scripts/build_guard.sh  ->  build_tmp/libgbx_guard.so   (load it with GBX_LIB=<path>)
 set -e
 ROOT=$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)

@@ -198,6 +198,7 @@ int main(int argc, char **argv)
         return 0;
     }
     const int threads = argc > 1 ? atoi(argv[1]) : 4, rounds = argc > 2 ? atoi(argv[2]) : 3;
+    setenv("GBX_HELPER_CACHE", "5", 1);                       // few idle helper threads are kept: the others end after their task (Helper::join)
     // (0) the chunk cuts of gbx_bsw_extend_host: 0 .. n, every inner cut a multiple of 64, ascending; the default rule (at most
     //     three equal chunks, none below 512 Ki pairs) and the two overrides
     {
