@@ -26,7 +26,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N.check(N.lib().gbx_host_prepare())
 t_end = time.time() + budget
-count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0, "fmi": 0}
+count = {"bsw": 0, "chain": 0, "phmm": 0, "poa": 0, "abea": 0, "fmi": 0, "combo": 0}
 skip_until = int(os.environ.get("FUZZ_SKIP_UNTIL", "0"))       # replay aid: draw the first jobs without running them
 job_no = 0
 
@@ -43,7 +43,7 @@ def announce(text):
 fmi_idx = {}                                                    # genome length -> (genome, index): built once per size
 n_multi = 0
 while time.time() < t_end:
-    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "abea", "fmi"])
+    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "poa", "abea", "fmi", "combo"])
     seed = int(rng.integers(1, 1 << 30))
     job_no += 1
     ok, what = True, ""
@@ -140,10 +140,56 @@ while time.time() < t_end:
         if announce("abea seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
             (go, gn), (wo, wn) = align_host(rs), O.abea_oracle(rs, 16)
             ok = np.array_equal(gn, wn) and all(np.array_equal(g, w) for g, w in zip(rs.split_pairs(go, gn), rs.split_pairs(wo, wn)))
+    elif k == "combo":
+        # round 6: small calls of one kernel from several threads at once - the host entries combine them (csrc/host_combine.h);
+        # every caller must get the results of its own call
+        import threading
+        kind = str(rng.choice(["bsw", "phmm", "poa"]))
+        T = int(rng.choice([2, 3, 8, 16]))
+        rounds = int(rng.choice([1, 3]))
+        if kind == "bsw":
+            jobs = [gen_bsw(int(rng.choice([1, 64, 512, 3000])), seed + t) for t in range(T)]
+            prm = [bsw_params() if rng.random() < 0.7 else bsw_params(zdrop=20, w=30) for _ in range(T)]
+            call = lambda t: extend_host(prm[t], jobs[t])
+            want = [O.bsw_oracle(prm[t], jobs[t], 4) for t in range(T)]
+            same_as = lambda g, w: np.array_equal(g, w)
+        elif kind == "phmm":
+            jobs = [gen_phmm(int(rng.choice([1, 2, 5])), seed + t) for t in range(T)]
+            call = lambda t: forward_host(jobs[t])
+            want = [O.phmm_oracle(jobs[t], 4) for t in range(T)]
+            same_as = lambda g, w: bool(np.all(np.abs(g - w) <= 1e-5 * np.maximum(1, np.abs(w)) + 5e-7))
+        else:
+            pps = [poa_params() if rng.random() < 0.7 else poa_params(o1=0, e1=2) for _ in range(T)]
+            jobs = [gen_poa(int(rng.choice([1, 2])), seed + t) for t in range(T)]
+            call = lambda t: consensus_host(pps[t], jobs[t])
+            want = [O.poa_oracle(pps[t], jobs[t], 4) for t in range(T)]
+            same_as = lambda g, w: g == w
+        what = "combo kind=%s threads=%d rounds=%d" % (kind, T, rounds)
+        if announce("combo seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
+            for _ in range(rounds):
+                got = [None] * T
+
+                def work(t):
+                    try:
+                        got[t] = call(t)
+                    except Exception as e:      # noqa: BLE001
+                        got[t] = e
+                th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                ok = ok and all(not isinstance(g, Exception) and same_as(g, w) for g, w in zip(got, want))
     else:
         nw = int(rng.choice([1, 5, 40]))
         ws = gen_poa(nw, seed)
-        pp = poa_params()
+        # round 6: spoa's three gap subtypes (linear when g >= e), and the int32 wide path forced onto ordinary windows
+        sub = rng.random()
+        pp = poa_params() if sub < 0.5 else poa_params(o1=0, e1=int(rng.choice([1, 2, 4]))) if sub < 0.75 else poa_params(o2=4, e2=2)
+        if rng.random() < 0.2 and nw <= 5:
+            os.environ["GBX_POA_FORCE_WIDE"] = "1"
+            if rng.random() < 0.5:
+                os.environ["GBX_POA_WIDE_SLOTS"] = "2"
         lock = rng.random() < 0.4                                # the lock-step form (default: the window kernel with the row ring)
         if lock:
             os.environ["GBX_POA_LOCKSTEP"] = "1"
@@ -151,13 +197,14 @@ while time.time() < t_end:
             os.environ["GBX_POA_DP_OCC"] = str(int(rng.choice([5, 6])))
         elif rng.random() < 0.4:                                 # (default: the team kernel; here one wavefront per window, or a mix)
             os.environ[str(rng.choice(["GBX_POA_TEAM", "GBX_POA_TEAM_MAX"]))] = "0"
-        what = "windows=%d lockstep=%s tb_serial=%s dp_occ=%s team=%s team_max=%s" % (nw, lock, os.environ.get("GBX_POA_TB_SERIAL"), os.environ.get("GBX_POA_DP_OCC"),
-                                                                                     os.environ.get("GBX_POA_TEAM"), os.environ.get("GBX_POA_TEAM_MAX"))
+        what = "windows=%d lockstep=%s tb_serial=%s dp_occ=%s team=%s team_max=%s scores=(g %d e %d q %d c %d) wide=%s" % (
+            nw, lock, os.environ.get("GBX_POA_TB_SERIAL"), os.environ.get("GBX_POA_DP_OCC"), os.environ.get("GBX_POA_TEAM"), os.environ.get("GBX_POA_TEAM_MAX"),
+            pp.g, pp.e, pp.q, pp.c, os.environ.get("GBX_POA_FORCE_WIDE"))
         run = announce("poa seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what))
         try:
             ok = not run or consensus_host(pp, ws) == O.poa_oracle(pp, ws, 8)
         finally:
-            for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC", "GBX_POA_TEAM", "GBX_POA_TEAM_MAX"):
+            for v in ("GBX_POA_LOCKSTEP", "GBX_POA_TB_SERIAL", "GBX_POA_DP_OCC", "GBX_POA_TEAM", "GBX_POA_TEAM_MAX", "GBX_POA_FORCE_WIDE", "GBX_POA_WIDE_SLOTS"):
                 os.environ.pop(v, None)
     what += " devices=%d min_units=%s" % (ndev, os.environ.get("GBX_SHARD_MIN_UNITS"))
     count[k] += 1
