@@ -1031,6 +1031,9 @@ RowKernel row_kernels[] = {
     GBX_ROW_KERNEL(16, 10), GBX_ROW_KERNEL(16, 12), GBX_ROW_KERNEL(16, 16), GBX_ROW_KERNEL(64, 16),
     // ... and alternatives for scripts/tune_bsw_shapes.sh
     GBX_ROW_KERNEL(4, 8), GBX_ROW_KERNEL(4, 12), GBX_ROW_KERNEL(8, 10), GBX_ROW_KERNEL(8, 12), GBX_ROW_KERNEL(16, 8),
+    // ... and for the direct launch of small jobs (bsw_launch_direct): a job of a few hundred pairs is as long as one pair's rows,
+    // so its pairs get many lanes and few columns each
+    GBX_ROW_KERNEL(64, 3), GBX_ROW_KERNEL(64, 4),
 };
 #undef GBX_ROW_KERNEL
 // widest query a class holds: classes 0..7 = 16,32,..,128; 8..11 = 160,192,256,1024
@@ -1192,9 +1195,19 @@ int bsw_launch_direct(const gbx_bsw_params *p, int64_t n, int max_qlen,
     BswWork W = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     dev.lane_on = 0;
     if (max_qlen > 256) { set_error("bsw: direct launch needs queries of at most 256"); return GBX_ERR_ARG; }
-    const int lpp = max_qlen <= 128 ? 8 : 16;
-    RowKernel *k = find_row_kernel(lpp, 16);
-    if (!k) { set_error("bsw: no %dx16 row kernel", lpp); return GBX_ERR_UNSUPPORTED; }
+    // A job this small is as long as its slowest pair's rows, and a row's time grows with the columns a lane holds: many lanes per
+    // pair, few columns each.  Measured (profiles/r06q_bsw_direct_shapes.txt, 151-bp pairs, whole host call): 512 pairs 0.340 ms on
+    // 16x16, 0.261 on 16x10, 0.216 on 64x3; 8 192 pairs 0.550 / 0.448 / 0.589 - a wavefront per pair up to a few thousand pairs,
+    // then the narrowest sixteen-lane shape that holds the longest query.
+    const int cols = max_qlen + 1;
+    int lpp = 16, cpl = cols <= 128 ? 8 : cols <= 160 ? 10 : cols <= 192 ? 12 : 16;
+    if (n < 4096) { lpp = 64; cpl = cols <= 192 ? 3 : 4; }
+    if (const char *e = getenv("GBX_BSW_DIRECT_SHAPE")) {        /* tuning aid: "LxC", must cover max_qlen + 1 columns */
+        int l = 0, c = 0;
+        if (sscanf(e, "%dx%d", &l, &c) == 2 && l * c > max_qlen && find_row_kernel(l, c)) { lpp = l; cpl = c; }
+    }
+    RowKernel *k = find_row_kernel(lpp, cpl);
+    if (!k) { set_error("bsw: no %dx%d row kernel", lpp, cpl); return GBX_ERR_UNSUPPORTED; }
     const bool sym = dev.oe_ins == dev.oe_del;
     const int gpb = 256 / lpp;                                // groups (pairs in flight) per block
     const int blocks = (int)((n + gpb - 1) / gpb);

@@ -460,7 +460,9 @@ int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t
     for (int t = 0; t < T; ++t) { part_r[(size_t)t + 1] += part_r[(size_t)t]; part_q[(size_t)t + 1] += part_q[(size_t)t]; }
     const int64_t packed_r = part_r[(size_t)T], packed_q = part_q[(size_t)T];
     std::vector<uint8_t> cref, cqer;
-    const bool sparse = n >= 4096 && (ref_bytes + qer_bytes) > 2 * (packed_r + packed_q) + ((int64_t)1 << 20);
+    // (small calls too: the driver's 512-pair batch spans 1.1 MB of slots for 180 KB of bases, and a call that size is mostly the
+    // copy into the pinned slab and the DMA)
+    const bool sparse = (ref_bytes + qer_bytes) > 2 * (packed_r + packed_q) + ((int64_t)64 << 10);
     if (sparse) {
         cref.resize((size_t)packed_r + 8); cqer.resize((size_t)packed_q + 8);
         // same thread ranges as above, so every thread knows where its pairs start in the packed arenas

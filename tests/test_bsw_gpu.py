@@ -329,3 +329,24 @@ def test_lane_packed_chunk_followed_by_unpacked_chunk(lane, monkeypatch, where):
 def test_lane_generated_reads_and_ragged_last_chunk(lane):
     b = gen_bsw(30_011, 77)                        # not a multiple of 64 in any length class
     assert_same(extend_host(make_params(), b), O.bsw_oracle(make_params(), b, 8), b)
+
+
+@pytest.mark.parametrize("n,max_q", [(300, 100), (700, 159), (1500, 191), (2000, 255), (5000, 120), (6000, 159), (7000, 190), (9000, 250)])
+def test_direct_launch_shapes(n, max_q, monkeypatch):
+    """Small plain jobs (every query 1..256, <= 16 384 pairs) are one launch of a row kernel whose shape follows the job: a wavefront
+    per pair (64x3 / 64x4) below 4 096 pairs, else the narrowest sixteen-lane shape that holds the longest query (16x8 .. 16x16).
+    Every shape against the oracle on adversarial pairs, and the forced shapes of the tuning switch."""
+    monkeypatch.delenv("GBX_BSW_DIRECT", raising=False)
+    monkeypatch.setenv("GBX_COMBINE", "0")
+    p = make_params()
+    b = adversarial_bsw(n, 100 + max_q, max_q=max_q, max_t=max_q + 200)
+    assert int(b.len2.max()) <= 256 and int(b.len2.min()) >= 1
+    want = O.bsw_oracle(p, b, 4)
+    N.profile_begin()
+    got = extend_host(p, b)
+    prof = N.profile_end(64)
+    assert_same(got, want, b)
+    assert len(prof) == 1 and list(prof)[0].startswith("bsw_rows_64x" if n < 4096 else "bsw_rows_16x"), prof
+    for shape in ("64x4", "16x16"):
+        monkeypatch.setenv("GBX_BSW_DIRECT_SHAPE", shape)
+        assert_same(extend_host(p, b), want, b)
