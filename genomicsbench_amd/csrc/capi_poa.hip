@@ -301,14 +301,17 @@ static int poa_host_wide(const gbx_poa_params *p, const std::vector<int64_t> &li
         if ((rc = dwf.alloc((size_t)(nr + 1) * 8)) || (rc = doff.alloc((size_t)ns * 8)) || (rc = dlen.alloc((size_t)ns * 4)) ||
             (rc = dcons.alloc((size_t)nr * (size_t)cons_stride)) || (rc = dcl.alloc((size_t)nr * 4)) || (rc = dst.alloc((size_t)nr * 4)))
             return rc;
+        std::vector<char> c2((size_t)nr * (size_t)cons_stride);
+        std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);
+        struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{st};      // whatever path leaves this pass
         GBX_HIP(hipMemcpyAsync(dwf.p, wf.data(), (size_t)(nr + 1) * 8, hipMemcpyHostToDevice, st));
         GBX_HIP(hipMemcpyAsync(doff.p, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, st));
         GBX_HIP(hipMemcpyAsync(dlen.p, len.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
         if ((rc = poa_launch_wide(p, nr, dwf.as<int64_t>(), doff.as<int64_t>(), dlen.as<int32_t>(), dar.as<uint8_t>(), dcons.as<uint8_t>(),
-                                  dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, (int)cap, deg, lmax, (int)slots, dw.p, wb, st)))
+                                  dcl.as<int32_t>(), dst.as<int32_t>(), cons_stride, (int)cap, deg, lmax, (int)slots, dw.p, wb, st))) {
+            (void)hipStreamSynchronize(st);                  // (the index arrays above are this scope's: nothing may still be reading them)
             return rc;
-        std::vector<char> c2((size_t)nr * (size_t)cons_stride);
-        std::vector<int32_t> l2((size_t)nr), s2((size_t)nr);
+        }
         GBX_HIP(hipMemcpyAsync(c2.data(), dcons.p, c2.size(), hipMemcpyDeviceToHost, st));
         GBX_HIP(hipMemcpyAsync(l2.data(), dcl.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
         GBX_HIP(hipMemcpyAsync(s2.data(), dst.p, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
