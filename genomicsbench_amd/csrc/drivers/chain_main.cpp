@@ -6,12 +6,39 @@
 #include <unistd.h>
 #include "driver_common.h"
 
-static void help() { fprintf(stderr, "usage: chain -i <input> -o <output> [-t threads] [--print]\n"); }
+static void help() { fprintf(stderr, "usage: chain -i <input> -o <output> [-t threads] [--print] [--cache <file>]\n"); }
+
+// the call: poff / pax / pay / phdr are the parsed arrays or, with --cache on a later run of the same input, the mapped ones
+static int run_calls(int gpus, int64_t nc, int64_t na, const int64_t *poff, const uint64_t *pax, const uint64_t *pay, const gbx_chain_call *phdr,
+                     bool print, FILE *fo)
+{
+    print_device_banner(gpus);
+    std::vector<int32_t> score((size_t)na + 1), parent((size_t)na + 1);
+    if (nc > 0) {                                               // warm-up on the first call only
+        int64_t o2[2] = {0, poff[1]};
+        die_on(gbx_chain_host(1, o2, pax, pay, phdr, score.data(), parent.data(), nullptr, nullptr), "gbx_chain_host");
+    }
+    const double t0 = now_s();
+    die_on(gbx_chain_host(nc, poff, pax, pay, phdr, score.data(), parent.data(), nullptr, nullptr), "gbx_chain_host");
+    const double dt = now_s() - t0;
+    if (print && fo) {
+        for (int64_t c = 0; c < nc; ++c) {
+            fprintf(fo, "%lld\n", (long long)(poff[c + 1] - poff[c]));
+            for (int64_t i = poff[c]; i < poff[c + 1]; ++i) fprintf(fo, "%d\t%d\n", score[i], parent[i]);
+            fprintf(fo, "EOR\n");
+        }
+    }
+    fprintf(stderr, "Time in kernel: %.2f sec\n", dt);
+    printf("{\"benchmark\":\"chain\",\"calls\":%lld,\"anchors\":%lld,\"seconds\":%.6f,\"manchors_per_s\":%.3f}\n",
+           (long long)nc, (long long)na, dt, na / dt / 1e6);
+    if (fo) fclose(fo);
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
     const int gpus = take_gpus_flag(argc, argv);
-    std::string in, outp;
+    std::string in, outp, cache;
     bool print = false, parse_only = false;
     int threads = 1;
     for (int i = 1; i < argc; ++i) {
@@ -20,12 +47,26 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--print")) print = true;
         else if (!strcmp(argv[i], "--parse-only")) parse_only = true;
+        else if (!strcmp(argv[i], "--cache") && i + 1 < argc) cache = argv[++i];
         else if (!strcmp(argv[i], "-h")) { help(); return 0; }
         else { help(); return 1; }
     }
     if (threads < 1) threads = 1;
     if (argc == 1) { help(); return EXIT_FAILURE; }
     fprintf(stderr, "Input file: %s\nOutput file: %s\n", in.c_str(), outp.c_str());
+    // --cache FILE (round 6, SURVEY 8f rank 1 "binary cache"; driver_common.h: InputCache): the converted arrays - offsets, x, y,
+    // headers - written after the first conversion, mapped by later runs of the same input instead of parsing a gigabyte of text
+    InputCache icache;
+    if (!cache.empty() && !parse_only && icache.open(cache.c_str(), in.c_str(), 0x6e696863 /* "chin" */, 4)) {
+        const int64_t nc = (int64_t)(icache.sec[0].second / 8) - 1, na = (int64_t)(icache.sec[1].second / 8) - 1;
+        if (nc < 0 || na < 0 || icache.sec[2].second != icache.sec[1].second || icache.sec[3].second != (size_t)nc * sizeof(gbx_chain_call)) {
+            fprintf(stderr, "%s: malformed cache\n", cache.c_str());
+            return EXIT_FAILURE;
+        }
+        fprintf(stderr, "Input arrays mapped from the cache %s\n", cache.c_str());
+        return run_calls(gpus, nc, na, (const int64_t *)icache.sec[0].first, (const uint64_t *)icache.sec[1].first, (const uint64_t *)icache.sec[2].first,
+                         (const gbx_chain_call *)icache.sec[3].first, print, fopen(outp.c_str(), "w"));
+    }
     std::vector<char> text;
     if (!slurp(in.c_str(), text)) { fprintf(stderr, "cannot open %s\n", in.c_str()); return EXIT_FAILURE; }
     FILE *fo = fopen(outp.c_str(), "w");
@@ -101,25 +142,8 @@ int main(int argc, char **argv)
         return 0;
     }
     fprintf(stderr, "Ingest: %.2f s with %d thread(s)\n", t_read, threads);
-    print_device_banner(gpus);
-    std::vector<int32_t> score((size_t)na + 1), parent((size_t)na + 1);
-    if (nc > 0) {                                               // warm-up on the first call only
-        int64_t o2[2] = {0, off[1]};
-        die_on(gbx_chain_host(1, o2, ax.data(), ay.data(), hdr.data(), score.data(), parent.data(), nullptr, nullptr), "gbx_chain_host");
-    }
-    const double t0 = now_s();
-    die_on(gbx_chain_host(nc, off.data(), ax.data(), ay.data(), hdr.data(), score.data(), parent.data(), nullptr, nullptr), "gbx_chain_host");
-    const double dt = now_s() - t0;
-    if (print && fo) {
-        for (int64_t c = 0; c < nc; ++c) {
-            fprintf(fo, "%lld\n", (long long)(off[c + 1] - off[c]));
-            for (int64_t i = off[c]; i < off[c + 1]; ++i) fprintf(fo, "%d\t%d\n", score[i], parent[i]);
-            fprintf(fo, "EOR\n");
-        }
-    }
-    fprintf(stderr, "Time in kernel: %.2f sec\n", dt);
-    printf("{\"benchmark\":\"chain\",\"calls\":%lld,\"anchors\":%lld,\"seconds\":%.6f,\"manchors_per_s\":%.3f}\n",
-           (long long)nc, (long long)na, dt, na / dt / 1e6);
-    if (fo) fclose(fo);
-    return 0;
+    if (!cache.empty() && !InputCache::write(cache.c_str(), in.c_str(), 0x6e696863, {{off.data(), (size_t)(nc + 1) * 8}, {ax.data(), (size_t)(na + 1) * 8},
+                                                                                     {ay.data(), (size_t)(na + 1) * 8}, {hdr.data(), (size_t)nc * sizeof(gbx_chain_call)}}))
+        fprintf(stderr, "warning: could not write the cache %s\n", cache.c_str());
+    return run_calls(gpus, nc, na, off.data(), ax.data(), ay.data(), hdr.data(), print, fo);
 }

@@ -220,6 +220,29 @@ def test_chain_driver_end_to_end(data):
 
 
 @pytest.mark.gpu
+def test_drivers_with_binary_input_cache(data, tmp_path):
+    """`--cache FILE` (optional): the first run converts the text and writes the arrays, the second maps them -
+    both give the output of a run without a cache; bsw through --dump, chain through its output file."""
+    d = data[0]
+    ref_out, c1, c2 = str(tmp_path / "plain.out"), str(tmp_path / "first.out"), str(tmp_path / "second.out")
+    cache = str(tmp_path / "chain.gbxcache")
+    assert run([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", ref_out, "--print"]).returncode == 0
+    r1 = run([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", c1, "--print", "-t", "3", "--cache", cache])
+    r2 = run([os.path.join(BIN, "chain"), "-i", str(d / "chain.in"), "-o", c2, "--print", "--cache", cache])
+    assert r1.returncode == 0 and r2.returncode == 0 and "mapped from the cache" not in r1.stderr and "mapped from the cache" in r2.stderr, r1.stderr + r2.stderr
+    assert open(c1).read() == open(ref_out).read() == open(c2).read()
+    bcache = str(tmp_path / "bsw.gbxcache")
+    dumps = []
+    for k in range(3):
+        dump = str(tmp_path / ("bsw%d.txt" % k))
+        args = [os.path.join(BIN, "bsw"), "-pairs", str(d / "pairs.txt"), "-t", "2", "-b", "512", "--dump", dump] + (["--cache", bcache] if k else [])
+        r = run(args)
+        assert r.returncode == 0 and ("mapped from the cache" in r.stdout) == (k == 2), r.stdout + r.stderr
+        dumps.append(open(dump).read())
+    assert dumps[0] == dumps[1] == dumps[2] and len(dumps[0]) > 100
+
+
+@pytest.mark.gpu
 def test_phmm_driver_end_to_end(data):
     d, ph = data[0], data[3]
     r = run([os.path.join(BIN, "phmm"), "-f", str(d / "phmm.in"), "-t", "1", "--print"])
