@@ -1197,6 +1197,12 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
     // bj-8..bj-1, one cell per lane, with the row's descriptor and the column's letter): a run of diagonal moves
     // to first predecessors is served from registers, one gather per 4-5 steps instead of one round trip each.
     int bi = -(1 << 20), bj = -(1 << 20), bH = 0, bP0 = 0, bInfo = 0, bNode = 0, bS = 0;
+    // LD == 1 (round 6): the block's rows also carry the rows of their SECOND and THIRD in-edge sources (the team's descriptor copy
+    // in LDS has them), so a diagonal move to one of those - a read that follows a side branch of the graph: most of the steps the
+    // block could not serve - is taken from the registers too when that row lies in the block (95 % of second sources are within
+    // six rows).  The in-edge order of the reference's test is kept: source p is tried only after sources 0..p-1 failed,
+    // and a source outside the block hands the step to the general path.
+    int bP1 = 0, bP2 = 0, d_p1 = 0, d_p2 = 0;
 #ifdef GBX_POA_PHASE_STATS
     unsigned long long tb_fast_ = 0, tb_slow_ = 0, tb_fill_ = 0;
 #endif
@@ -1209,6 +1215,7 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         bH = PG_AT(M.H, row, col);
         const int dr = max(row - 1, 0);
         bP0 = desc_p0(dr); bInfo = d_info_of(dr); bNode = d_node_of(dr);
+        if (LD == 1) { bP1 = (int)ldesc[ldn + dr]; bP2 = (int)ldesc[2 * ldn + dr]; }
         bS = seq[col];
     };
     while (!(i == 0 && j == 0)) {
@@ -1228,8 +1235,38 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
                     i = p0f; j = j - 1; Hcur = hd;
                     d_p0 = __builtin_amdgcn_readlane(bP0, L); d_info = __builtin_amdgcn_readlane(bInfo, L);
                     d_node = __builtin_amdgcn_readlane(bNode, L); d_known = p0f > 0;
+                    if (LD == 1) { d_p1 = __builtin_amdgcn_readlane(bP1, L); d_p2 = __builtin_amdgcn_readlane(bP2, L); }
                     if (np > g.aln_path_cap) { g.err |= POA_ERR_NODES; break; }
                     continue;
+                }
+#ifndef GBX_POA_TB_BLOCK23
+#define GBX_POA_TB_BLOCK23 1          // 0: the block serves first in-edge sources only (round 5), for A/B builds
+#endif
+                if (LD == 1 && GBX_POA_TB_BLOCK23) {
+                    const int icf = (d_info >> 8) & 0xff;
+                    int took = -1, Lt = 0, ht = 0;
+#pragma unroll
+                    for (int p = 1; p < 3; ++p) {
+                        if (took >= 0 || p >= icf) break;
+                        const int pp = p == 1 ? d_p1 : d_p2;
+                        const int rp = bi - 1 - pp;
+                        if ((unsigned)rp >= 8u) break;               // that source's row is not in the block: the general path goes on from here
+                        const int Lp = rp * 8 + cc;
+                        const int hp = __builtin_amdgcn_readlane(bH, Lp);
+                        if (Hcur == hp + mc) { took = pp; Lt = Lp; ht = hp; }
+                    }
+                    if (took >= 0) {
+#ifdef GBX_POA_PHASE_STATS
+                        ++tb_fast_;
+#endif
+                        PG_PUSH(d_node, j - 1);
+                        i = took; j = j - 1; Hcur = ht;
+                        d_p0 = __builtin_amdgcn_readlane(bP0, Lt); d_info = __builtin_amdgcn_readlane(bInfo, Lt);
+                        d_node = __builtin_amdgcn_readlane(bNode, Lt); d_known = took > 0;
+                        d_p1 = __builtin_amdgcn_readlane(bP1, Lt); d_p2 = __builtin_amdgcn_readlane(bP2, Lt);
+                        if (np > g.aln_path_cap) { g.err |= POA_ERR_NODES; break; }
+                        continue;
+                    }
                 }
             }
         }
@@ -1240,13 +1277,18 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
         bool found = false, ext_left = false, ext_up = false;
         int node = -1, ic = 0, p0 = 0;
         int n_p0 = 0, n_info = 0, n_node = 0, Hnext = 0, info = 0;
+        int c_p1 = 0, c_p2 = 0, n_p1 = 0, n_p2 = 0;           // (LD == 1) rows of the second / third in-edge source: of this row, of the first source's row
         bool hn_known = false, dn_first = false;          // next step: H known / descriptor = the prefetched one
         if (i != 0) {
-            if (d_known) { p0 = d_p0; info = d_info; node = d_node; }
-            else { p0 = desc_p0(i - 1); info = d_info_of(i - 1); node = d_node_of(i - 1); }
+            if (d_known) { p0 = d_p0; info = d_info; node = d_node; c_p1 = d_p1; c_p2 = d_p2; }
+            else {
+                p0 = desc_p0(i - 1); info = d_info_of(i - 1); node = d_node_of(i - 1);
+                if (LD == 1) { c_p1 = (int)ldesc[ldn + i - 1]; c_p2 = (int)ldesc[2 * ldn + i - 1]; }
+            }
             ic = (info >> 8) & 0xff;
             const int pr = p0 > 0 ? p0 - 1 : 0;            // descriptor of the first predecessor's row, in flight with its cell
             n_p0 = desc_p0(pr); n_info = d_info_of(pr); n_node = d_node_of(pr);
+            if (LD == 1) { n_p1 = (int)ldesc[ldn + pr]; n_p2 = (int)ldesc[2 * ldn + pr]; }
             if (j != 0) {
                 const int mc = (info & 0xff) == seq[j - 1] ? S.m : S.n;
                 int pfirst = 0;
@@ -1296,8 +1338,8 @@ __device__ __attribute__((always_inline)) void poa_traceback_wave(PoaGraph &g, c
             if (c1 || c2 || c3 || c4) { prev_i = i; prev_j = j - 1; found = true; Hnext = hv; hn_known = true; same_row = i != 0; }
         }
         // state for the next step
-        if (same_row) { d_p0 = p0; d_info = info; d_node = node; d_known = true; }
-        else if (dn_first) { d_p0 = n_p0; d_info = n_info; d_node = n_node; d_known = true; }
+        if (same_row) { d_p0 = p0; d_info = info; d_node = node; d_p1 = c_p1; d_p2 = c_p2; d_known = true; }
+        else if (dn_first) { d_p0 = n_p0; d_info = n_info; d_node = n_node; d_p1 = n_p1; d_p2 = n_p2; d_known = true; }
         else d_known = false;
         Hcur = Hnext; h_known = hn_known && !ext_left && !ext_up;
         if (ext_left || ext_up) d_known = d_known && ext_left;      // the extension loops below move on; a left run stays in the row

@@ -33,6 +33,9 @@ for n in sizes:
         if tot:
             line += " | wave clocks: DP %.1f%% traceback %.1f%% add %.1f%% consensus %.1f%%; %.0f clocks per DP row, %.0f per traceback step" % (
                 100 * dp / tot, 100 * tb / tot, 100 * add / tot, 100 * cons / tot, dp / max(int(c[12]), 1), tb / max(int(c[13]), 1))
+            if int(c[28]) + int(c[29]):       # traceback steps served from the register block / by the general path, block refills
+                line += "; traceback steps: %.1f%% from the block, %.1f%% general, a refill per %.1f block steps" % (
+                    100 * int(c[28]) / (int(c[28]) + int(c[29])), 100 * int(c[29]) / (int(c[28]) + int(c[29])), int(c[28]) / max(int(c[30]), 1))
     print(line, flush=True)
     del d
     torch.cuda.empty_cache()
