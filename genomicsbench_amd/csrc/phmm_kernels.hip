@@ -91,6 +91,7 @@ struct PhmmWork {
     // stream path (reads of <= stream_rows rows), all indexed by read id unless noted
     int32_t stream_rows; // STREAM_MAX_ROWS, or 0 for small jobs: every pair takes the one-pair-per-wavefront kernels
     int32_t seg_max;     // pairs per unit of the stream path (SEG_MAX_PAIRS; fewer for jobs too small to fill the chip with long units)
+    int32_t lut;         // 1: the stream holds symbol codes (phmm_sym_code) and the stream kernels take the priors from LDS tables
     int64_t n_reads;
     int32_t *rcount;     // pairs of the read
     int32_t *rslen;      // stream symbols of the read: sum (H+1)
@@ -477,22 +478,49 @@ __global__ void __launch_bounds__(256) phmm_unit_walk_kernel(PhmmArgs A, PhmmWor
     for (; off < end; ++off) W.stream[off] = 0;
 }
 
-// One wavefront per grouped pair: boundary byte + haplotype bytes into the read's stream.  The body is
+// Symbol codes of the stream in its table form (PhmmWork::lut): 0 = boundary, 1..5 = A C T G N.  The priors of a cell depend on
+// the haplotype symbol only through "equal to the read's base, or one of them N" (PairHMMUnitTest.cpp's scalar semantics, literal
+// bytes); with the five symbols the reference's tables know (pairhmm_common.h:34-38) that is a table of six entries per read row,
+// built once per unit.  A haplotype with any other byte cannot be coded: its pair gets Y[0][*] = 0, so that its fp32 sum is an
+// exact zero and the pair goes to the fp64 pass, which compares literal bytes.
+constexpr int PHMM_SYMS = 6;                                 // 0 = boundary, 1..5 = A C T G N (phmm_sym_char)
+// Four bytes at a time: bits 1-3 of the five letters are distinct (A 0, C 1, T 2, G 3, N 7), so they select the code and - to tell a
+// letter from any other byte with the same three bits - the letter itself out of two eight-byte tables (v_perm_b32).
+__device__ constexpr int phmm_sym_char(int code) { return code == 1 ? 'A' : code == 2 ? 'C' : code == 3 ? 'T' : code == 4 ? 'G' : code == 5 ? 'N' : -1; }
+__device__ inline uint32_t phmm_sym_code4(uint32_t w, bool &bad)
+{
+    const uint32_t x = (w >> 1) & 0x07070707u;
+    const uint32_t code = __builtin_amdgcn_perm(0x05010101u, 0x04030201u, x);              // entries 7..4 | 3..0
+    const uint32_t canon = __builtin_amdgcn_perm(0x4e000000u, 0x47544341u, x);             // 'N' 0 0 0 | 'G' 'T' 'C' 'A'
+    bad |= canon != w;
+    return code;
+}
+__device__ inline uint32_t phmm_sym_code(uint32_t c, bool &bad)
+{
+    bool b4 = false;
+    const uint32_t k = phmm_sym_code4(c | 0x41414100u, b4) & 0xff;                          // (the upper bytes: 'A's)
+    bad |= b4;
+    return k;
+}
+
+// One wavefront per grouped pair: boundary byte + haplotype bytes (or their symbol codes) into the read's stream.  The body is
 // copied as aligned 4-byte words of the destination; a source word straddles two aligned source words and
 // is put together with v_alignbyte (the haplotype arena must be readable a few bytes past its end).
 __global__ void __launch_bounds__(256) phmm_stream_copy_kernel(PhmmArgs A, PhmmWork W)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = W.next[0];
+    const bool lut = W.lut != 0;
     for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < n; j += (int64_t)gridDim.x * 4) {
         const int hp = A.pair_hap[W.porder[j]];
         const int H = A.hap_len[hp];
         const uint8_t *src = A.hap + A.hap_off[hp];
         uint8_t *dst = W.stream + W.soff[j];
+        bool bad = false;
         if (lane == 0) dst[0] = 0;
         ++dst;                                                  // haplotype bytes follow the boundary byte
         const int head = min(H, (int)((4 - ((uintptr_t)dst & 3)) & 3));
-        if (lane < head) dst[lane] = src[lane];
+        if (lane < head) dst[lane] = lut ? (uint8_t)phmm_sym_code(src[lane], bad) : src[lane];
         const int nw = (H - head) >> 2;                         // aligned destination words
         const uint8_t *sb = src + head;
         const int m = (int)((uintptr_t)sb & 3);
@@ -500,10 +528,12 @@ __global__ void __launch_bounds__(256) phmm_stream_copy_kernel(PhmmArgs A, PhmmW
         uint32_t *d32 = (uint32_t *)(dst + head);
         for (int t = lane; t < nw; t += 64) {
             const uint32_t lo = s32[t], hi = s32[t + 1];
-            d32[t] = m ? __builtin_amdgcn_alignbyte(hi, lo, (unsigned)m) : lo;
+            const uint32_t w = m ? __builtin_amdgcn_alignbyte(hi, lo, (unsigned)m) : lo;
+            d32[t] = lut ? phmm_sym_code4(w, bad) : w;
         }
         const int done = head + 4 * nw;
-        if (lane < H - done) dst[done + lane] = src[done + lane];
+        if (lane < H - done) dst[done + lane] = lut ? (uint8_t)phmm_sym_code(src[done + lane], bad) : src[done + lane];
+        if (lut && __any(bad) && lane == 0) W.yin[j] = 0.f;
     }
 }
 
@@ -517,9 +547,24 @@ __global__ void __launch_bounds__(256) phmm_stream_copy_kernel(PhmmArgs A, PhmmW
 // A 0 byte is DP column 0 of the next haplotype: every slot that meets it resets to zero, the lane that
 // owns the last read row emits the finished sum.  Unused slots below the last row (same lane) copy M+X
 // downwards (pMX = pXX = 1), so the sum is always read from slot RPL-1 of that lane.
-template <int RPL>
+//
+// LUT (round 6): the prior of a cell - `(h == base || h == 'N' || base == 'N') ? 1 - e : e / 3` - was a compare and a select per
+// cell, two of the ten instructions of a cell and both of the half-rate kind (profiles/valu_peak.json: 4.2 against 2.25 SIMD
+// cycles).  With the stream in symbol codes the lane looks its RPL priors up instead: a table of PHMM_SYMS x RPL floats per lane
+// in LDS (entry (sym, k) of lane l at word (sym * RPL + k) * 64 + l: every lane its own bank whatever the symbols), written once
+// per unit, read with one address (`sym * RPL * 256 + 4 * lane`, a v_mad) and RPL immediate offsets per step.  7.5 KB a wavefront
+// at RPL = 5: the sixteen wavefronts per CU the kernel's registers allow fit the CU's 160 KB.
+#ifndef GBX_PHMM_SFEED
+#define GBX_PHMM_SFEED 1            // 0: the table form takes its symbols from vector registers like the other (A/B builds)
+#endif
+#ifndef GBX_PHMM_CARRY
+#define GBX_PHMM_CARRY 0            // 1: the table form carries the diagonal M, X over from the step before (its uM, uX) instead of shifting them in again: one instruction MORE per step - the shifts it saves were operand modifiers of a multiply, the carried values need moves of their own
+#endif
+template <int RPL, bool LUT>
 __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W, int cls)
 {
+    constexpr bool SFEED = LUT && GBX_PHMM_SFEED, CARRY = LUT && GBX_PHMM_CARRY;
+    __shared__ float lut[LUT ? PHMM_SYMS * RPL * 64 : 1];
     const int lane = threadIdx.x, hl = lane & 31, half = lane >> 5;
     const int ufirst = W.ubase[cls * UBUCKETS];
     const int ucnt = W.ubase[(cls + 1) * UBUCKETS] - ufirst;
@@ -577,29 +622,95 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
             }
 #pragma unroll
             for (int v = 0; v < 3; ++v) { S0[v][k] = zero; S1[v][k] = zero; }
+            if (LUT) {
+                // (entry 0, the boundary symbol: any finite value - the slots that meet it are reset; px[k] is pm[k] already when the base is N)
+#pragma unroll
+                for (int y = 0; y < PHMM_SYMS; ++y) lut[(y * RPL + k) * 64 + lane] = (phmm_sym_char(y) == rch[k] || y == 5) ? pm[k] : px[k];
+            }
         }
         int kk = 0;                                            // boundaries this lane has met
         float ycur = zero, ynext = W.yin[first];
         float acc = zero;                                      // sum over the columns of the current haplotype (lane llast)
         int h = 1;                                             // symbol of this lane's column (1: nothing yet, matches nothing)
         // symbol words: w0 holds the symbols of this group of 4 steps (after the skew shift), w1/w2 the next words
-        uint32_t wa = wp[0], wb = wp[1], wc = wp[2];
+        uint32_t wa = 0, wb = 0, wc = 0;
+        if (!SFEED) { wa = wp[0]; wb = wp[1]; wc = wp[2]; }
+        // LUT: the priors are looked up one step ahead (the first of them feeds the chain m -> x of the row below -> ... at the very
+        // start of a step): hn = this lane's symbol of the coming step, dnx[] its priors, on their way from LDS during the step before
+        // (a symbol travels down the lanes as its table's byte offset, SYM_STEP per code: the look-up address is one OR away, and 0
+        // is still the boundary)
+        constexpr int SYM_STEP = RPL * 64 * 4;
+        int hn = SYM_STEP;
+        float dnx[RPL];
+        const int lane4 = lane * 4;
+        auto lookup = [&](int symoff) {
+            const float *lp = (const float *)((const char *)lut + (symoff | lane4));
+#pragma unroll
+            for (int k = 0; k < RPL; ++k) dnx[k] = lp[k * 64];
+        };
+        // LUT: the symbols of the two top lanes are fed from scalar registers - the two units' stream words come by scalar loads, the
+        // skew shift, the end-of-unit guard, the byte extracts and the scaling are scalar instructions, and a step writes its two
+        // symbols into lanes 0 and 32 (v_writelane) - where the other form spends a compare, a select and a share of the word
+        // arithmetic per step in every lane for the sake of two.
+        typedef const __attribute__((address_space(4))) uint32_t sword_t;
+        sword_t *qa = nullptr, *qb = nullptr;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, w4a = 0, w4b = 0;
+        int skew_a = 0, skew_b = 0, slen_a = 0, slen_b = 0;
+        auto uni64 = [](uint64_t v, int l) -> uint64_t {
+            return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32;
+        };
+        auto group = [](uint32_t lo, uint32_t hi, int sk, int rem) -> uint32_t {       // the four symbols of a group, `rem` of them inside the unit
+            const uint32_t w = (uint32_t)(((uint64_t)hi << 32 | lo) >> (8 * sk));
+            return rem >= 4 ? w : rem <= 0 ? 0u : w & (0xffffffffu >> (8 * (4 - rem)));
+        };
+        if (LUT && !SFEED) {
+            const uint32_t w4 = skew ? (uint32_t)(((uint64_t)wb << 32 | wa) >> (8 * skew)) : wa;
+            if (top) hn = (int)(w4 & 0xff) * SYM_STEP;         // (symbol 0 of a unit is its opening boundary: slen >= 1)
+            lookup(hn);
+        }
+        if (SFEED) {
+            qa = (sword_t *)uni64((uint64_t)wp, 0); qb = (sword_t *)uni64((uint64_t)wp, 32);
+            skew_a = __builtin_amdgcn_readlane(skew, 0); skew_b = __builtin_amdgcn_readlane(skew, 32);
+            slen_a = __builtin_amdgcn_readlane(slen, 0); slen_b = __builtin_amdgcn_readlane(slen, 32);
+            a0 = qa[0]; a1 = qa[1]; a2 = qa[2]; b0 = qb[0]; b1 = qb[1]; b2 = qb[2];
+            w4a = group(a0, a1, skew_a, slen_a); w4b = group(b0, b1, skew_b, slen_b);
+            hn = lane == 0 ? (int)(w4a & 0xff) * SYM_STEP : lane == 32 ? (int)(w4b & 0xff) * SYM_STEP : hn;
+            lookup(hn);
+        }
+        float cM = zero, cX = zero;                            // LUT: uM, uX of the step before = this step's dM, dX (the same array, the same shift)
 
-        auto step = [&](int sym_in, const float (&P)[3][RPL], float (&N)[3][RPL]) {
+        // sym_in: the symbol entering the top lane at this step - LUT: sym_in / sym_b enter lanes 0 / 32 at the NEXT step
+        auto step = [&](int sym_in, int sym_b, const float (&P)[3][RPL], float (&N)[3][RPL]) {
             // the row above slot 0: previous lane's last slot (this column = its previous step, P; the column
             // before = two steps ago, N before it is overwritten); DP row 0 for the top lane
             const float uM = shr1z(P[0][RPL - 1]), uX = shr1z(P[1][RPL - 1]);
-            const float dM = shr1z(N[0][RPL - 1]), dX = shr1z(N[1][RPL - 1]);
+            const float dM = CARRY ? cM : shr1z(N[0][RPL - 1]), dX = CARRY ? cX : shr1z(N[1][RPL - 1]);
             float dY = shr1z(N[2][RPL - 1]);
-            h = shr1z(h);
-            if (top) { dY = ycur; h = sym_in; }
+            float dist[RPL];
+            if (LUT) {
+                if (CARRY) { cM = uM; cX = uX; }
+                h = hn;
+#pragma unroll
+                for (int k = 0; k < RPL; ++k) dist[k] = dnx[k];
+                hn = shr1z(h);
+                if (SFEED) {
+                    // (v_writelane_b32: one instruction per symbol - a select on a scalar operand would need the operand moved to a
+                    // vector register first, the mask being the one scalar operand a VOP3 instruction may read on this chip)
+                    asm("s_nop 1\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 32\n\ts_nop 0" : "+v"(hn) : "s"(sym_in), "s"(sym_b));
+                } else if (top) hn = sym_in * SYM_STEP;
+                if (top) dY = ycur;
+                lookup(hn);
+            } else {
+                h = shr1z(h);
+                if (top) { dY = ycur; h = sym_in; }
+            }
             const bool isb = h == 0;
-            const bool hN = h == 'N';
+            const bool hN = !LUT && h == 'N';
 #pragma unroll
             for (int k = 0; k < RPL; ++k) {
                 const float gM = k ? P[0][k - 1] : dM, gX = k ? P[1][k - 1] : dX, gY = k ? P[2][k - 1] : dY;
                 const float aM = k ? N[0][k - 1] : uM, aX = k ? N[1][k - 1] : uX;
-                const float distm = (h == rch[k] || hN) ? pm[k] : px[k];
+                const float distm = LUT ? dist[k] : (h == rch[k] || hN) ? pm[k] : px[k];
                 const float m = distm * fmaf(gX + gY, pGap[k], gM * pMM[k]);
                 const float x = fmaf(aM, pMX[k], aX * pXX[k]);
                 const float y = fmaf(P[0][k], pMY[k], P[2][k] * pYY[k]);
@@ -618,6 +729,23 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
             }
             acc += N[0][RPL - 1] + N[1][RPL - 1];               // only lane llast's sum is ever read
         };
+        if (SFEED) {
+            for (int s = 0; s < steps; s += 4) {
+                // this group's symbols are in w4a / w4b; the next group's are put together now: its first symbol rides in this group's last step
+                a0 = a1; a1 = a2; a2 = qa[(s >> 2) + 3];
+                b0 = b1; b1 = b2; b2 = qb[(s >> 2) + 3];
+                const uint32_t na = group(a0, a1, skew_a, slen_a - s - 4), nb = group(b0, b1, skew_b, slen_b - s - 4);
+                step((int)(w4a >> 8 & 0xff) * SYM_STEP, (int)(w4b >> 8 & 0xff) * SYM_STEP, S0, S1);
+                __builtin_amdgcn_sched_barrier(0);              // keep the steps apart: interleaving them only costs registers
+                step((int)(w4a >> 16 & 0xff) * SYM_STEP, (int)(w4b >> 16 & 0xff) * SYM_STEP, S1, S0);
+                __builtin_amdgcn_sched_barrier(0);
+                step((int)(w4a >> 24) * SYM_STEP, (int)(w4b >> 24) * SYM_STEP, S0, S1);
+                __builtin_amdgcn_sched_barrier(0);
+                step((int)(na & 0xff) * SYM_STEP, (int)(nb & 0xff) * SYM_STEP, S1, S0);
+                __builtin_amdgcn_sched_barrier(0);
+                w4a = na; w4b = nb;
+            }
+        } else {
         for (int s = 0; s < steps; s += 4) {
             // the 4 symbols entering the top lane at steps s..s+3 (0 = boundary beyond the unit's end)
             const uint32_t w4 = skew ? (uint32_t)(((uint64_t)wb << 32 | wa) >> (8 * skew)) : wa;
@@ -625,14 +753,20 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
             wc = wp[(s >> 2) + 3];
             const int s0 = s < slen ? (int)(w4 & 0xff) : 0, s1 = s + 1 < slen ? (int)(w4 >> 8 & 0xff) : 0;
             const int s2 = s + 2 < slen ? (int)(w4 >> 16 & 0xff) : 0, s3 = s + 3 < slen ? (int)(w4 >> 24) : 0;
-            step(s0, S0, S1);
+            int s4 = 0;                                         // LUT: the first symbol of the next group
+            if (LUT) {
+                const uint32_t w4n = skew ? (uint32_t)(((uint64_t)wb << 32 | wa) >> (8 * skew)) : wa;
+                s4 = s + 4 < slen ? (int)(w4n & 0xff) : 0;
+            }
+            step(LUT ? s1 : s0, 0, S0, S1);
             __builtin_amdgcn_sched_barrier(0);                  // keep the steps apart: interleaving them only costs registers
-            step(s1, S1, S0);
+            step(LUT ? s2 : s1, 0, S1, S0);
             __builtin_amdgcn_sched_barrier(0);
-            step(s2, S0, S1);
+            step(LUT ? s3 : s2, 0, S0, S1);
             __builtin_amdgcn_sched_barrier(0);
-            step(s3, S1, S0);
+            step(LUT ? s4 : s3, 0, S1, S0);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
 }
@@ -822,6 +956,10 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
         int sm = se ? atoi(se) : n_pairs < 200000 ? 1 : n_pairs < 400000 ? 2 : SEG_MAX_PAIRS;
         W.seg_max = sm < 1 ? 1 : sm > SEG_MAX_PAIRS ? SEG_MAX_PAIRS : sm;
     }
+    {
+        const char *le = getenv("GBX_PHMM_LUT");                // 0: the compare-and-select form of round 5 (A/B runs)
+        W.lut = le ? atoi(le) != 0 : 1;
+    }
     W.rcount = (int32_t *)(wb + L.rcount); W.rslen = (int32_t *)(wb + L.rslen); W.rcur = (int32_t *)(wb + L.rcur);
     W.rfirst = (int32_t *)(wb + L.rfirst); W.rsbase = (int64_t *)(wb + L.rsbase);
     W.porder = (int32_t *)(wb + L.porder); W.soff = (int64_t *)(wb + L.soff);
@@ -864,22 +1002,24 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
     if ((rc = side_streams(&ss))) return rc;
     std::unique_lock<std::mutex> side_lock(ss->mu);
     if ((rc = ss->fork(s))) return rc;
-#define GBX_STREAM(RPL_, STREAM_)                                                                                       \
+#define GBX_STREAM2(RPL_, LUT_, STREAM_)                                                                                \
     {                                                                                                                   \
         static int per_cu = 0;                                                                                          \
         if (!per_cu) {                                                                                                  \
             int qb = 0;                                                                                                 \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qb, phmm_stream_kernel<RPL_>, 64, 0) != hipSuccess || qb < 1) { \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&qb, phmm_stream_kernel<RPL_, LUT_>, 64, 0) != hipSuccess || qb < 1) { \
                 (void)hipGetLastError(); qb = 8;                                                                        \
             }                                                                                                           \
             per_cu = qb > 32 ? 32 : qb;                                                                                 \
         }                                                                                                               \
         Stage st("phmm_stream_rpl" #RPL_, STREAM_);                                                                     \
-        hipLaunchKernelGGL(phmm_stream_kernel<RPL_>, dim3(grid(per_cu)), dim3(64), 0, STREAM_, A, W, RPL_ - 1);         \
+        hipLaunchKernelGGL((phmm_stream_kernel<RPL_, LUT_>), dim3(grid(per_cu)), dim3(64), 0, STREAM_, A, W, RPL_ - 1); \
     }
+#define GBX_STREAM(RPL_, STREAM_) { if (W.lut) GBX_STREAM2(RPL_, true, STREAM_) else GBX_STREAM2(RPL_, false, STREAM_) }
     GBX_STREAM(5, s) GBX_STREAM(4, ss->side[0]) GBX_STREAM(6, ss->side[1]) GBX_STREAM(3, ss->side[2])
     GBX_STREAM(2, ss->side[0]) GBX_STREAM(7, ss->side[1]) GBX_STREAM(1, ss->side[2]) GBX_STREAM(8, ss->side[1])
 #undef GBX_STREAM
+#undef GBX_STREAM2
     if ((rc = ss->join(s))) return rc;
     side_lock.unlock();
     { Stage st("phmm_stream_finish", s); hipLaunchKernelGGL(phmm_stream_finish_kernel, dim3(cb), dim3(256), 0, s, A, W); }

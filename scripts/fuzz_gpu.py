@@ -2,7 +2,8 @@
 """Randomised parity run on the GPU: host entries of the six kernels against the oracle on random jobs of random
 sizes (small-job modes, class modes, staged and packed transfers all get hit).  usage: fuzz_gpu.py [seconds] [seed]
 FUZZ_LOG=<file>: every job's description is appended (and synced) before it runs - after a hang the last line is the culprit;
-FUZZ_SKIP_UNTIL=<n>: the first n-1 jobs are drawn but not run (replays the random stream up to a job of interest)."""
+FUZZ_SKIP_UNTIL=<n>: the first n-1 jobs are drawn but not run (replays the random stream up to a job of interest);
+FUZZ_KINDS=phmm,combo: only these job kinds (a run aimed at one kernel after a change to it)."""
 import os
 import sys
 import time
@@ -42,8 +43,9 @@ def announce(text):
     return job_no >= skip_until
 fmi_idx = {}                                                    # genome length -> (genome, index): built once per size
 n_multi = 0
+kinds = os.environ["FUZZ_KINDS"].split(",") if os.environ.get("FUZZ_KINDS") else ["bsw", "bsw", "chain", "phmm", "poa", "poa", "abea", "fmi", "combo"]
 while time.time() < t_end:
-    k = rng.choice(["bsw", "bsw", "chain", "phmm", "poa", "poa", "abea", "fmi", "combo"])
+    k = rng.choice(kinds)
     seed = int(rng.integers(1, 1 << 30))
     job_no += 1
     ok, what = True, ""
@@ -121,7 +123,13 @@ while time.time() < t_end:
     elif k == "phmm":
         nb = int(rng.choice([1, 2, 9, 40, 90]))
         bs = gen_phmm(nb, seed)
-        what = "batches=%d pairs=%d" % (nb, bs.n_pairs)
+        odd = rng.random() < 0.35
+        if odd:                                                  # bytes the prior tables do not code (lower case, IUPAC), and N: literal compares
+            for arr in (bs.hap, bs.rs):
+                nmut = max(1, len(arr) // int(rng.choice([50, 400, 5000])))
+                at = rng.integers(0, max(1, len(arr) - 8), nmut)
+                arr[at] = rng.choice(np.frombuffer(b"NNacgtRYn", dtype=np.uint8), nmut)
+        what = "batches=%d pairs=%d odd_bytes=%s" % (nb, bs.n_pairs, odd)
         if announce("phmm seed=%d devices=%d min_units=%s %s" % (seed, ndev, os.environ.get("GBX_SHARD_MIN_UNITS"), what)):
             want, _ = O.phmm_oracle(bs, 8, True)
             got = forward_host(bs)

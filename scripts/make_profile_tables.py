@@ -47,7 +47,7 @@ def stage_name(kname):
         if m.group(1) == "true":
             return "bsw_lane_c%d" % {16: 47, 10: 79, 8: 99, 7: 135, 6: 159}.get(per_cu, 0)
         return "bsw_lane_w%d" % {14: 39, 7: 79, 5: 103, 4: 127, 3: 159}.get(per_cu, 0)
-    m = re.match(r"phmm_stream_kernel<(\d+)>", kname)
+    m = re.match(r"phmm_stream_kernel<(\d+)(?:, true)?>", kname)            # (the table form; <N, false> = GBX_PHMM_LUT=0 is not the default and gets no entry)
     if m:
         return "phmm_stream_rpl" + m.group(1)
     if re.match(r"chain_kernel<\d+>", kname):

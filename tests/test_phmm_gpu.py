@@ -112,6 +112,29 @@ def test_n_bases_and_single_cells():
     assert_close(forward_host(bs), O.phmm_oracle(bs))
 
 
+def test_bytes_outside_acgtn_compare_literally():
+    """The scalar semantics compare literal bytes (PairHMMUnitTest.cpp / oracle: `rs == hap || rs == 'N' || hap == 'N'`).  The
+    stream kernels' prior tables know A C G T N only: a haplotype with any other byte is sent to the fp64 pass, which compares
+    bytes; a READ with other bytes needs nothing special (it matches no coded symbol but N)."""
+    rng = np.random.default_rng(11)
+    core = rand_seq(rng, 90)
+    haps = [core, core[:40].lower() + core[40:], core[:30] + "R" + core[31:], core.replace("A", "a"), rand_seq(rng, 70, "ACGTN")]
+    reads = [core[5:80], core[5:80].lower(), core[10:60].replace("C", "c"), core[20:85], rand_seq(rng, 60, "ACGTNacgtRY")]
+    bs = make_set(reads, haps, seed=12)
+    assert_close(forward_host(bs), O.phmm_oracle(bs))
+
+
+def test_prior_tables_against_compares(monkeypatch):
+    """GBX_PHMM_LUT=0 is round 5's compare-and-select form of the stream kernels: same sums, bit for bit (the table holds the
+    two values the select chose between)."""
+    bs = gen_phmm(30, 3003)
+    a = forward_host(bs)
+    monkeypatch.setenv("GBX_PHMM_LUT", "0")
+    b = forward_host(bs)
+    assert np.array_equal(a, b)
+    assert_close(a, O.phmm_oracle(bs, 8, True)[0])
+
+
 def test_device_entry_and_batch_subset_equivalence():
     import torch
     bs = gen_phmm(30, 11)
