@@ -1,6 +1,8 @@
 // capi_bsw.hip — bsw entries of the C-ABI (include/gbx.h): device entry, host-buffer entry, the SeqPair drop-in.
 #include "capi_common.h"
 
+static constexpr int BSW_HOST_WORKERS = 4;        // upload / validation helpers of a bsw host call (host_workers: GBX_HOST_THREADS overrides)
+
 using namespace gbx;
 
 extern "C" {
@@ -167,7 +169,7 @@ static int bsw_host_one(const gbx_bsw_params *p, int64_t n,
         (rc = dwork.alloc(wb1 * (size_t)n_chunks)))
         return rc;
     mark("allocated", 0);
-    HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28, n_chunks > 1);
+    HostPipe pipe(L, (size_t)ref_bytes + (size_t)qer_bytes + (size_t)n * 28, n_chunks > 1, BSW_HOST_WORKERS);
     if ((rc = pipe.prepare(n_chunks))) return rc;
     // Staged (large) calls send the bases two per byte: the upload workers pack them on their way into the pinned slabs
     // (host_pipeline.h: pack4), the device expands them into the byte arenas the kernels read (bsw_unpack4) - the
@@ -294,7 +296,7 @@ static int bsw_host_entry(const gbx_bsw_params *p, int64_t n,
     if (!host_multi_wanted() || !p || n <= 0 || !ref || !qer || !idr || !idq || !len1 || !len2 || !h0 || !out || ref_bytes < 0 || qer_bytes < 0)
         return bsw_host_one(p, n, ref, ref_bytes, qer, qer_bytes, idr, idq, len1, len2, h0, out);
     {   // argument errors come first and read as on one device: a job with a bad pair takes the one-device path, which names it
-        const int T = host_workers();
+        const int T = host_workers(BSW_HOST_WORKERS);
         std::vector<char> bad((size_t)T, 0);
         parallel_ranges(n, T, [&](int t, int64_t lo, int64_t hi) {
             for (int64_t j = lo; j < hi; ++j)
@@ -439,7 +441,7 @@ int gbx_bsw_extend_seqpairs(const gbx_bsw_params *p, gbx_seqpair *pairs, int64_t
     // main_banded.cpp:56-58,160-172), so the arenas are mostly holes: 2 M pairs span 4.6 GB for 0.6 GB of bases.
     // The flat arrays are extracted with a few threads, and when the layout is that sparse the bases are gathered
     // into packed arenas first instead of sending the holes over PCIe.
-    const int T = host_workers();
+    const int T = host_workers(BSW_HOST_WORKERS);
     std::vector<int64_t> idr(n), idq(n);
     std::vector<int32_t> l1(n), l2(n), h0(n);
     std::vector<gbx_bsw_result> out(n);

@@ -217,10 +217,12 @@ static unsigned host_wait_event_flags()
     return hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0u);
 }
 
-static int host_workers()
+// dflt: a kernel's own default (bsw: 4 - measured on the pool's 16-core quota, profiles/r06zj_bsw_host_threads.txt: medians 8.75-8.84 ms
+// with four workers, 8.95-9.37 with six, worse with three or five: the workers alternate between the two upload streams)
+static int host_workers(int dflt = 6)
 {
     const char *env = getenv("GBX_HOST_THREADS");
-    int t = env ? atoi(env) : 6;
+    int t = env ? atoi(env) : dflt;
     return t < 1 ? 1 : t > Lane::MAX_WORKERS ? Lane::MAX_WORKERS : t;
 }
 
@@ -489,8 +491,8 @@ struct HostPipe {
     // seven to twelve of them); results come back through the pinned download slab
     bool packed;
     size_t pack_off = 0;
-    HostPipe(Lane *l, size_t total_bytes, bool overlap)
-        : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers()),
+    HostPipe(Lane *l, size_t total_bytes, bool overlap, int default_workers = 6)
+        : L(l), staged(total_bytes >= stage_min() && !getenv("GBX_HOST_PAGEABLE")), workers(host_workers(default_workers)),
           xfer(overlap ? l->copy : l->compute), xfer2(overlap ? l->copy2 : l->compute), xdown(overlap ? l->down : l->compute),
           packed(!staged && l->staged_ready && total_bytes <= Lane::PIECE / 2 && !getenv("GBX_HOST_PAGEABLE")) {}
     // an early return between start() and the last chunk_launched() must not leave the downloader waiting for a chunk
