@@ -58,7 +58,25 @@ static int chain_host_one(int64_t n_calls, const int64_t *anchor_off, const uint
     // one pipeline chunk (host_pipeline.h): staged uploads, the kernels on the lane's compute stream, staged
     // downloads.  The calls of a job share one load-balanced launch, so there is nothing to gain from chunks.
     HostPipe pipe(lane.l, (size_t)na * 16 + (size_t)n_calls * (8 + sizeof(gbx_chain_call)), false);
-    if ((rc = pipe.prepare(1))) return rc;
+    // A large staged call: its few longest jobs - each a lone wavefront that works for tens of milliseconds after the rest of the
+    // chip has finished (on 'large': 66 ms of the call's 68) - run in a launch of their own (ChainSplit), and everything else comes
+    // home while they are still at work: the results of the rest are downloaded behind the main launch (the longest jobs' stretches
+    // of the arrays come along unfinished), theirs follow, gathered into one buffer on the device, behind their own.
+    // GBX_CHAIN_SPLIT_TOP=<jobs> (0: off; default 32), from GBX_CHAIN_SPLIT_MIN anchors on (default 4 Mi).
+    int split_top = 0;
+    {
+        const char *e = getenv("GBX_CHAIN_SPLIT_TOP"), *em = getenv("GBX_CHAIN_SPLIT_MIN");     /* read per call: the tests vary them */
+        const int want = e ? atoi(e) : 32;
+        const int64_t min_anchors = em ? atoll(em) : (int64_t)4 << 20;
+        if (pipe.staged && want > 0 && na >= min_anchors && n_calls > want) split_top = want < CHAIN_SPLIT_MAX ? want : CHAIN_SPLIT_MAX;
+    }
+    const int n_arrays = 2 + (target ? 1 : 0) + (peak ? 1 : 0);
+    int64_t max_call = 0;
+    if (split_top) for (int64_t c = 0; c < n_calls; ++c) max_call = anchor_off[c + 1] - anchor_off[c] > max_call ? anchor_off[c + 1] - anchor_off[c] : max_call;
+    DevBuf dtab(L), dpacked(L);
+    std::vector<int64_t> h_tab((size_t)1 + 3 * CHAIN_SPLIT_MAX, 0);
+    if (split_top && ((rc = dtab.alloc(h_tab.size() * 8)) || (rc = dpacked.alloc((size_t)split_top * (size_t)max_call * 4 * (size_t)n_arrays)))) return rc;
+    if ((rc = pipe.prepare(split_top ? 2 : 1))) return rc;
     pipe.stage(0, doff.p, anchor_off, (n_calls + 1) * 8);
     pipe.stage(0, dh.p, hdr, n_calls * sizeof(gbx_chain_call));
     pipe.stage(0, dx.p, ax, na * 8);
@@ -67,14 +85,42 @@ static int chain_host_one(int64_t n_calls, const int64_t *anchor_off, const uint
     pipe.start();
     if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
     mark("uploads queued");
+    ChainSplit sp;
+    std::vector<HostPipe::Seg> segs;
+    if (split_top) {
+        // (the lane's copy stream: this call's pipe does its transfers on the compute stream, and the lane is this call's alone)
+        sp.top = split_top; sp.side = L->copy;
+        sp.ev_rest = pipe.join_events(0)[0]; sp.ev_top = pipe.join_events(1)[0]; sp.ev_fork = pipe.join_events(1)[1];
+        sp.d_tab = dtab.as<int64_t>(); sp.h_tab = h_tab.data(); sp.d_packed = dpacked.as<int32_t>();
+        sp.n_arrays = n_arrays;
+        int a = 0;
+        sp.src[a++] = ds.as<int32_t>(); sp.src[a++] = dp.as<int32_t>();
+        if (target) sp.src[a++] = dt.as<int32_t>();
+        if (peak) sp.src[a++] = dk.as<int32_t>();
+        for (; a < 4; ++a) sp.src[a] = ds.as<int32_t>();
+    }
     rc = chain_launch(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
-                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute);
+                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute, split_top ? &sp : nullptr);
     if (rc) return pipe.finish(rc);
     pipe.fetch(0, score, ds.p, na * 4);
     pipe.fetch(0, parent, dp.p, na * 4);
     if (target) pipe.fetch(0, target, dt.p, na * 4);
     if (peak) pipe.fetch(0, peak, dk.p, na * 4);
-    if ((rc = pipe.chunk_launched(0))) return pipe.finish(rc);
+    if ((rc = pipe.chunk_launched(0, split_top ? 1 : 0))) return pipe.finish(rc);
+    if (split_top) {
+        // the longest jobs' results: one packed buffer, job after job, array after array - delivered over what the first download
+        // left in their stretches of the caller's arrays
+        const int m = (int)h_tab[0];
+        int32_t *const outs[4] = {score, parent, target ? target : peak, target ? peak : nullptr};
+        size_t bytes = 0;
+        for (int k = 0; k < m; ++k) {
+            const int64_t start = h_tab[(size_t)1 + 3 * k], n = h_tab[(size_t)2 + 3 * k];
+            if (start < 0 || n < 0 || start + n > na || n > max_call) { set_error("gbx_chain_host: inconsistent job table"); return pipe.finish(GBX_ERR_HIP); }
+            for (int a = 0; a < n_arrays; ++a) { segs.push_back(HostPipe::Seg{(char *)(outs[a] + start), (size_t)n * 4}); bytes += (size_t)n * 4; }
+        }
+        if (bytes) pipe.fetch_scatter(1, dpacked.p, bytes, &segs);
+        if ((rc = pipe.chunk_launched(1, 1))) return pipe.finish(rc);
+    }
     mark("kernels queued");
     rc = pipe.finish();
     mark("results downloaded");

@@ -142,3 +142,29 @@ def test_host_entry_staged_transfers(monkeypatch):
     assert_same(chain_host(*case), want)
     monkeypatch.setenv("GBX_HOST_PAGEABLE", "1")
     assert_same(chain_host(*case), want)
+
+
+@pytest.mark.parametrize("top", ["1", "5", "64"])
+def test_host_entry_longest_jobs_in_a_launch_of_their_own(top, monkeypatch):
+    """A large staged call runs its longest jobs in a launch of their own and downloads everything else meanwhile
+    (capi_chain.hip, ChainSplit; default from 4 Mi anchors on): forced onto small jobs here - every output array, with and
+    without the optional ones, a call list cut into many jobs, fewer calls than the split takes, small download pieces."""
+    monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
+    monkeypatch.setenv("GBX_CHAIN_SPLIT_MIN", "1")
+    monkeypatch.setenv("GBX_CHAIN_SPLIT_TOP", top)
+    case = gen_chain(150, 4242)
+    want = O.chain_oracle(*case, nthreads=8)
+    assert_same(chain_host(*case), want)
+    s, p, t, k = chain_host(*case, want_target=False, want_peak=False)
+    assert t is None and k is None and np.array_equal(s, want[0]) and np.array_equal(p, want[1])
+    s, p, t, k = chain_host(*case, want_target=True, want_peak=False)
+    assert k is None and np.array_equal(s, want[0]) and np.array_equal(p, want[1]) and np.array_equal(t, want[2])
+    monkeypatch.setenv("GBX_HOST_DOWN_PIECE", "4096")
+    assert_same(chain_host(*case), want)
+    for name in ("cuts", "realistic", "multiseg"):            # calls that fall apart into jobs: a job table of pieces
+        gcase, g = load_chain_golden(name)
+        assert_same(chain_host(*gcase), [g[:, 0], g[:, 1], g[:, 2], g[:, 3]])
+    few = gen_chain(3, 9)                                      # fewer calls than the split takes: one launch as before
+    assert_same(chain_host(*few), O.chain_oracle(*few))
+    monkeypatch.setenv("GBX_CHAIN_SPLIT_TOP", "0")
+    assert_same(chain_host(*case), want)
