@@ -1,5 +1,6 @@
 // capi_chain.hip — chain entries of the C-ABI (include/gbx.h).
 #include "capi_common.h"
+#include "chain_split.h"
 
 using namespace gbx;
 
@@ -99,8 +100,8 @@ static int chain_host_one(int64_t n_calls, const int64_t *anchor_off, const uint
         if (peak) sp.src[a++] = dk.as<int32_t>();
         for (; a < 4; ++a) sp.src[a] = ds.as<int32_t>();
     }
-    rc = chain_launch(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
-                      ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute, split_top ? &sp : nullptr);
+    rc = chain_launch_split(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
+                            ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute, split_top ? &sp : nullptr);
     if (rc) return pipe.finish(rc);
     pipe.fetch(0, score, ds.p, na * 4);
     pipe.fetch(0, parent, dp.p, na * 4);

@@ -29,6 +29,7 @@
 // one segment id takes the narrow 32-bit path even when its call as a whole could not.
 // Jobs are handed out longest-first from a cursor (the longest job bounds the kernel's makespan).
 #include "gbx_internal.h"
+#include "chain_split.h"
 
 namespace gbx {
 namespace {
@@ -767,7 +768,15 @@ __global__ void __launch_bounds__(256) chain_top_gather_kernel(const int64_t *__
 int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
                  int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
-                 void *d_work, size_t work_bytes, hipStream_t s, ChainSplit *split)
+                 void *d_work, size_t work_bytes, hipStream_t s)
+{
+    return chain_launch_split(n_calls, n_anchors, d_off, d_ax, d_ay, d_hdr, d_score, d_parent, d_target, d_peak, d_work, work_bytes, s, nullptr);
+}
+
+int chain_launch_split(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
+                       const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
+                       int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
+                       void *d_work, size_t work_bytes, hipStream_t s, ChainSplit *split)
 {
     if (n_calls == 0) return GBX_OK;
     if (n_calls > 0x7fffffffLL - 1024) { set_error("chain: more than 2^31 calls"); return GBX_ERR_UNSUPPORTED; }
