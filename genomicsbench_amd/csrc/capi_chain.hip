@@ -59,68 +59,107 @@ static int chain_host_one(int64_t n_calls, const int64_t *anchor_off, const uint
     // one pipeline chunk (host_pipeline.h): staged uploads, the kernels on the lane's compute stream, staged
     // downloads.  The calls of a job share one load-balanced launch, so there is nothing to gain from chunks.
     HostPipe pipe(lane.l, (size_t)na * 16 + (size_t)n_calls * (8 + sizeof(gbx_chain_call)), false);
-    // A large staged call: its few longest jobs - each a lone wavefront that works for tens of milliseconds after the rest of the
-    // chip has finished (on 'large': 66 ms of the call's 68) - run in a launch of their own (ChainSplit), and everything else comes
-    // home while they are still at work: the results of the rest are downloaded behind the main launch (the longest jobs' stretches
-    // of the arrays come along unfinished), theirs follow, gathered into one buffer on the device, behind their own.
-    // GBX_CHAIN_SPLIT_TOP=<jobs> (0: off; default 32), from GBX_CHAIN_SPLIT_MIN anchors on (default 4 Mi).
-    int split_top = 0;
+    // A large staged call is as long as its longest calls: each of them a lone wavefront for tens of milliseconds (on 'large': 66 ms of
+    // the kernels' 68), in front of which the whole job was uploaded (12.5 ms) and behind which the whole result came home (13 ms).
+    // Such a call now runs as two launches.  Its `top` longest calls go first: their anchors are uploaded ahead of everything (a few
+    // per cent of the bytes) into arrays of their own and their launch starts on the lane's second stream while the rest of the job
+    // is still on its way; the main launch takes every other call (chain_launch_skip), and its results are downloaded behind IT, with
+    // the longest calls still at work; theirs follow, scattered into their stretches of the caller's arrays.
+    // GBX_CHAIN_SPLIT_TOP=<calls> (0: one launch; default 32), from GBX_CHAIN_SPLIT_MIN anchors on (default 4 Mi).
+    int top = 0;
     {
         const char *e = getenv("GBX_CHAIN_SPLIT_TOP"), *em = getenv("GBX_CHAIN_SPLIT_MIN");     /* read per call: the tests vary them */
         const int want = e ? atoi(e) : 32;
         const int64_t min_anchors = em ? atoll(em) : (int64_t)4 << 20;
-        if (pipe.staged && want > 0 && na >= min_anchors && n_calls > want) split_top = want < CHAIN_SPLIT_MAX ? want : CHAIN_SPLIT_MAX;
+        if (pipe.staged && want > 0 && na >= min_anchors && n_calls > want) top = want < 4096 ? want : 4096;
     }
-    const int n_arrays = 2 + (target ? 1 : 0) + (peak ? 1 : 0);
-    int64_t max_call = 0;
-    if (split_top) for (int64_t c = 0; c < n_calls; ++c) max_call = anchor_off[c + 1] - anchor_off[c] > max_call ? anchor_off[c + 1] - anchor_off[c] : max_call;
-    DevBuf dtab(L), dpacked(L);
-    std::vector<int64_t> h_tab((size_t)1 + 3 * CHAIN_SPLIT_MAX, 0);
-    if (split_top && ((rc = dtab.alloc(h_tab.size() * 8)) || (rc = dpacked.alloc((size_t)split_top * (size_t)max_call * 4 * (size_t)n_arrays)))) return rc;
-    if ((rc = pipe.prepare(split_top ? 2 : 1))) return rc;
-    pipe.stage(0, doff.p, anchor_off, (n_calls + 1) * 8);
-    pipe.stage(0, dh.p, hdr, n_calls * sizeof(gbx_chain_call));
-    pipe.stage(0, dx.p, ax, na * 8);
-    pipe.stage(0, dy.p, ay, na * 8);
+    std::vector<int64_t> tcall, toff;                           // the longest calls, by position; their offsets in the arrays of their own
+    std::vector<uint8_t> skip;
+    std::vector<gbx_chain_call> thdr;
+    int64_t tna = 0;
+    if (top) {
+        std::vector<int64_t> idx((size_t)n_calls);
+        for (int64_t c = 0; c < n_calls; ++c) idx[(size_t)c] = c;
+        auto len = [&](int64_t c) { return anchor_off[c + 1] - anchor_off[c]; };
+        std::nth_element(idx.begin(), idx.begin() + top, idx.end(), [&](int64_t a, int64_t b) { return len(a) != len(b) ? len(a) > len(b) : a < b; });
+        tcall.assign(idx.begin(), idx.begin() + top);
+        std::sort(tcall.begin(), tcall.end());
+        skip.assign((size_t)n_calls, 0);
+        toff.assign((size_t)top + 1, 0);
+        thdr.resize((size_t)top);
+        for (int k = 0; k < top; ++k) {
+            const int64_t c = tcall[(size_t)k];
+            skip[(size_t)c] = 1; thdr[(size_t)k] = hdr[c];
+            toff[(size_t)k + 1] = toff[(size_t)k] + len(c);
+        }
+        tna = toff[(size_t)top];
+        if (tna == 0) top = 0;
+    }
+    DevBuf toffd(L), txd(L), tyd(L), thd(L), tsd(L), tpd(L), ttd(L), tkd(L), twd(L), skipd(L);
+    const size_t twb = top ? chain_workspace_bytes(top, tna) : 0;
+    if (top && ((rc = toffd.alloc((size_t)(top + 1) * 8)) || (rc = txd.alloc(tna * 8)) || (rc = tyd.alloc(tna * 8)) ||
+                (rc = thd.alloc((size_t)top * sizeof(gbx_chain_call))) || (rc = tsd.alloc(tna * 4)) || (rc = tpd.alloc(tna * 4)) ||
+                (rc = ttd.alloc(tna * 4)) || (rc = tkd.alloc(tna * 4)) || (rc = twd.alloc(twb)) || (rc = skipd.alloc((size_t)n_calls))))
+        return rc;
+    // chunks of the pipe: 0 = the longest calls' uploads, 1 = the job's uploads and the main launch's results, 2 = the longest calls' results
+    const int64_t cm = top ? 1 : 0;
+    if ((rc = pipe.prepare(top ? 3 : 1))) return rc;
+    if (top) {
+        pipe.stage(0, toffd.p, toff.data(), (size_t)(top + 1) * 8);
+        pipe.stage(0, thd.p, thdr.data(), (size_t)top * sizeof(gbx_chain_call));
+        for (int k = 0; k < top; ++k) {
+            const int64_t o = anchor_off[tcall[(size_t)k]], n = toff[(size_t)k + 1] - toff[(size_t)k];
+            if (!n) continue;
+            pipe.stage(0, txd.as<uint64_t>() + toff[(size_t)k], ax + o, (size_t)n * 8);
+            pipe.stage(0, tyd.as<uint64_t>() + toff[(size_t)k], ay + o, (size_t)n * 8);
+        }
+        pipe.stage(cm, skipd.p, skip.data(), (size_t)n_calls);
+    }
+    pipe.stage(cm, doff.p, anchor_off, (n_calls + 1) * 8);
+    pipe.stage(cm, dh.p, hdr, n_calls * sizeof(gbx_chain_call));
+    pipe.stage(cm, dx.p, ax, na * 8);
+    pipe.stage(cm, dy.p, ay, na * 8);
     mark("device buffers ready");
     pipe.start();
-    if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
-    mark("uploads queued");
-    ChainSplit sp;
-    std::vector<HostPipe::Seg> segs;
-    if (split_top) {
-        // (the lane's copy stream: this call's pipe does its transfers on the compute stream, and the lane is this call's alone)
-        sp.top = split_top; sp.side = L->copy;
-        sp.ev_rest = pipe.join_events(0)[0]; sp.ev_top = pipe.join_events(1)[0]; sp.ev_fork = pipe.join_events(1)[1];
-        sp.d_tab = dtab.as<int64_t>(); sp.h_tab = h_tab.data(); sp.d_packed = dpacked.as<int32_t>();
-        sp.n_arrays = n_arrays;
-        int a = 0;
-        sp.src[a++] = ds.as<int32_t>(); sp.src[a++] = dp.as<int32_t>();
-        if (target) sp.src[a++] = dt.as<int32_t>();
-        if (peak) sp.src[a++] = dk.as<int32_t>();
-        for (; a < 4; ++a) sp.src[a] = ds.as<int32_t>();
+    std::vector<HostPipe::Seg> segs[4];
+    if (top) {
+        if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
+        // (this pipe's transfers run on the compute stream: the event lies behind the longest calls' uploads and whatever of the
+        // job's the workers have queued since - a few pieces)
+        hipEvent_t up = pipe.join_events(0)[0], done = pipe.join_events(2)[0];
+        GBX_HIP(hipEventRecord(up, L->compute));
+        GBX_HIP(hipStreamWaitEvent(L->copy, up, 0));
+        rc = chain_launch(top, tna, toffd.as<int64_t>(), txd.as<uint64_t>(), tyd.as<uint64_t>(), thd.as<gbx_chain_call>(),
+                          tsd.as<int32_t>(), tpd.as<int32_t>(), target ? ttd.as<int32_t>() : nullptr, peak ? tkd.as<int32_t>() : nullptr,
+                          twd.p, twb, L->copy);
+        if (rc) return pipe.finish(rc);
+        GBX_HIP(hipEventRecord(done, L->copy));
+        if ((rc = pipe.chunk_launched(0, 1))) return pipe.finish(rc);
+        mark("longest calls queued");
     }
-    rc = chain_launch_split(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
-                            ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute, split_top ? &sp : nullptr);
+    if ((rc = pipe.wait_stage(cm))) return pipe.finish(rc);
+    mark("uploads queued");
+    rc = chain_launch_skip(n_calls, na, doff.as<int64_t>(), dx.as<uint64_t>(), dy.as<uint64_t>(), dh.as<gbx_chain_call>(),
+                           ds.as<int32_t>(), dp.as<int32_t>(), dt.as<int32_t>(), dk.as<int32_t>(), dw.p, wb, lane.l->compute,
+                           top ? skipd.as<uint8_t>() : nullptr);
     if (rc) return pipe.finish(rc);
-    pipe.fetch(0, score, ds.p, na * 4);
-    pipe.fetch(0, parent, dp.p, na * 4);
-    if (target) pipe.fetch(0, target, dt.p, na * 4);
-    if (peak) pipe.fetch(0, peak, dk.p, na * 4);
-    if ((rc = pipe.chunk_launched(0, split_top ? 1 : 0))) return pipe.finish(rc);
-    if (split_top) {
-        // the longest jobs' results: one packed buffer, job after job, array after array - delivered over what the first download
-        // left in their stretches of the caller's arrays
-        const int m = (int)h_tab[0];
-        int32_t *const outs[4] = {score, parent, target ? target : peak, target ? peak : nullptr};
-        size_t bytes = 0;
-        for (int k = 0; k < m; ++k) {
-            const int64_t start = h_tab[(size_t)1 + 3 * k], n = h_tab[(size_t)2 + 3 * k];
-            if (start < 0 || n < 0 || start + n > na || n > max_call) { set_error("gbx_chain_host: inconsistent job table"); return pipe.finish(GBX_ERR_HIP); }
-            for (int a = 0; a < n_arrays; ++a) { segs.push_back(HostPipe::Seg{(char *)(outs[a] + start), (size_t)n * 4}); bytes += (size_t)n * 4; }
+    pipe.fetch(cm, score, ds.p, na * 4);
+    pipe.fetch(cm, parent, dp.p, na * 4);
+    if (target) pipe.fetch(cm, target, dt.p, na * 4);
+    if (peak) pipe.fetch(cm, peak, dk.p, na * 4);
+    if ((rc = pipe.chunk_launched(cm))) return pipe.finish(rc);
+    if (top) {
+        int32_t *const outs[4] = {score, parent, target, peak};
+        const void *const devs[4] = {tsd.p, tpd.p, ttd.p, tkd.p};
+        for (int a = 0; a < 4; ++a) {
+            if (!outs[a]) continue;
+            for (int k = 0; k < top; ++k) {
+                const size_t n = (size_t)(toff[(size_t)k + 1] - toff[(size_t)k]) * 4;
+                if (n) segs[a].push_back(HostPipe::Seg{(char *)(outs[a] + anchor_off[tcall[(size_t)k]]), n});
+            }
+            pipe.fetch_scatter(2, devs[a], (size_t)tna * 4, &segs[a]);
         }
-        if (bytes) pipe.fetch_scatter(1, dpacked.p, bytes, &segs);
-        if ((rc = pipe.chunk_launched(1, 1))) return pipe.finish(rc);
+        if ((rc = pipe.chunk_launched(2, 1))) return pipe.finish(rc);
     }
     mark("kernels queued");
     rc = pipe.finish();

@@ -227,10 +227,13 @@ __global__ void __launch_bounds__(256) chain_st_kernel(int n_calls, const int64_
 // Jobs of a call: [0, c1), [c1, c2) ... at the cuts chain_st_kernel recorded (one per block of 64 anchors at most); an
 // unsorted call is one job.  One block per call; the job slots of a call are contiguous (one atomic per call), the
 // order kernel sorts the jobs by size afterwards.  job_flag is zero on entry.
-__global__ void __launch_bounds__(256) chain_jobs_kernel(int n_calls, const int64_t *__restrict__ off, ChainWork W, int split_on)
+// skip (nullable): calls that get no job at all - the host entry runs its longest calls as a launch of their own (capi_chain.hip).
+__global__ void __launch_bounds__(256) chain_jobs_kernel(int n_calls, const int64_t *__restrict__ off, ChainWork W, int split_on,
+                                                         const uint8_t *__restrict__ skip)
 {
     const int call = blockIdx.x;
     if (call >= n_calls) return;
+    if (skip && skip[call]) return;
     const int64_t o = off[call];
     const int n = (int)(off[call + 1] - o);
     const int nb = (n + 63) >> 6;
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
                                                    const uint64_t *__restrict__ ax, const uint64_t *__restrict__ ay,
                                                    const gbx_chain_call *__restrict__ hdr,
                                                    int32_t *score, int32_t *parent, int32_t *target, int32_t *peak,
-                                                   ChainWork W, int cursor, int slot_lo, int slot_hi)
+                                                   ChainWork W)
 {
     // ring entries: the anchor words {x, y} and the DP state {score, parent, target, peak} of the reference's four
     // vectors, 16 bytes each, so that a look-back chunk is two ds_read_b128 per lane.  Scores / parents / peaks go
@@ -322,12 +325,10 @@ __global__ void __launch_bounds__(64) chain_kernel(int n_calls, const int64_t *_
 
     // the resident blocks draw jobs from the longest-first list through a cursor: a dynamic LPT schedule.  Everything
     // derived from `slot` stays wave-uniform
-    // the launch's share of the longest-first list: slots [slot_lo, min(jobs, slot_hi)), its own cursor (ChainSplit: W.next[6] serves
-    // the launch of the longest jobs, W.next[0] everything else, or everything)
-    const int n_jobs = min(W.next[5], slot_hi);
+    const int n_jobs = W.next[5];
     for (;;) {
         int slot = 0;
-        if (lane == 0) slot = slot_lo + atomicAdd(&W.next[cursor], 1);
+        if (lane == 0) slot = atomicAdd(&W.next[0], 1);
         slot = __builtin_amdgcn_readfirstlane(slot);
         if (slot >= n_jobs) break;
         const int job = W.order[slot];
@@ -742,41 +743,18 @@ int chain_read_job_stats(const void *d_work, int64_t n_calls, int64_t n_anchors,
     return GBX_OK;
 }
 
-// ChainSplit: the table of the `top` longest jobs (one thread: at most CHAIN_SPLIT_MAX entries), and the gather of their results
-__global__ void __launch_bounds__(64) chain_top_kernel(ChainWork W, int top, int n_arrays, int64_t *tab)
-{
-    if (threadIdx.x) return;
-    const int m = min(top, W.next[5]);
-    tab[0] = m;
-    int64_t at = 0;
-    for (int k = 0; k < m; ++k) {
-        const int job = W.order[k];
-        tab[1 + 3 * k] = W.job_start[job]; tab[2 + 3 * k] = W.job_n[job]; tab[3 + 3 * k] = at;
-        at += (int64_t)W.job_n[job] * n_arrays;
-    }
-}
-__global__ void __launch_bounds__(256) chain_top_gather_kernel(const int64_t *__restrict__ tab, int n_arrays, const int32_t *a0, const int32_t *a1,
-                                                              const int32_t *a2, const int32_t *a3, int32_t *__restrict__ dst)
-{
-    const int k = blockIdx.x, a = blockIdx.y;
-    if (k >= (int)tab[0] || a >= n_arrays) return;
-    const int64_t start = tab[1 + 3 * k], n = tab[2 + 3 * k], at = tab[3 + 3 * k] + (int64_t)a * n;
-    const int32_t *src = (a == 0 ? a0 : a == 1 ? a1 : a == 2 ? a2 : a3) + start;
-    for (int64_t j = threadIdx.x; j < n; j += 256) dst[at + j] = src[j];
-}
-
 int chain_launch(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
                  const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
                  int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
                  void *d_work, size_t work_bytes, hipStream_t s)
 {
-    return chain_launch_split(n_calls, n_anchors, d_off, d_ax, d_ay, d_hdr, d_score, d_parent, d_target, d_peak, d_work, work_bytes, s, nullptr);
+    return chain_launch_skip(n_calls, n_anchors, d_off, d_ax, d_ay, d_hdr, d_score, d_parent, d_target, d_peak, d_work, work_bytes, s, nullptr);
 }
 
-int chain_launch_split(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
-                       const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
-                       int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
-                       void *d_work, size_t work_bytes, hipStream_t s, ChainSplit *split)
+int chain_launch_skip(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
+                      const uint64_t *d_ax, const uint64_t *d_ay, const gbx_chain_call *d_hdr,
+                      int32_t *d_score, int32_t *d_parent, int32_t *d_target, int32_t *d_peak,
+                      void *d_work, size_t work_bytes, hipStream_t s, const uint8_t *d_skip)
 {
     if (n_calls == 0) return GBX_OK;
     if (n_calls > 0x7fffffffLL - 1024) { set_error("chain: more than 2^31 calls"); return GBX_ERR_UNSUPPORTED; }
@@ -812,7 +790,7 @@ int chain_launch_split(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
     {
         Stage st("chain_order", s);
         hipLaunchKernelGGL(chain_jobs_kernel, dim3((unsigned)n_calls), dim3(256), 0, s, (int)n_calls, d_off, W,
-                           nosplit_env && atoi(nosplit_env) ? 0 : 1);
+                           nosplit_env && atoi(nosplit_env) ? 0 : 1, d_skip);
         const int ob = (int)((L.max_jobs + 255) / 256);
         hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, W, 0);
         hipLaunchKernelGGL(chain_order_kernel, dim3(ob), dim3(256), 0, s, W, 1);
@@ -842,32 +820,10 @@ int chain_launch_split(int64_t n_calls, int64_t n_anchors, const int64_t *d_off,
         const char *renv = getenv("GBX_CHAIN_RING");         // test / tuning aid: "short" or "long" for every job
         const int force = renv ? (renv[0] == 'l' ? 1 : renv[0] == 's' ? 0 : -1) : -1;
         hipLaunchKernelGGL(chain_pick_kernel, dim3(1), dim3(64), 0, s, W, (long long)n_anchors, cus, force);
-        int lo = 0;
-        if (split && split->top > 0) {
-            // the longest jobs: their table to the host, their launch (both instances, like the main one) and the gather of their
-            // results on the side stream, behind everything queued on `s` so far
-            const int top = split->top < CHAIN_SPLIT_MAX ? split->top : CHAIN_SPLIT_MAX;
-            hipLaunchKernelGGL(chain_top_kernel, dim3(1), dim3(64), 0, s, W, top, split->n_arrays, split->d_tab);
-            GBX_HIP(hipMemcpyAsync(split->h_tab, split->d_tab, (size_t)(1 + 3 * top) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            GBX_HIP(hipEventRecord(split->ev_fork, s));
-            GBX_HIP(hipStreamWaitEvent(split->side, split->ev_fork, 0));
-            hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3((unsigned)top), dim3(64), 0, split->side, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
-                               d_score, d_parent, d_target, d_peak, W, 6, 0, top);
-            hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3((unsigned)top), dim3(64), 0, split->side, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
-                               d_score, d_parent, d_target, d_peak, W, 6, 0, top);
-            hipLaunchKernelGGL(chain_top_gather_kernel, dim3((unsigned)top, (unsigned)split->n_arrays), dim3(256), 0, split->side, split->d_tab, split->n_arrays,
-                               split->src[0], split->src[1], split->src[2], split->src[3], split->d_packed);
-            GBX_HIP(hipEventRecord(split->ev_top, split->side));
-            lo = top;
-        }
         hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE>, dim3((unsigned)blocks_s), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
-                           d_score, d_parent, d_target, d_peak, W, 0, lo, 0x7fffffff);
+                           d_score, d_parent, d_target, d_peak, W);
         hipLaunchKernelGGL(chain_kernel<GBX_CHAIN_RING_LIVE_LONG>, dim3((unsigned)blocks_l), dim3(64), 0, s, (int)n_calls, d_off, d_ax, d_ay, d_hdr,
-                           d_score, d_parent, d_target, d_peak, W, 0, lo, 0x7fffffff);
-        if (lo) {
-            GBX_HIP(hipEventRecord(split->ev_rest, s));
-            GBX_HIP(hipEventSynchronize(split->ev_fork));          // the table is on the host
-        }
+                           d_score, d_parent, d_target, d_peak, W);
     }
     GBX_HIP(hipGetLastError());
     GBX_GUARD_CHECK("chain");

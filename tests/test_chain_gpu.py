@@ -145,10 +145,11 @@ def test_host_entry_staged_transfers(monkeypatch):
 
 
 @pytest.mark.parametrize("top", ["1", "5", "64"])
-def test_host_entry_longest_jobs_in_a_launch_of_their_own(top, monkeypatch):
-    """A large staged call runs its longest jobs in a launch of their own and downloads everything else meanwhile
-    (capi_chain.hip, ChainSplit; default from 4 Mi anchors on): forced onto small jobs here - every output array, with and
-    without the optional ones, a call list cut into many jobs, fewer calls than the split takes, small download pieces."""
+def test_host_entry_longest_calls_in_a_launch_of_their_own(top, monkeypatch):
+    """A large staged call uploads and launches its longest calls ahead of everything else, runs the rest as a second launch
+    and downloads that one's results while the longest calls are still at work (capi_chain.hip; default from 4 Mi anchors on):
+    forced onto small jobs here - every output array, with and without the optional ones, call lists that fall apart into
+    many jobs, fewer calls than the split takes, small download pieces."""
     monkeypatch.setenv("GBX_HOST_STAGE_MIN", "0")
     monkeypatch.setenv("GBX_CHAIN_SPLIT_MIN", "1")
     monkeypatch.setenv("GBX_CHAIN_SPLIT_TOP", top)
