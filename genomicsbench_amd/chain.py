@@ -9,17 +9,23 @@ import numpy as np
 from . import _native as N
 
 
-def chain_host(off, ax, ay, hdr, want_target=True, want_peak=True):
-    """gbx_chain_host -> (score, parent, target, peak) int32 arrays over the concatenated anchors."""
+def chain_host(off, ax, ay, hdr, want_target=True, want_peak=True, out=None):
+    """gbx_chain_host -> (score, parent, target, peak) int32 arrays over the concatenated anchors.
+    out: four int32 arrays of that length to write into (what a C driver hands over: memory that exists), instead of new ones."""
     off = np.ascontiguousarray(off, dtype=np.int64)
     ax = np.ascontiguousarray(ax, dtype=np.uint64)
     ay = np.ascontiguousarray(ay, dtype=np.uint64)
     hdr = np.ascontiguousarray(hdr, dtype=N.CHAIN_CALL_DTYPE)
     n = int(off[-1]) if len(off) else 0
-    score = np.zeros(n, dtype=np.int32)
-    parent = np.zeros(n, dtype=np.int32)
-    target = np.zeros(n, dtype=np.int32) if want_target else None
-    peak = np.zeros(n, dtype=np.int32) if want_peak else None
+    if out is not None:
+        score, parent, target, peak = out
+        for a in out:
+            assert a.dtype == np.int32 and a.flags.c_contiguous and len(a) == n
+    else:
+        score = np.zeros(n, dtype=np.int32)
+        parent = np.zeros(n, dtype=np.int32)
+        target = np.zeros(n, dtype=np.int32) if want_target else None
+        peak = np.zeros(n, dtype=np.int32) if want_peak else None
     N.check(N.lib().gbx_chain_host(len(off) - 1, N.ptr(off), N.ptr(ax), N.ptr(ay), N.ptr(hdr), N.ptr(score),
                                    N.ptr(parent), N.ptr(target), N.ptr(peak)))
     return score, parent, target, peak
