@@ -26,3 +26,14 @@ if "poa" in which:
     from genomicsbench_amd.datagen import gen_poa
     w = gen_poa(6000, 4001); p = make_params()
     timed("poa large (6000 windows) gbx_poa_consensus_host", lambda: consensus_host(p, w))
+if "abea" in which:
+    from genomicsbench_amd.abea import PAIR_DTYPE
+    from genomicsbench_amd.datagen import gen_abea
+    rs = gen_abea(int(os.environ.get("ABEA_READS", "4000")), 5001)
+    ev = rs.events_struct()
+    out = np.zeros(2 * max(int(rs.event_off[-1]), 1), dtype=PAIR_DTYPE)
+    out["ref_pos"][:] = -1
+    npairs = np.zeros(max(rs.n_reads, 1), dtype=np.int32)
+    timed("abea (%d reads, %d events) gbx_abea_align_host" % (rs.n_reads, int(rs.event_off[-1])), lambda: N.check(N.lib().gbx_abea_align_host(
+        rs.n_reads, N.ptr(rs.seq_off), N.ptr(rs.seq_len), N.ptr(rs.seq_arena), rs.seq_arena.size, N.ptr(rs.event_off), N.ptr(ev), N.ptr(rs.model),
+        N.ptr(rs.scale), N.ptr(rs.shift), N.ptr(out), N.ptr(npairs))))
