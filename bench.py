@@ -1394,13 +1394,13 @@ def main():
             torch.cuda.empty_cache()
             sub = argparse.Namespace(**vars(args))
             sub.size, sub.cpu_units = 0, 0                   # --size / --cpu-units speak about the headline kernel
-            others[kind] = run_kernel(kind, sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 1))
+            others[kind] = run_kernel(kind, sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 2))
         # BASELINE config 4 as written: ONE 'large' poa job (6000 windows) sharded over the N GPUs (strong)
         if world > 1 and args.mode != "local":
             torch.cuda.empty_cache()
             sub = argparse.Namespace(**vars(args))
             sub.size, sub.cpu_units, sub.no_cpu = 0, 0, True
-            st = run_kernel("poa", sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 1),
+            st = run_kernel("poa", sub, ctx, min(args.steps, args.other_steps), min(args.warmup, 2),
                             per_gpu_units=-(-PoaWork.large // world),
                             label="poa large: ONE job of %d windows sharded over %d GPUs by scatter / gather (BASELINE config 4)"
                                   % (-(-PoaWork.large // world) * world, world))
