@@ -1,5 +1,6 @@
 // capi_phmm.hip — phmm entries of the C-ABI (include/gbx.h).
 #include "capi_common.h"
+#include "phmm_split.h"
 
 using namespace gbx;
 
@@ -116,18 +117,34 @@ static int phmm_host_one(int64_t n_pairs, const int32_t *pair_read, const int32_
         (rc = dho.alloc(n_haps * 8)) || (rc = dhl.alloc(n_haps * 4)) || (rc = dh.alloc(hap_bytes)) ||
         (rc = dout.alloc(n_pairs * 8)) || (rc = dw.alloc(wb)))
         return rc;
-    HostPipe pipe(lane.l, (size_t)read_bytes * 5 + (size_t)hap_bytes + (size_t)n_pairs * 8 + (size_t)(n_reads + n_haps) * 12, false);
+    // A large staged call uploads in two stages: what the grouping passes of the launch read (pair lists, length tables, haplotypes:
+    // a fifth of the bytes) first, the reads' bases and four quality tracks behind - and the launch makes the stream wait for the
+    // second stage only where its first kernel needs it (phmm_split.h), so that the grouping (5 ms on 'large') runs under the upload.
+    // GBX_PHMM_UPLOAD_STAGES=1: one stage, as before.
+    const size_t up_bytes = (size_t)read_bytes * 5 + (size_t)hap_bytes + (size_t)n_pairs * 8 + (size_t)(n_reads + n_haps) * 12;
+    const bool two = up_bytes >= ((size_t)64 << 20) && !(getenv("GBX_PHMM_UPLOAD_STAGES") && atoi(getenv("GBX_PHMM_UPLOAD_STAGES")) == 1) &&
+                     !getenv("GBX_HOST_PAGEABLE");
+    HostPipe pipe(lane.l, up_bytes, two);
+    const bool staged2 = two && pipe.staged;
     if ((rc = pipe.prepare(1))) return rc;
+    if (staged2) pipe.upload_stages(2);
+    const int64_t s1 = staged2 ? 1 : 0;
     pipe.stage(0, dpr.p, pair_read, n_pairs * 4); pipe.stage(0, dph.p, pair_hap, n_pairs * 4);
     pipe.stage(0, dro.p, read_off, n_reads * 8); pipe.stage(0, drl.p, read_len, n_reads * 4);
-    pipe.stage(0, drs.p, rs, read_bytes); pipe.stage(0, dq.p, q, read_bytes); pipe.stage(0, di.p, i, read_bytes);
-    pipe.stage(0, dd.p, d, read_bytes); pipe.stage(0, dc.p, c, read_bytes);
     pipe.stage(0, dho.p, hap_off, n_haps * 8); pipe.stage(0, dhl.p, hap_len, n_haps * 4);
     pipe.stage(0, dh.p, hap, hap_bytes);
+    pipe.stage(s1, drs.p, rs, read_bytes); pipe.stage(s1, dq.p, q, read_bytes); pipe.stage(s1, di.p, i, read_bytes);
+    pipe.stage(s1, dd.p, d, read_bytes); pipe.stage(s1, dc.p, c, read_bytes);
     mark("device buffers ready");
     pipe.start();
     if ((rc = pipe.wait_stage(0))) return pipe.finish(rc);
-    mark("uploads queued");
+    mark(staged2 ? "first upload stage queued" : "uploads queued");
+    const std::function<int()> between = [&]() -> int {
+        const int r = pipe.wait_stage(1);
+        mark("uploads queued");
+        return r;
+    };
+    if (staged2) phmm_set_between(&between);
     rc = phmm_launch(n_pairs, dpr.as<int32_t>(), dph.as<int32_t>(), n_reads, dro.as<int64_t>(), drl.as<int32_t>(),
                      drs.as<uint8_t>(), dq.as<uint8_t>(), di.as<uint8_t>(), dd.as<uint8_t>(), dc.as<uint8_t>(),
                      dho.as<int64_t>(), dhl.as<int32_t>(), dh.as<uint8_t>(), max_h, dout.as<double>(), dw.p, wb,

@@ -33,6 +33,7 @@
 #include <mutex>
 #include <vector>
 #include "gbx_internal.h"
+#include "phmm_split.h"
 
 namespace gbx {
 namespace {
@@ -914,12 +915,17 @@ int phmm_init_tables() { DevTables t; return upload_tables(&t); }
 
 const float *phmm_host_mm_table_f(int *n) { if (n) *n = MM_USED; return host_tables().mm_f.data(); }
 
+static thread_local const std::function<int()> *t_phmm_between = nullptr;
+void phmm_set_between(const std::function<int()> *between) { t_phmm_between = between; }
+
 int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_hap,
                 int64_t n_reads, const int64_t *read_off, const int32_t *read_len,
                 const uint8_t *rs, const uint8_t *q, const uint8_t *qi, const uint8_t *qd, const uint8_t *qc,
                 const int64_t *hap_off, const int32_t *hap_len, const uint8_t *hap, int max_hap_len,
                 double *out, void *d_work, size_t work_bytes, hipStream_t s, int64_t stream_syms)
 {
+    const std::function<int()> *between = t_phmm_between;      // (phmm_split.h) this launch's, and only this launch's
+    t_phmm_between = nullptr;
     if (n_pairs == 0) return GBX_OK;
     if (n_pairs > 0x7fffffffLL - 1024 || n_reads > 0x7fffffffLL - 1024) {
         set_error("phmm: more than 2^31 pairs or reads in one call");
@@ -990,6 +996,8 @@ int phmm_launch(int64_t n_pairs, const int32_t *pair_read, const int32_t *pair_h
             hipLaunchKernelGGL(phmm_stream_copy_kernel, dim3((int)(want < cap_c ? want : cap_c)), dim3(256), 0, s, A, W);
         }
     }
+    // everything above reads the pair lists, the length tables and the haplotypes; from here on the reads' bases and qualities too
+    if (between) { const int brc = (*between)(); if (brc) return brc; }
     int dev_id = 0, cus = 256;
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
