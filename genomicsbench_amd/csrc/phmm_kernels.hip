@@ -574,7 +574,17 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
     const float zero = 0.f, one = 1.f;
     const bool top = hl == 0;
 
-    for (int slot = blockIdx.x; 2 * slot < ucnt; slot += gridDim.x) {
+    // Unit pairs are drawn from a cursor (the class's, zeroed with the workspace header), not strided over the grid: the seven
+    // kernels of a launch set become ready together, and when workgroups of a smaller class land on a CU first, some of this
+    // class's cannot become resident until those leave - with a fixed share of the units such a latecomer ends that much later
+    // (the launch set's slow mode: 145 against 175 ms for the same host call, profiles/r06zza_phmm_host_bimodal.txt); drawn from
+    // the cursor - longest streams first - it simply takes fewer.
+    int32_t *const ucursor = W.counts + 32 + cls;
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(ucursor, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (2 * slot >= ucnt) break;
         const int ui = 2 * slot + half;
         const bool have = ui < ucnt;
         // the unit: `cnt` grouped pairs from `first` on, all of read `rd`
