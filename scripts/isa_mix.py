@@ -8,7 +8,7 @@ Rate classes (scripts/valu_peak.hip on MI355X, 8 wavefronts per SIMD): `full` = 
 in their plain VOP1/VOP2 encodings), `quarter` = 8.2 (transcendentals), `half` = 4.17 (everything else: max/min/max3, v_lshlrev,
 compares, selects, bit-field ops, v_perm, every DPP and SDWA form, every packed and 64-bit form, fma, conversions, readlane).
 The mix is static (whole kernel, not weighted by trip counts): the kernels are unrolled row / column loops, so the static
-mix is dominated by the loop bodies.  Cross-compiles for gfx950; no GPU needed.
+mix is dominated by the loop bodies (phmm's stream kernels: the step bodies only - their per-unit set-up is large and rare).  Cross-compiles for gfx950; no GPU needed.
 
 usage: python scripts/isa_mix.py            (writes profiles/valu_mix.json)"""
 import collections
@@ -62,7 +62,19 @@ def main():
             dem = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip()
             dem = dem.replace("(anonymous namespace)::", "").replace("void ", "").replace("gbx::", "").split("(")[0]
             counts = collections.Counter()
-            for line in body.splitlines():
+            lines = body.splitlines()
+            if dem.startswith("phmm_stream_kernel"):
+                # the stream kernels' set-up per unit (the prior tables, thirty selects and LDS writes per lane, unrolled) is a third of
+                # their static instructions and a thousandth of the executed ones: the mix is that of the step bodies - the basic blocks
+                # that hold a step's FMAs - which is what the counters weigh
+                blocks, cur = [], []
+                for line in lines:
+                    if re.match(r"^\.LBB\d+_\d+:", line.strip()) or line.strip().startswith("; %bb."):
+                        blocks.append(cur); cur = []
+                    cur.append(line)
+                blocks.append(cur)
+                lines = [ln for b in blocks if sum(1 for x in b if x.strip().startswith("v_fmac_f32")) >= 2 * int(re.search(r"<(\d+)", dem).group(1)) for ln in b]
+            for line in lines:
                 t = line.strip()
                 if t.startswith("v_") and not t.startswith(("v_cmpx",)):
                     counts[rate_class(t.split()[0])] += 1
