@@ -1028,10 +1028,13 @@ def run_kernel(kind, args, ctx, steps, warmup, per_gpu_units=None, label=None):
         return None
 
     # ---- rank 0: the line
-    # the dominant kernel = the longest-running launch that had work (a launch whose class is empty still waits for its LDS)
+    # the dominant kernel = the longest-running launch among those that had a real share of the work (a launch whose class is empty
+    # still waits for its LDS; phmm's smaller classes live as long as the dominant one - they run in what it leaves free - with a
+    # fiftieth of its cells): at least a quarter of the largest launch's units
+    umax = max((work.roofline_bytes(n_)[1] or 0) for n_ in stages) if stages else 0
     for name, (ms_sum, launches) in sorted(stages.items(), key=lambda kv: -kv[1][0]):
         alg_bytes, k_units = work.roofline_bytes(name)
-        if k_units:
+        if k_units and k_units >= 0.25 * umax:
             break
     k_ms = ms_sum / max(launches, 1)
     # a job that runs as several launches of the same kernel per step (fmi: chunks of reads): bytes and units per launch
