@@ -579,12 +579,11 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
     // class's cannot become resident until those leave - with a fixed share of the units such a latecomer ends that much later
     // (the launch set's slow mode: 145 against 175 ms for the same host call, profiles/r06zza_phmm_host_bimodal.txt); drawn from
     // the cursor - longest streams first - it simply takes fewer.
+    // (a workgroup's first pair is its own index - a launch of a class without units, or with fewer pairs than workgroups, ends
+    // without touching the cursor: eight kernels x 5 000 workgroups of atomics on one cache line were 0.4 ms of a small job -, the
+    // cursor hands out the pairs from gridDim.x on)
     int32_t *const ucursor = W.counts + 32 + cls;
-    for (;;) {
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(ucursor, 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (2 * slot >= ucnt) break;
+    for (int slot = blockIdx.x; 2 * slot < ucnt;) {
         const int ui = 2 * slot + half;
         const bool have = ui < ucnt;
         // the unit: `cnt` grouped pairs from `first` on, all of read `rd`
@@ -779,6 +778,9 @@ __global__ void __launch_bounds__(64) phmm_stream_kernel(PhmmArgs A, PhmmWork W,
             __builtin_amdgcn_sched_barrier(0);
         }
         }
+        // the next pair: from the cursor
+        if (lane == 0) slot = (int)gridDim.x + atomicAdd(ucursor, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
     }
 }
 
